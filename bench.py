@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""bench.py -- ALS ratings/sec per iteration (U + I solve) on synthetic ratings of the
+shapes BASELINE.json names, one process per GPU.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload mal|c3|ml1m|ml100k] [--double]
+
+A "step" is one full ALS iteration = EmfLord.alsTrainIter(): the byUser half-step, the
+exchange of the solved user shard, the byItem half-step and its exchange.  Inputs (CSR by
+user and by item, both factor matrices) are resident in HBM before the timed region.  With
+N > 1 the total problem is fixed and rows are sharded over the ranks ("strong").
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline      -- the dominant kernel (als_gram_solve) against its binding roof, from HIP-event
+                   durations measured inside libycnr_als.so on the launch stream
+  cpu_baseline  -- the CPU oracle (a port of the reference algorithm) timed on a bounded row
+                   sample of the same workload on this box's host cores (N = 1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "you-can-not-recommend_amd", "python"))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+WORKLOADS = {
+    # name: users, items, nnz, k, max_rating, zipf_a, degree_sigma, description
+    "mal": (1_750_000, 12_700, 121_000_000, 100, 10, 0.6, 1.2, "MAL-scale synthetic 1.75Mx12.7K, 121M nnz, k=100"),
+    "c3": (200_000, 20_000, 20_000_000, 64, 10, 0.8, 1.0, "synthetic 200Kx20K, 20M nnz, k=64"),
+    "ml1m": (6040, 3883, 1_000_209, 100, 5, 0.9, 0.9, "MovieLens-1M-shaped synthetic 6040x3883, 1M nnz, k=100"),
+    "ml100k": (943, 1682, 100_000, 20, 5, 0.8, 0.9, "MovieLens-100k-shaped synthetic 943x1682, 100K nnz, k=20"),
+}
+
+PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector = fp32 MFMA peak
+PEAK_FP64_TFLOPS = 78.6
+PEAK_HBM_GBS = 8000.0     # spec; ~6300 achievable
+
+
+def algorithmic_flops(nnz, rows_solved, k):
+    """Minimum-flop model of one half-step: symmetric Gramian + rhs per rating,
+    Cholesky + two triangular solves per row."""
+    return nnz * (k * (k + 1) + 2 * k) + rows_solved * (k ** 3 / 3.0 + 2 * k * k)
+
+
+def algorithmic_bytes(nnz, rows_solved, k, s):
+    """Gather-model bytes of one half-step: index + value + gathered factor row
+    per rating, row write + row pointer per solved row."""
+    return nnz * (4 + s + k * s) + rows_solved * (k * s + 8)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="mal", choices=sorted(WORKLOADS))
+    ap.add_argument("--double", action="store_true", help="useDoublePrecision")
+    ap.add_argument("--chunk", type=int, default=0, help="ratings per split work unit (0 = library default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the baseline sample")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from ycnr_als.data import synth_ratings
+    from ycnr_als.emf import Dataset, EmfLord
+    users, items, nnz_target, k, max_rating, zipf_a, sigma, desc = WORKLOADS[args.workload]
+    dev = torch.device("cuda", local_rank)
+    t0 = time.time()
+    tdt = torch.float64 if args.double else torch.float32
+    by_user, by_item = synth_ratings(users, items, nnz_target, max_rating=max_rating, seed=20260004, device=dev,
+                                     dtype=tdt, degree_sigma=sigma, zipf_a=zipf_a)
+    nnz = by_user.nnz
+    torch.cuda.synchronize()
+    t_gen = time.time() - t0
+    # in-sample RMSE set: every 10th rating of each... keep it simple: a 10 % Bernoulli sample
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    from ycnr_als.data import select_csr
+    val = select_csr(by_user, torch.rand(nnz, generator=g, device=dev) < 0.10)
+    ds = Dataset(by_user, by_item, validate=val, test=None, total_ratings_avg=float(by_user.vals.double().mean()))
+    lord = EmfLord(options={"factorsCount": k, "trainIters": args.steps, "useDoublePrecision": args.double,
+                            "dbType": "mal" if max_rating == 10 else "ml", "chunkRatings": args.chunk,
+                            "dataSetDistr": [90, 10, 0]}, dist=dist)
+    lord.prepareToTrain(ds, seed=20260004, device=local_rank)
+    t_prep = time.time() - t0 - t_gen
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        lord.alsTrainIter()
+    lord.stepTimes.clear()
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        lord.alsTrainIter()
+    barrier()
+    elapsed = time.perf_counter() - t1
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = nnz * args.steps / elapsed
+
+    # dominant kernel: als_gram_solve, both launches (byUser + byItem) of every timed iteration
+    s = 8 if args.double else 4
+    kern_ms = {"byUser": 0.0, "byItem": 0.0}
+    red_ms = {"byUser": 0.0, "byItem": 0.0}
+    flops = 0.0
+    abytes = 0.0
+    launches = 0
+    for st in lord.stepTimes:
+        info = st["info"]
+        kern_ms[st["stepType"]] += info.gramSolveMs
+        red_ms[st["stepType"]] += info.reduceSolveMs
+        flops += algorithmic_flops(info.ratings, info.rows, k)
+        abytes += algorithmic_bytes(info.ratings, info.rows, k, s)
+        launches += 1
+    kern_total_ms = kern_ms["byUser"] + kern_ms["byItem"]
+    peak = PEAK_FP64_TFLOPS if args.double else PEAK_FP32_TFLOPS
+    achieved_tflops = flops / (kern_total_ms * 1e-3) / 1e12 if kern_total_ms > 0 else 0.0
+    roofline = {
+        "bound": "mfma", "kernel": "als_gram_solve_kernel", "achieved": round(achieved_tflops, 3), "peak": peak,
+        "unit": "TFLOP/s", "frac": round(achieved_tflops / peak, 4), "traffic": None,
+        "launches": launches, "avg_launch_ms": round(kern_total_ms / max(launches, 1), 4),
+        "flops_model": "k(k+1)+2k per rating + k^3/3+2k^2 per row (symmetric Gramian + Cholesky)",
+        # the HBM roof beside it (gather-model algorithmic bytes over the same kernel time)
+        "hbm_achieved_GBs": round(abytes / (kern_total_ms * 1e-3) / 1e9, 1) if kern_total_ms > 0 else 0.0,
+        "hbm_peak_GBs": PEAK_HBM_GBS,
+        "hbm_frac": round(abytes / (kern_total_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if kern_total_ms > 0 else 0.0,
+        "per_step_ms": {"byUser_gram_solve": round(kern_ms["byUser"] / args.steps, 3),
+                        "byItem_gram_solve": round(kern_ms["byItem"] / args.steps, 3),
+                        "byUser_reduce_solve": round(red_ms["byUser"] / args.steps, 3),
+                        "byItem_reduce_solve": round(red_ms["byItem"] / args.steps, 3)},
+    }
+
+    rmse = lord.calcRmse("rmseValidate", False)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(lord, by_user, by_item, k, args)
+
+    if rank == 0:
+        out = {
+            "metric": "ALS ratings/sec per iteration (U+I solve)", "value": value, "unit": "ratings/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64" if args.double else "f32", "data": "synthetic",
+            "config": {"workload": desc, "users": users, "items": items, "nnz": nnz, "factorsCount": k,
+                       "lambda": 0.05, "parallelism": f"row-shard x{world} + all-gather" if world > 1 else "1 GPU"},
+            "rmse_in_sample_after_iters": rmse, "iters_run": args.steps + args.warmup,
+            "roofline": roofline, "cpu_baseline": cpu,
+            "setup_s": {"generate": round(t_gen, 2), "prepare": round(t_prep, 2)},
+        }
+        print(json.dumps(out), flush=True)
+    lord.destroy()
+    if dist:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(lord, by_user, by_item, k, args):
+    """Time the CPU oracle (kind 'port': a structure-faithful restatement of
+    EmfWorker.mw_calcTrainAlsPortion) on a bounded, contiguous row sample of both half-steps,
+    with the same factor matrices the GPU run ended with.  ratings/s of a full iteration is
+    extrapolated as 1 / (1/rate_user + 1/rate_item)."""
+    from oracle import oracle as orc
+    orc.build()
+    cores = os.cpu_count() or 1
+    dt = np.float64 if args.double else np.float32
+    U = lord.backend.get_factors(0)
+    V = lord.backend.get_factors(1)
+    # rough speed model to size the sample: ~1.5 GFLOP/s per core for the scalar port
+    budget = args.cpu_seconds * 0.5 * 1.5e9 * cores
+
+    def sample(csr, fixed, solved, lam):
+        rp = csr.rowPtr.cpu().numpy()
+        cnt = rp[1:] - rp[:-1]
+        cost = np.cumsum(cnt * (2.0 * k * k + 2 * k) + (cnt > 0) * (2.0 / 3 * k ** 3 + 2 * k * k))
+        rows = int(np.searchsorted(cost, budget)) + 1
+        rows = max(1, min(rows, csr.rows))
+        e = int(rp[rows])
+        indx = csr.indx[:e].cpu().numpy()
+        vals = csr.vals[:e].cpu().numpy().astype(dt)
+        out = solved.copy()
+        t = time.perf_counter()
+        n = orc.als_step_csr(lam, k, np.ascontiguousarray(rp[:rows + 1]), indx, vals, fixed, out, 0, rows, threads=cores)
+        return n, time.perf_counter() - t, rows
+
+    nu, tu, ru = sample(by_user, V, U, 0.05)
+    ni, ti, ri = sample(by_item, U, V, 0.05)
+    rate_u, rate_i = nu / tu, ni / ti
+    return {"value": 1.0 / (1.0 / rate_u + 1.0 / rate_i), "unit": "ratings/s", "cores": cores, "kind": "port",
+            "sample": f"first {ru} user rows ({nu} ratings, {tu:.1f} s) + first {ri} item rows ({ni} ratings, {ti:.1f} s) "
+                      f"of the same workload, OpenMP over rows; extrapolated to a full iteration",
+            "rate_byUser": rate_u, "rate_byItem": rate_i}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,190 @@
+/*
+ * ycnr_als.h -- C ABI of libycnr_als.so, the MI355X (gfx950) replacement for the
+ * per-iteration ALS user/item factor solve of ukrbublik/You-Can-Not-Recommend.
+ *
+ * Every entry point names the reference interface it replaces (paths relative to the
+ * reference repo).  Plain pointers and sizes only; no C++ or torch types cross this
+ * boundary.  All functions are synchronous unless named *_async, are not re-entrant per
+ * handle, never abort(), and return 0 / a non-negative count on success or a negative
+ * YCNR_ERR_* code, with a human-readable message available from ycnr_last_error().
+ *
+ * Two levels:
+ *   level 1 -- portion ops on caller-owned HOST buffers: bit-for-bit the argument meaning
+ *              of EmfWorker.mw_calcTrainAlsPortion / mw_calcRmsePortion;
+ *   level 2 -- a resident trainer that keeps CSR ratings and both factor matrices in HBM
+ *              and runs whole half-steps (EmfLord.alsTrainStep) and RMSE passes.
+ *
+ * The reference's native boundary is the node-gyp addon cpp_utils (binding.gyp:3-16,
+ * cpp_utils/cpp_utils.cc:3-8) with s/d-prefixed functions over typed arrays
+ * (cpp_utils/cpp_utils.js:15-19); the same s/d naming is kept here.
+ */
+#ifndef YCNR_ALS_H
+#define YCNR_ALS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YCNR_ALS_ABI_VERSION 1
+
+/* error codes */
+#define YCNR_OK 0
+#define YCNR_ERR_INVALID (-1)     /* bad argument: null pointer, k out of range, index >= rows ... */
+#define YCNR_ERR_HIP (-2)         /* a HIP runtime call failed (message carries hipGetErrorString) */
+#define YCNR_ERR_NOMEM (-3)       /* host or device allocation failed */
+#define YCNR_ERR_UNSUPPORTED (-4) /* valid request this build cannot serve (e.g. factorsCount > 128) */
+#define YCNR_ERR_NUMERIC (-5)     /* a row's normal matrix was not positive definite (NaN/Inf input) */
+#define YCNR_ERR_STATE (-6)       /* call order violated (e.g. step before set_ratings) */
+
+/* stepType of EmfLord.alsTrainStep(stepType), lib/emf/EmfLord.js:963: 'byUser' | 'byItem' */
+#define YCNR_BY_USER 0
+#define YCNR_BY_ITEM 1
+/* options.useDoublePrecision, lib/emf/EmfBase.js:112,174-182 */
+#define YCNR_F32 0
+#define YCNR_F64 1
+/* where a caller's buffer lives */
+#define YCNR_MEM_HOST 0
+#define YCNR_MEM_DEVICE 1
+/* stepType of EmfLord.calcRmse(stepType, ...), lib/emf/EmfLord.js:1043: 'rmseValidate' | 'rmseTest' */
+#define YCNR_RMSE_VALIDATE 0
+#define YCNR_RMSE_TEST 1
+
+/* Message of the last failing call on this thread ("" if none). */
+const char *ycnr_last_error(void);
+/* YCNR_ALS_ABI_VERSION the library was built with. */
+int ycnr_version(void);
+/* Number of visible HIP devices, or YCNR_ERR_HIP. Does not create a context. */
+int ycnr_device_count(void);
+
+/* ------------------------------------------------------------------ level 1: portion ops
+ *
+ * ycnr_{s,d}AlsCalcPortion replaces the body of EmfWorker.mw_calcTrainAlsPortion,
+ * lib/emf/EmfWorker.js:176-251, for one portion buffer:
+ *   lambda        als.userFactReg / als.itemFactReg of the step (EmfWorker.js:180-181);
+ *                 applied as lambda * cols on the diagonal (EmfWorker.js:233-235)
+ *   k             options.factorsCount
+ *   alsRows       Int32 [nRows, rowId0, cols0, rowId1, cols1, ...]   (EmfMaster.js:597-598,609)
+ *   alsIndx       Int32 column ids, rows concatenated                 (EmfMaster.js:590)
+ *   alsVals       Float32/64 ratings, rows concatenated               (EmfMaster.js:589)
+ *   fixedFactors  [fixedRows x k] row-major: the opposite side (item factors for 'byUser');
+ *                 read only (EmfBase.copySubFixedFactors, EmfBase.js:537-555)
+ *   solvedFactors [solvedRows x k] row-major: row rowId is overwritten in place
+ *                 (EmfBase.getLatentFactorsPartData, EmfBase.js:518-532); other rows untouched
+ * Buffers are borrowed for the duration of the call (as cpp_utils/als_utils.cc:4-20 does).
+ * Unlike the reference, ids are bounds-checked (YCNR_ERR_INVALID) and rows recorded with
+ * cols == 0 are skipped instead of solving a singular system.
+ * Returns ratingsInPortion (the 'completedPortion' message field, EmfWorker.js:257) or < 0. */
+int64_t ycnr_sAlsCalcPortion(double lambda, int k, const int32_t *alsRows, const int32_t *alsIndx,
+                             const float *alsVals, const float *fixedFactors, int64_t fixedRows,
+                             float *solvedFactors, int64_t solvedRows);
+int64_t ycnr_dAlsCalcPortion(double lambda, int k, const int32_t *alsRows, const int32_t *alsIndx,
+                             const double *alsVals, const double *fixedFactors, int64_t fixedRows,
+                             double *solvedFactors, int64_t solvedRows);
+
+/* ycnr_{s,d}RmsePortion replaces EmfWorker.mw_calcRmsePortion, lib/emf/EmfWorker.js:266-315:
+ * pred = userFactors[u] . itemFactors[i] + globalAvgShift (EmfBase._alsPredict, EmfBase.js:825-827);
+ * out = {rSumDiff2, rCnt, rSum} accumulated in double (EmfWorker.js:297-299). */
+int ycnr_sRmsePortion(int k, const int32_t *rmseRows, const int32_t *rmseIndx, const float *rmseVals,
+                      const float *userFactors, int64_t usersRows, const float *itemFactors,
+                      int64_t itemsRows, double globalAvgShift, double *out3);
+int ycnr_dRmsePortion(int k, const int32_t *rmseRows, const int32_t *rmseIndx, const double *rmseVals,
+                      const double *userFactors, int64_t usersRows, const double *itemFactors,
+                      int64_t itemsRows, double globalAvgShift, double *out3);
+
+/* ------------------------------------------------------------------ level 2: resident trainer */
+
+typedef struct ycnr_als ycnr_als; /* opaque; owns device memory (cf. createSharedFactors, EmfBase.js:399-425) */
+
+/* The subset of EmfBase.DefaultOptions (lib/emf/EmfBase.js:52-140) and stats
+ * (EmfBase.js:142-169) the path depends on. */
+typedef struct ycnr_als_options {
+  int32_t struct_size;     /* = sizeof(ycnr_als_options) */
+  int32_t device;          /* HIP device ordinal (one process per GPU: LOCAL_RANK) */
+  int32_t dtype;           /* YCNR_F32 | YCNR_F64 = options.useDoublePrecision */
+  int32_t factorsCount;    /* options.factorsCount, 1..128 in this build */
+  int64_t totalUsersCount; /* stats.totalUsersCount = max user id (EmfLord.js:81) */
+  int64_t totalItemsCount; /* stats.totalItemsCount = max item id (EmfLord.js:82) */
+  double userFactReg;      /* options.als.userFactReg (EmfBase.js:67) */
+  double itemFactReg;      /* options.als.itemFactReg (EmfBase.js:69) */
+  int32_t chunkRatings;    /* ratings per work unit for split rows; 0 = default */
+  int32_t flags;           /* reserved, 0 */
+} ycnr_als_options;
+
+/* Timing / accounting of the last ycnr_als_step, measured with HIP events on the
+ * handle's stream around each kernel (DESIGN.md "Measurement"). */
+typedef struct ycnr_als_step_info {
+  int32_t struct_size;
+  int32_t side;
+  int64_t rows;          /* rows solved (rows with >= 1 rating in the local shard) */
+  int64_t ratings;       /* ratings consumed */
+  int64_t units;         /* wave-level work units launched by the Gramian kernel */
+  int64_t splitRows;     /* rows whose Gramian was split over several units */
+  float gramSolveMs;     /* als_gram_solve kernel (dominant) */
+  float reduceSolveMs;   /* als_reduce_solve kernel (split rows), 0 if not launched */
+  float totalMs;         /* first kernel start -> last kernel end */
+  int32_t numericErrors; /* rows whose matrix was not positive definite */
+} ycnr_als_step_info;
+
+int ycnr_als_create(const ycnr_als_options *opts, ycnr_als **out);
+/* Frees all device memory of the handle (cf. detachSharedFactors, EmfBase.js:351-376). */
+int ycnr_als_destroy(ycnr_als *h);
+
+/* Use an existing hipStream_t (e.g. torch's current stream) for all work of the handle;
+ * NULL restores the handle's own stream. */
+int ycnr_als_set_stream(ycnr_als *h, void *hipStream);
+
+/* Ratings of one side in CSR form, replacing the per-portion SQL fetch + packer
+ * (EmfMaster.m_fetchPortionTrainAlsOrRmse / m_processFetchedPortionAlsOrRmse,
+ * lib/emf/EmfMaster.js:501-614) by a one-time upload:
+ *   side       YCNR_BY_USER: rows = users, indx = item ids; YCNR_BY_ITEM: rows = items, indx = user ids
+ *   rowPtr     int64[totalRows + 1] offsets into indx / vals (ids 0-based = db id - 1, EmfMaster.js:584-586)
+ *   vals       float or double per options.dtype
+ *   rowBegin,rowEnd  the shard [rowBegin, rowEnd) this handle solves (whole matrix: 0, totalRows);
+ *              only that slice of indx / vals is copied to the device
+ *   memKind    YCNR_MEM_HOST or YCNR_MEM_DEVICE for all three arrays
+ * Column ids are validated against the opposite side's row count. */
+int ycnr_als_set_ratings(ycnr_als *h, int side, const int64_t *rowPtr, const int32_t *indx,
+                         const void *vals, int64_t rowBegin, int64_t rowEnd, int memKind);
+
+/* Ratings for an RMSE pass (always by user; dataset_type 2 / 3 rows of
+ * EmfMaster.js:502-503), same layout as above. */
+int ycnr_als_set_rmse_ratings(ycnr_als *h, int which, const int64_t *rowPtr, const int32_t *indx,
+                              const void *vals, int64_t rowBegin, int64_t rowEnd, int memKind);
+
+/* Whole factor matrix in / a row range out, in the reference's layout: dense row-major
+ * [rows x factorsCount] of float/double = the raw content of the user_factors /
+ * item_factors files (EmfBase.js:384-390, EmfManager.js:241-255). */
+int ycnr_als_set_factors(ycnr_als *h, int side, const void *src, int memKind);
+int ycnr_als_get_factors(ycnr_als *h, int side, void *dst, int64_t rowBegin, int64_t rowCount,
+                         int memKind);
+/* Borrowed device pointer of a side's matrix, so the host harness can all-gather shards in
+ * place with RCCL (replaces 'alsSaveCalcedFactors' streaming, EmfMaster.js:711-723). */
+int ycnr_als_factors_ptr(ycnr_als *h, int side, void **devicePtr);
+/* Adopt caller-owned device memory ([rows x k], e.g. a torch tensor) as a side's matrix. */
+int ycnr_als_bind_factors(ycnr_als *h, int side, void *devicePtr);
+
+/* One half-step = EmfLord.alsTrainStep(stepType), lib/emf/EmfLord.js:963-984: every local
+ * row with >= 1 rating is re-solved against the CURRENT opposite factors and written in
+ * place; rows without ratings are untouched.  Returns after the stream has drained. */
+int ycnr_als_step(ycnr_als *h, int side);
+/* Enqueue only; pair with ycnr_als_sync before reading results or step info. */
+int ycnr_als_step_async(ycnr_als *h, int side);
+int ycnr_als_sync(ycnr_als *h);
+int ycnr_als_last_step_info(ycnr_als *h, ycnr_als_step_info *info);
+
+/* RMSE partial sums = EmfLord.calcRmse / EmfWorker.mw_calcRmsePortion
+ * (lib/emf/EmfLord.js:1043-1081, EmfWorker.js:266-315) over the local rows of set `which`:
+ *   nPortions, portionRowEnd[p]  exclusive 0-based upper row of portion p (ascending, clipped to
+ *              the local shard), so the caller can reproduce the reference's per-portion
+ *              reduce including predAvg = LAST portion's rSum / rCnt (EmfMaster.js:779);
+ *              nPortions == 0: one portion covering the shard
+ *   out        double[3 * max(nPortions,1)] = {rSumDiff2, rCnt, rSum} per portion */
+int ycnr_als_rmse(ycnr_als *h, int which, double globalAvgShift, int nPortions,
+                  const int64_t *portionRowEnd, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YCNR_ALS_H */

@@ -1,0 +1,407 @@
+// als_kernels.hip.h -- CDNA4 (gfx950) device code of the ALS half-step.
+//
+// What one row of a half-step computes (reference: EmfWorker.mw_calcTrainAlsPortion,
+// lib/emf/EmfWorker.js:214-248):
+//     Y = fixed[indx[0..n), :]            gather        (EmfBase.js:537-555)
+//     A = Y^T Y + (lambda*n) I            k x k         (EmfWorker.js:231-235)
+//     b = Y^T r                           k             (EmfWorker.js:238-245)
+//     x = A^-1 b -> solved[row, :]        in place      (EmfWorker.js:246-247)
+//
+// Mapping to the machine (DESIGN.md has the full account):
+//  * One 64-lane wavefront owns one work unit = a row, or a chunk of a heavy row.
+//  * The Gramian is accumulated on the matrix cores with v_mfma_f32_16x16x4_f32
+//    (v_mfma_f64_16x16x4_f64 in double mode): exact IEEE fma chains, no reduced
+//    precision.  k is padded to NB*16; only the NB*(NB+1)/2 upper 16x16 tiles are
+//    kept, all of them in the wave's accumulator registers.
+//  * The gathered factor rows are read straight from global memory in MFMA operand
+//    layout: lane l holds Y[n0 + (l>>4)][16*cb + (l&15)], which is at once the
+//    A operand of tile row cb and the B operand of tile column cb, so 4 ratings cost
+//    NB loads and NB*(NB+1)/2 MFMAs.  No LDS staging is needed at this ratio.
+//  * b is accumulated beside it on the VALU from the same operand registers.
+//  * Rows that fit one unit are solved by the same wave (Cholesky in LDS); split rows
+//    write partial tiles to a slab and als_reduce_solve sums them in a fixed order,
+//    so results do not depend on how many GPUs or workgroups took part.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ycnr {
+
+// A wave-level work unit: ratings [beg, end) of the local CSR belong to `row`.
+// slab < 0: the unit covers the whole row and solves it; else it writes partial
+// sums to slab number `slab`.
+struct Unit {
+  int64_t beg;
+  int64_t end;
+  int32_t row;
+  int32_t slab;
+};
+
+// A row whose Gramian was split over nslabs units (slab0 .. slab0+nslabs-1).
+struct SplitRow {
+  int64_t n;  // ratings of the row (for lambda * n)
+  int32_t row;
+  int32_t slab0;
+  int32_t nslabs;
+  int32_t pad;
+};
+
+struct ErrInfo {
+  int32_t count;     // rows with a non-positive pivot
+  int32_t firstRow;  // one of them
+};
+
+template <typename T>
+struct MfmaTraits;
+
+template <>
+struct MfmaTraits<float> {
+  typedef float acc_t __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  // C/D layout: col = lane & 15, row = 4*(lane>>4) + reg
+  static __device__ __forceinline__ int cd_row(int lane, int reg) { return ((lane >> 4) << 2) + reg; }
+};
+
+template <>
+struct MfmaTraits<double> {
+  typedef double acc_t __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  // f64 C/D layout differs: col = lane & 15, row = (lane>>4) + 4*reg
+  static __device__ __forceinline__ int cd_row(int lane, int reg) { return (lane >> 4) + (reg << 2); }
+};
+
+__host__ __device__ constexpr int tile_count(int nb) { return nb * (nb + 1) / 2; }
+__host__ __device__ constexpr int tile_index(int bi, int bj, int nb) {
+  return bi * nb - bi * (bi - 1) / 2 + (bj - bi);
+}
+// elements of T one split unit writes: NT tiles x 4 regs x 64 lanes + NB b-partials x 64 lanes
+__host__ __device__ constexpr int64_t slab_elems(int nb) { return (int64_t)(tile_count(nb) * 4 + nb) * 64; }
+
+template <typename T>
+__device__ __forceinline__ T wave_shfl_xor(T v, int mask);
+template <>
+__device__ __forceinline__ float wave_shfl_xor<float>(float v, int mask) { return __shfl_xor(v, mask, 64); }
+template <>
+__device__ __forceinline__ double wave_shfl_xor<double>(double v, int mask) { return __shfl_xor(v, mask, 64); }
+
+template <typename T, int NB>
+struct Gram {
+  using Tr = MfmaTraits<T>;
+  using acc_t = typename Tr::acc_t;
+  static constexpr int NT = tile_count(NB);
+  static constexpr int KP = NB * 16;
+
+  // Operand registers for 4 consecutive ratings: lane (g = l>>4, c = l&15) reads
+  // row[16*cb + c] for every column block cb, where row is the gathered factor row of its
+  // rating, or a row of zeros when the rating index is past the unit's end (branch-free).
+  // Only the last block can run past k: those lanes read a zero instead.
+  static __device__ __forceinline__ void load_y(T (&y)[NB], const T *__restrict__ row,
+                                                const T *__restrict__ zeros, int k, int c) {
+#pragma unroll
+    for (int cb = 0; cb < NB - 1; ++cb) y[cb] = row[cb * 16 + c];
+    const int col = (NB - 1) * 16 + c;
+    const T *plast = col < k ? row + col : zeros;  // select the address, not the loaded value
+    y[NB - 1] = *plast;
+  }
+
+  static __device__ __forceinline__ void mma_step(acc_t (&acc)[NT], T (&bacc)[NB], const T (&y)[NB], T r) {
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) bacc[cb] = fma(y[cb], r, bacc[cb]);
+#pragma unroll
+    for (int bi = 0; bi < NB; ++bi) {
+#pragma unroll
+      for (int bj = bi; bj < NB; ++bj) {
+        acc[tile_index(bi, bj, NB)] = Tr::mma(y[bi], y[bj], acc[tile_index(bi, bj, NB)]);
+      }
+    }
+  }
+
+  // acc += Y^T Y (upper tiles), bacc += per-lane-group partials of Y^T r over ratings [beg, end).
+  // Two-deep software pipeline: indices two steps ahead, operands one step ahead of the MFMAs.
+  static __device__ __forceinline__ void accumulate(acc_t (&acc)[NT], T (&bacc)[NB],
+                                                    const int32_t *__restrict__ indx,
+                                                    const T *__restrict__ vals,
+                                                    const T *__restrict__ fixed,
+                                                    const T *__restrict__ zeros, int k, int64_t beg,
+                                                    int64_t end, int lane) {
+    const int g = lane >> 4, c = lane & 15;
+    const int64_t nsteps = (end - beg + 3) >> 2;
+    const int64_t last = end - 1;
+    // (index, rating, row pointer) of this lane group's rating in a step; past-the-end
+    // ratings read the last valid entry but point at the zero row and carry rating 0
+    int64_t n = beg + g;
+    int64_t nc = n < end ? n : last;
+    const T *row0 = n < end ? fixed + (int64_t)indx[nc] * k : zeros;
+    T rv = vals[nc];
+    T r0 = n < end ? rv : T(0);
+    n += 4;
+    nc = n < end ? n : last;
+    int32_t id1 = indx[nc];
+    rv = vals[nc];
+    T r1 = n < end ? rv : T(0);
+    bool v1 = n < end;
+    T yA[NB], yB[NB];
+    load_y(yA, row0, zeros, k, c);
+    for (int64_t i = 0; i < nsteps; ++i) {
+      const T *row1 = v1 ? fixed + (int64_t)id1 * k : zeros;
+      load_y(yB, row1, zeros, k, c);  // operands of step i+1
+      const T ra = r0;
+      r0 = r1;
+      n += 4;  // indices of step i+2
+      nc = n < end ? n : last;
+      v1 = n < end;
+      id1 = indx[nc];
+      rv = vals[nc];
+      r1 = v1 ? rv : T(0);
+      mma_step(acc, bacc, yA, ra);
+#pragma unroll
+      for (int cb = 0; cb < NB; ++cb) yA[cb] = yB[cb];
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------------------
+// Solve (A + lam I) x = b for one row, A given as upper MFMA tiles in registers.
+// Version 1: dump to LDS, right-looking Cholesky A = U^T U by one wave with b carried as
+// column k (so the forward substitution is part of the factorisation), then a
+// column-oriented back substitution.  S is [KP][LD], LD = KP + 1 (odd: conflict-free
+// row and column sweeps); only the upper triangle and column k are used.
+template <typename T, int NB>
+struct SolveLds {
+  using Tr = MfmaTraits<T>;
+  using acc_t = typename Tr::acc_t;
+  static constexpr int NT = tile_count(NB);
+  static constexpr int KP = NB * 16;
+  static constexpr int LD = KP + 1;
+  static constexpr size_t lds_bytes() { return sizeof(T) * (size_t)KP * LD; }
+
+  static __device__ __forceinline__ void run(const acc_t (&acc)[NT], const T (&bacc)[NB], T *S, int k,
+                                             T lam, T *__restrict__ out_row, int row, ErrInfo *err,
+                                             int lane) {
+    const int g = lane >> 4, c = lane & 15;
+#pragma unroll
+    for (int bi = 0; bi < NB; ++bi) {
+#pragma unroll
+      for (int bj = bi; bj < NB; ++bj) {
+        const acc_t a = acc[tile_index(bi, bj, NB)];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) S[(bi * 16 + Tr::cd_row(lane, t)) * LD + bj * 16 + c] = a[t];
+      }
+    }
+    __syncthreads();
+    // b: sum the four lane-group partials; group 0 stores b[16*cb + c] into column k
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) {
+      T v = bacc[cb];
+      v += wave_shfl_xor<T>(v, 16);
+      v += wave_shfl_xor<T>(v, 32);
+      const int i = cb * 16 + c;
+      if (g == 0 && i < k) S[i * LD + k] = v;
+    }
+    for (int i = lane; i < k; i += 64) S[i * LD + i] += lam;
+    __syncthreads();
+
+    bool bad = false;
+    for (int p = 0; p < k; ++p) {
+      T d = S[p * LD + p];
+      if (!(d > T(0))) {
+        bad = true;
+        d = T(1);
+      }
+      const T rs = T(1) / sqrt(d);
+      const int c0 = p + 1 + lane, c1 = c0 + 64;
+      T u0 = T(0), u1 = T(0);
+      if (c0 <= k) {
+        u0 = S[p * LD + c0] * rs;
+        S[p * LD + c0] = u0;
+      }
+      if (c1 <= k) {
+        u1 = S[p * LD + c1] * rs;
+        S[p * LD + c1] = u1;
+      }
+      if (lane == 0) S[p * LD + p] = rs;  // keep 1/U[p][p]
+      __syncthreads();
+      for (int r = p + 1; r < k; ++r) {
+        const T ur = S[p * LD + r];
+        if (c0 >= r && c0 <= k) S[r * LD + c0] -= ur * u0;
+        if (c1 >= r && c1 <= k) S[r * LD + c1] -= ur * u1;
+      }
+      __syncthreads();
+    }
+    // back substitution, x overwrites column k
+    for (int p = k - 1; p >= 0; --p) {
+      const T x = S[p * LD + k] * S[p * LD + p];
+      __syncthreads();
+      if (lane == 0) S[p * LD + k] = x;
+      for (int r = lane; r < p; r += 64) S[r * LD + k] -= S[r * LD + p] * x;
+      __syncthreads();
+    }
+    for (int i = lane; i < k; i += 64) out_row[i] = S[i * LD + k];
+    if (bad && lane == 0) {
+      atomicAdd(&err->count, 1);
+      err->firstRow = row;
+    }
+  }
+};
+
+template <typename T>
+struct StepArgs {
+  const Unit *units;
+  const SplitRow *split;
+  const int32_t *indx;
+  const T *vals;
+  const T *fixed;  // opposite side's factors, [fixedRows x k]
+  const T *zeros;  // >= 128 zeros: the "row" gathered for ratings past a unit's end
+  T *solved;       // this side's factors, [rows x k], rows written in place
+  T *slabs;
+  ErrInfo *err;
+  double lambda;
+  int32_t k;
+};
+
+// Kernel 1 (dominant): one wave per unit -- gather + Gramian + rhs, then either the row's
+// solve or a partial slab.
+template <typename T, int NB>
+__global__ __launch_bounds__(64) void als_gram_solve_kernel(StepArgs<T> a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using G = Gram<T, NB>;
+  using acc_t = typename G::acc_t;
+  const int lane = threadIdx.x;
+  const Unit u = a.units[blockIdx.x];
+  acc_t acc[G::NT];
+  T bacc[NB];
+#pragma unroll
+  for (int t = 0; t < G::NT; ++t) acc[t] = acc_t{T(0), T(0), T(0), T(0)};
+#pragma unroll
+  for (int cb = 0; cb < NB; ++cb) bacc[cb] = T(0);
+  G::accumulate(acc, bacc, a.indx, a.vals, a.fixed, a.zeros, a.k, u.beg, u.end, lane);
+  if (u.slab >= 0) {
+    T *s = a.slabs + (int64_t)u.slab * slab_elems(NB) + lane;
+#pragma unroll
+    for (int t = 0; t < G::NT; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[(t * 4 + r) * 64] = acc[t][r];
+    }
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) s[(G::NT * 4 + cb) * 64] = bacc[cb];
+    return;
+  }
+  // lambda.diagonal(_lambda * _n): the product is formed in double and rounded to T once
+  const T lam = (T)(a.lambda * (double)(u.end - u.beg));
+  SolveLds<T, NB>::run(acc, bacc, reinterpret_cast<T *>(smem), a.k, lam,
+                       a.solved + (int64_t)u.row * a.k, u.row, a.err, lane);
+}
+
+// Kernel 2: one wave per split row -- sum its slabs in slab order, then solve.
+template <typename T, int NB>
+__global__ __launch_bounds__(64) void als_reduce_solve_kernel(StepArgs<T> a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using G = Gram<T, NB>;
+  using acc_t = typename G::acc_t;
+  const int lane = threadIdx.x;
+  const SplitRow sr = a.split[blockIdx.x];
+  acc_t acc[G::NT];
+  T bacc[NB];
+#pragma unroll
+  for (int t = 0; t < G::NT; ++t) acc[t] = acc_t{T(0), T(0), T(0), T(0)};
+#pragma unroll
+  for (int cb = 0; cb < NB; ++cb) bacc[cb] = T(0);
+  for (int sl = 0; sl < sr.nslabs; ++sl) {
+    const T *s = a.slabs + (int64_t)(sr.slab0 + sl) * slab_elems(NB) + lane;
+#pragma unroll
+    for (int t = 0; t < G::NT; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[t][r] += s[(t * 4 + r) * 64];
+    }
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) bacc[cb] += s[(G::NT * 4 + cb) * 64];
+  }
+  const T lam = (T)(a.lambda * (double)sr.n);
+  SolveLds<T, NB>::run(acc, bacc, reinterpret_cast<T *>(smem), a.k, lam,
+                       a.solved + (int64_t)sr.row * a.k, sr.row, a.err, lane);
+}
+
+// ---------------------------------------------------------------------------------------
+// RMSE partial sums (EmfWorker.mw_calcRmsePortion, lib/emf/EmfWorker.js:266-315).
+// One 256-thread workgroup per portion; a 16-lane group walks one user row at a time,
+// its lanes striding the k factors of U[u] and I[i]; (r - pred)^2, pred and the count are
+// accumulated in double per group and reduced once per workgroup.
+template <typename T>
+struct RmseArgs {
+  const int64_t *rowPtr;  // local rows, rebased: rowPtr[0] = 0
+  const int32_t *indx;
+  const T *vals;
+  const T *userFactors;
+  const T *itemFactors;
+  const int64_t *portionRowEnd;  // local exclusive upper row per portion
+  double *out;                   // 3 per portion
+  double shift;
+  int64_t rowBegin;  // global id of local row 0
+  int32_t k;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void als_rmse_kernel(RmseArgs<T> a) {
+  __shared__ double red[3][16];
+  const int tid = threadIdx.x, grp = tid >> 4, l16 = tid & 15;
+  const int p = blockIdx.x;
+  const int64_t r0 = p == 0 ? 0 : a.portionRowEnd[p - 1];
+  const int64_t r1 = a.portionRowEnd[p];
+  double sd2 = 0, sp = 0, cnt = 0;
+  for (int64_t r = r0 + grp; r < r1; r += 16) {
+    const T *uF = a.userFactors + (a.rowBegin + r) * a.k;
+    for (int64_t q = a.rowPtr[r]; q < a.rowPtr[r + 1]; ++q) {
+      const T *iF = a.itemFactors + (int64_t)a.indx[q] * a.k;
+      T dot = T(0);
+      for (int f = l16; f < a.k; f += 16) dot = fma(uF[f], iF[f], dot);
+      dot += wave_shfl_xor<T>(dot, 8);
+      dot += wave_shfl_xor<T>(dot, 4);
+      dot += wave_shfl_xor<T>(dot, 2);
+      dot += wave_shfl_xor<T>(dot, 1);
+      if (l16 == 0) {
+        const double pred = (double)dot + a.shift;
+        const double d = (double)a.vals[q] - pred;
+        sd2 += d * d;
+        sp += pred;
+        cnt += 1.0;
+      }
+    }
+  }
+  if (l16 == 0) {
+    red[0][grp] = sd2;
+    red[1][grp] = cnt;
+    red[2][grp] = sp;
+  }
+  __syncthreads();
+  if (tid < 3) {
+    double s = 0;
+    for (int i = 0; i < 16; ++i) s += red[tid][i];  // fixed order: deterministic
+    a.out[3 * p + tid] = s;
+  }
+}
+
+// max over an int32 array (index validation after upload)
+__global__ void max_i32_kernel(const int32_t *x, int64_t n, int32_t *out_max, int32_t *out_min) {
+  int32_t mx = INT32_MIN, mn = INT32_MAX;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t v = x[i];
+    mx = v > mx ? v : mx;
+    mn = v < mn ? v : mn;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const int32_t a = __shfl_xor(mx, o, 64), b = __shfl_xor(mn, o, 64);
+    mx = a > mx ? a : mx;
+    mn = b < mn ? b : mn;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(out_max, mx);
+    atomicMin(out_min, mn);
+  }
+}
+
+}  // namespace ycnr

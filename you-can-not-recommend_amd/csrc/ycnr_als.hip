@@ -1,0 +1,771 @@
+// ycnr_als.hip -- host side of libycnr_als.so: the C ABI declared in include/ycnr_als.h.
+//
+// Owns device memory (CSR shards, factor matrices, work-unit tables, partial slabs),
+// builds the work-unit schedule once per rating upload, and launches the kernels of
+// als_kernels.hip.h.  There is deliberately no CPU fallback anywhere in this file: without
+// a HIP device every entry point fails with YCNR_ERR_HIP.
+#include "../../include/ycnr_als.h"
+#include "als_kernels.hip.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace ycnr;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char *fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                           \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess)                                                                       \
+      return fail(e_ == hipErrorOutOfMemory ? YCNR_ERR_NOMEM : YCNR_ERR_HIP, "%s failed: %s (%s:%d)", \
+                  #expr, hipGetErrorString(e_), __FILE__, __LINE__);                            \
+  } while (0)
+
+constexpr int kMaxFactors = 128;
+constexpr int kDefaultChunk = 1024;  // ratings per split unit (and the largest fused row)
+constexpr int kMaxSlabsPerRow = 64;  // heavier rows get proportionally longer chunks
+constexpr size_t kZeroRowBytes = 2048;  // >= kMaxFactors doubles
+
+size_t tsize(int dtype) { return dtype == YCNR_F64 ? 8 : 4; }
+
+struct Ratings {
+  int64_t rowBegin = 0, rowEnd = 0, nnz = 0;
+  int64_t *dRowPtr = nullptr;  // local, rebased to 0 (RMSE only)
+  int32_t *dIndx = nullptr;
+  void *dVals = nullptr;
+  bool loaded = false;
+  void release() {
+    if (dRowPtr) (void)hipFree(dRowPtr);
+    if (dIndx) (void)hipFree(dIndx);
+    if (dVals) (void)hipFree(dVals);
+    dRowPtr = nullptr;
+    dIndx = nullptr;
+    dVals = nullptr;
+    loaded = false;
+    nnz = 0;
+  }
+};
+
+struct Schedule {
+  Unit *dUnits = nullptr;
+  SplitRow *dSplit = nullptr;
+  void *dSlabs = nullptr;
+  int64_t nUnits = 0, nSplit = 0, nSlabs = 0, solvedRows = 0;
+  void release() {
+    if (dUnits) (void)hipFree(dUnits);
+    if (dSplit) (void)hipFree(dSplit);
+    if (dSlabs) (void)hipFree(dSlabs);
+    dUnits = nullptr;
+    dSplit = nullptr;
+    dSlabs = nullptr;
+    nUnits = nSplit = nSlabs = solvedRows = 0;
+  }
+};
+
+// Split rows into wave-level units (the counterpart of EmfLord.splitToPortions,
+// lib/emf/EmfLord.js:510-612, at wave instead of worker-process granularity).
+// rowPtr: local (length nRows + 1, any base).  Units index ratings relative to rowPtr[0].
+void build_schedule(const int64_t *rowPtr, int64_t rowBegin, int64_t nRows, int chunk,
+                    std::vector<Unit> &units, std::vector<SplitRow> &split, int64_t &nSlabs,
+                    int64_t &solvedRows) {
+  const int64_t base = rowPtr[0];
+  units.clear();
+  split.clear();
+  nSlabs = 0;
+  solvedRows = 0;
+  std::vector<Unit> fused;
+  fused.reserve((size_t)nRows);
+  for (int64_t r = 0; r < nRows; ++r) {
+    const int64_t b = rowPtr[r] - base, e = rowPtr[r + 1] - base, n = e - b;
+    if (n <= 0) continue;  // rows without ratings are never written
+    ++solvedRows;
+    const int32_t row = (int32_t)(rowBegin + r);
+    if (n <= chunk) {
+      fused.push_back(Unit{b, e, row, -1});
+      continue;
+    }
+    int64_t ch = chunk;
+    if ((n + ch - 1) / ch > kMaxSlabsPerRow) ch = (n + kMaxSlabsPerRow - 1) / kMaxSlabsPerRow;
+    ch = (ch + 3) & ~(int64_t)3;
+    const int64_t parts = (n + ch - 1) / ch;
+    split.push_back(SplitRow{n, row, (int32_t)nSlabs, (int32_t)parts, 0});
+    for (int64_t p = 0; p < parts; ++p) {
+      const int64_t ub = b + p * ch, ue = std::min(e, ub + ch);
+      units.push_back(Unit{ub, ue, row, (int32_t)(nSlabs + p)});
+    }
+    nSlabs += parts;
+  }
+  // longest first: split chunks (all ~chunk long, longest chunks first), then fused rows by
+  // descending length, so the tail of the launch is made of the cheapest units
+  std::stable_sort(units.begin(), units.end(),
+                   [](const Unit &a, const Unit &b) { return (a.end - a.beg) > (b.end - b.beg); });
+  std::stable_sort(fused.begin(), fused.end(),
+                   [](const Unit &a, const Unit &b) { return (a.end - a.beg) > (b.end - b.beg); });
+  units.insert(units.end(), fused.begin(), fused.end());
+}
+
+template <typename T, int NB>
+int launch_nb(const StepArgs<T> &args, int64_t nUnits, int64_t nSplit, hipStream_t stream,
+              hipEvent_t *ev /* 4 events or null */) {
+  const size_t lds = SolveLds<T, NB>::lds_bytes();
+  auto k1 = als_gram_solve_kernel<T, NB>;
+  auto k2 = als_reduce_solve_kernel<T, NB>;
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k1),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k2),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (ev) HIP_TRY(hipEventRecord(ev[0], stream));
+  if (nUnits > 0) {
+    hipLaunchKernelGGL(k1, dim3((unsigned)nUnits), dim3(64), lds, stream, args);
+    HIP_TRY(hipGetLastError());
+  }
+  if (ev) HIP_TRY(hipEventRecord(ev[1], stream));
+  if (nSplit > 0) {
+    if (ev) HIP_TRY(hipEventRecord(ev[2], stream));
+    hipLaunchKernelGGL(k2, dim3((unsigned)nSplit), dim3(64), lds, stream, args);
+    HIP_TRY(hipGetLastError());
+    if (ev) HIP_TRY(hipEventRecord(ev[3], stream));
+  }
+  return YCNR_OK;
+}
+
+template <typename T>
+int launch_step(const StepArgs<T> &args, int64_t nUnits, int64_t nSplit, hipStream_t stream,
+                hipEvent_t *ev) {
+  if (nUnits > 0x7fffffffLL || nSplit > 0x7fffffffLL)
+    return fail(YCNR_ERR_UNSUPPORTED, "too many work units for one launch (%lld)", (long long)nUnits);
+  const int nb = (args.k + 15) / 16;
+  switch (nb) {
+    case 1: return launch_nb<T, 1>(args, nUnits, nSplit, stream, ev);
+    case 2: return launch_nb<T, 2>(args, nUnits, nSplit, stream, ev);
+    case 3: return launch_nb<T, 3>(args, nUnits, nSplit, stream, ev);
+    case 4: return launch_nb<T, 4>(args, nUnits, nSplit, stream, ev);
+    case 5: return launch_nb<T, 5>(args, nUnits, nSplit, stream, ev);
+    case 6: return launch_nb<T, 6>(args, nUnits, nSplit, stream, ev);
+    case 7: return launch_nb<T, 7>(args, nUnits, nSplit, stream, ev);
+    case 8: return launch_nb<T, 8>(args, nUnits, nSplit, stream, ev);
+    default:
+      return fail(YCNR_ERR_UNSUPPORTED, "factorsCount %d > %d is not supported by this build", args.k,
+                  kMaxFactors);
+  }
+}
+
+int slab_nb(int k) { return (k + 15) / 16; }
+
+// copy `bytes` from src (host or device) to a device destination
+int copy_in(void *dst, const void *src, size_t bytes, int memKind, hipStream_t stream) {
+  if (bytes == 0) return YCNR_OK;
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, memKind == YCNR_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                         stream));
+  return YCNR_OK;
+}
+
+// validate 0 <= indx[i] < limit on the device
+int check_index_range(const int32_t *dIndx, int64_t n, int64_t limit, hipStream_t stream,
+                      const char *what) {
+  if (n == 0) return YCNR_OK;
+  int32_t *dmm = nullptr;
+  HIP_TRY(hipMalloc(&dmm, 2 * sizeof(int32_t)));
+  int32_t init[2] = {INT32_MIN, INT32_MAX};
+  hipError_t e = hipMemcpyAsync(dmm, init, sizeof init, hipMemcpyHostToDevice, stream);
+  if (e == hipSuccess) {
+    const int blocks = (int)std::min<int64_t>(2048, (n + 255) / 256);
+    hipLaunchKernelGGL(max_i32_kernel, dim3(blocks), dim3(256), 0, stream, dIndx, n, dmm, dmm + 1);
+    e = hipGetLastError();
+  }
+  int32_t got[2] = {0, 0};
+  if (e == hipSuccess) e = hipMemcpyAsync(got, dmm, sizeof got, hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  (void)hipFree(dmm);
+  if (e != hipSuccess) return fail(YCNR_ERR_HIP, "index range check failed: %s", hipGetErrorString(e));
+  if (got[1] < 0 || (int64_t)got[0] >= limit)
+    return fail(YCNR_ERR_INVALID, "%s: column id out of range (min %d, max %d, rows of the opposite side %lld)",
+                what, got[1], got[0], (long long)limit);
+  return YCNR_OK;
+}
+
+}  // namespace
+
+struct ycnr_als {
+  ycnr_als_options opt{};
+  hipStream_t ownStream = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  void *factors[2] = {nullptr, nullptr};
+  bool ownFactors[2] = {false, false};
+  Ratings ratings[2];
+  Schedule sched[2];
+  Ratings rmse[2];
+  ErrInfo *dErr = nullptr;
+  void *dZeros = nullptr;  // the zero "factor row" read for ratings past a unit's end
+  ycnr_als_step_info info{};
+  bool infoPending = false;
+  bool infoHasSplit = false;
+
+  int64_t rows(int side) const { return side == YCNR_BY_USER ? opt.totalUsersCount : opt.totalItemsCount; }
+  size_t ts() const { return tsize(opt.dtype); }
+};
+
+extern "C" {
+
+const char *ycnr_last_error(void) { return g_last_error.c_str(); }
+
+int ycnr_version(void) { return YCNR_ALS_ABI_VERSION; }
+
+int ycnr_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) return fail(YCNR_ERR_HIP, "hipGetDeviceCount failed: %s", hipGetErrorString(e));
+  return n;
+}
+
+int ycnr_als_create(const ycnr_als_options *o, ycnr_als **out) {
+  if (!o || !out) return fail(YCNR_ERR_INVALID, "ycnr_als_create: null argument");
+  if (o->struct_size != (int32_t)sizeof(ycnr_als_options))
+    return fail(YCNR_ERR_INVALID, "ycnr_als_create: options.struct_size %d != %zu", o->struct_size,
+                sizeof(ycnr_als_options));
+  if (o->dtype != YCNR_F32 && o->dtype != YCNR_F64) return fail(YCNR_ERR_INVALID, "bad dtype %d", o->dtype);
+  if (o->factorsCount < 1) return fail(YCNR_ERR_INVALID, "factorsCount must be >= 1");
+  if (o->factorsCount > kMaxFactors)
+    return fail(YCNR_ERR_UNSUPPORTED, "factorsCount %d > %d is not supported by this build", o->factorsCount,
+                kMaxFactors);
+  if (o->totalUsersCount < 1 || o->totalItemsCount < 1 || o->totalUsersCount > 0x7fffffffLL ||
+      o->totalItemsCount > 0x7fffffffLL)
+    return fail(YCNR_ERR_INVALID, "totalUsersCount / totalItemsCount must be in [1, 2^31)");
+  if (!(o->userFactReg >= 0) || !(o->itemFactReg >= 0)) return fail(YCNR_ERR_INVALID, "negative regularisation");
+  if (o->chunkRatings < 0) return fail(YCNR_ERR_INVALID, "chunkRatings < 0");
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (o->device < 0 || o->device >= ndev)
+    return fail(YCNR_ERR_INVALID, "device %d out of range (%d visible)", o->device, ndev);
+  HIP_TRY(hipSetDevice(o->device));
+  ycnr_als *h = new (std::nothrow) ycnr_als();
+  if (!h) return fail(YCNR_ERR_NOMEM, "out of host memory");
+  h->opt = *o;
+  if (h->opt.chunkRatings == 0) h->opt.chunkRatings = kDefaultChunk;
+  h->opt.chunkRatings = (h->opt.chunkRatings + 3) & ~3;
+  hipError_t e = hipStreamCreateWithFlags(&h->ownStream, hipStreamNonBlocking);
+  for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&h->ev[i]);
+  for (int s = 0; s < 2 && e == hipSuccess; ++s) {
+    e = hipMalloc(&h->factors[s], (size_t)h->rows(s) * o->factorsCount * h->ts());
+    if (e == hipSuccess) {
+      h->ownFactors[s] = true;
+      e = hipMemsetAsync(h->factors[s], 0, (size_t)h->rows(s) * o->factorsCount * h->ts(), h->ownStream);
+    }
+  }
+  if (e == hipSuccess) e = hipMalloc(&h->dErr, sizeof(ErrInfo));
+  if (e == hipSuccess) e = hipMemsetAsync(h->dErr, 0, sizeof(ErrInfo), h->ownStream);
+  if (e == hipSuccess) e = hipMalloc(&h->dZeros, kZeroRowBytes);
+  if (e == hipSuccess) e = hipMemsetAsync(h->dZeros, 0, kZeroRowBytes, h->ownStream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->ownStream);
+  if (e != hipSuccess) {
+    int code = fail(e == hipErrorOutOfMemory ? YCNR_ERR_NOMEM : YCNR_ERR_HIP, "ycnr_als_create: %s",
+                    hipGetErrorString(e));
+    ycnr_als_destroy(h);
+    return code;
+  }
+  h->stream = h->ownStream;
+  *out = h;
+  return YCNR_OK;
+}
+
+int ycnr_als_destroy(ycnr_als *h) {
+  if (!h) return YCNR_OK;
+  (void)hipSetDevice(h->opt.device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (int s = 0; s < 2; ++s) {
+    h->ratings[s].release();
+    h->sched[s].release();
+    h->rmse[s].release();
+    if (h->ownFactors[s] && h->factors[s]) (void)hipFree(h->factors[s]);
+  }
+  if (h->dErr) (void)hipFree(h->dErr);
+  if (h->dZeros) (void)hipFree(h->dZeros);
+  for (int i = 0; i < 4; ++i)
+    if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+  if (h->ownStream) (void)hipStreamDestroy(h->ownStream);
+  delete h;
+  return YCNR_OK;
+}
+
+int ycnr_als_set_stream(ycnr_als *h, void *s) {
+  if (!h) return fail(YCNR_ERR_INVALID, "null handle");
+  HIP_TRY(hipSetDevice(h->opt.device));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  h->stream = s ? (hipStream_t)s : h->ownStream;
+  return YCNR_OK;
+}
+
+static int upload_ratings(ycnr_als *h, Ratings &R, int64_t totalRows, int64_t oppositeRows,
+                          const int64_t *rowPtr, const int32_t *indx, const void *vals, int64_t rowBegin,
+                          int64_t rowEnd, int memKind, std::vector<int64_t> &hostPtr, const char *what) {
+  if (!rowPtr || !indx || !vals) return fail(YCNR_ERR_INVALID, "%s: null array", what);
+  if (rowBegin < 0 || rowEnd < rowBegin || rowEnd > totalRows)
+    return fail(YCNR_ERR_INVALID, "%s: shard [%lld, %lld) outside [0, %lld)", what, (long long)rowBegin,
+                (long long)rowEnd, (long long)totalRows);
+  if (memKind != YCNR_MEM_HOST && memKind != YCNR_MEM_DEVICE) return fail(YCNR_ERR_INVALID, "bad memKind");
+  HIP_TRY(hipSetDevice(h->opt.device));
+  const int64_t nRows = rowEnd - rowBegin;
+  hostPtr.resize((size_t)nRows + 1);
+  if (memKind == YCNR_MEM_HOST) {
+    memcpy(hostPtr.data(), rowPtr + rowBegin, sizeof(int64_t) * ((size_t)nRows + 1));
+  } else {
+    HIP_TRY(hipMemcpy(hostPtr.data(), rowPtr + rowBegin, sizeof(int64_t) * ((size_t)nRows + 1),
+                      hipMemcpyDeviceToHost));
+  }
+  for (int64_t r = 0; r < nRows; ++r)
+    if (hostPtr[r + 1] < hostPtr[r]) return fail(YCNR_ERR_INVALID, "%s: rowPtr not ascending at row %lld", what,
+                                                 (long long)(rowBegin + r));
+  if (hostPtr[0] < 0) return fail(YCNR_ERR_INVALID, "%s: negative rowPtr", what);
+  const int64_t base = hostPtr[0], nnz = hostPtr[nRows] - base;
+  R.release();
+  R.rowBegin = rowBegin;
+  R.rowEnd = rowEnd;
+  R.nnz = nnz;
+  const size_t ts = h->ts();
+  HIP_TRY(hipMalloc(&R.dIndx, std::max<size_t>(4, (size_t)nnz * 4)));
+  HIP_TRY(hipMalloc(&R.dVals, std::max<size_t>(8, (size_t)nnz * ts)));
+  int rc = copy_in(R.dIndx, indx + base, (size_t)nnz * 4, memKind, h->stream);
+  if (rc) return rc;
+  rc = copy_in(R.dVals, (const char *)vals + (size_t)base * ts, (size_t)nnz * ts, memKind, h->stream);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  rc = check_index_range(R.dIndx, nnz, oppositeRows, h->stream, what);
+  if (rc) {
+    R.release();
+    return rc;
+  }
+  R.loaded = true;
+  return YCNR_OK;
+}
+
+int ycnr_als_set_ratings(ycnr_als *h, int side, const int64_t *rowPtr, const int32_t *indx, const void *vals,
+                         int64_t rowBegin, int64_t rowEnd, int memKind) {
+  if (!h) return fail(YCNR_ERR_INVALID, "null handle");
+  if (side != YCNR_BY_USER && side != YCNR_BY_ITEM) return fail(YCNR_ERR_INVALID, "bad side %d", side);
+  std::vector<int64_t> hp;
+  int rc = upload_ratings(h, h->ratings[side], h->rows(side), h->rows(1 - side), rowPtr, indx, vals, rowBegin,
+                          rowEnd, memKind, hp, side == YCNR_BY_USER ? "set_ratings(byUser)" : "set_ratings(byItem)");
+  if (rc) return rc;
+  std::vector<Unit> units;
+  std::vector<SplitRow> split;
+  int64_t nSlabs = 0, solved = 0;
+  build_schedule(hp.data(), rowBegin, rowEnd - rowBegin, h->opt.chunkRatings, units, split, nSlabs, solved);
+  Schedule &S = h->sched[side];
+  S.release();
+  S.nUnits = (int64_t)units.size();
+  S.nSplit = (int64_t)split.size();
+  S.nSlabs = nSlabs;
+  S.solvedRows = solved;
+  if (S.nUnits) {
+    HIP_TRY(hipMalloc(&S.dUnits, sizeof(Unit) * units.size()));
+    HIP_TRY(hipMemcpy(S.dUnits, units.data(), sizeof(Unit) * units.size(), hipMemcpyHostToDevice));
+  }
+  if (S.nSplit) {
+    HIP_TRY(hipMalloc(&S.dSplit, sizeof(SplitRow) * split.size()));
+    HIP_TRY(hipMemcpy(S.dSplit, split.data(), sizeof(SplitRow) * split.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(&S.dSlabs, (size_t)nSlabs * slab_elems(slab_nb(h->opt.factorsCount)) * h->ts()));
+  }
+  return YCNR_OK;
+}
+
+int ycnr_als_set_rmse_ratings(ycnr_als *h, int which, const int64_t *rowPtr, const int32_t *indx,
+                              const void *vals, int64_t rowBegin, int64_t rowEnd, int memKind) {
+  if (!h) return fail(YCNR_ERR_INVALID, "null handle");
+  if (which != YCNR_RMSE_VALIDATE && which != YCNR_RMSE_TEST) return fail(YCNR_ERR_INVALID, "bad rmse set %d", which);
+  std::vector<int64_t> hp;
+  Ratings &R = h->rmse[which];
+  int rc = upload_ratings(h, R, h->opt.totalUsersCount, h->opt.totalItemsCount, rowPtr, indx, vals, rowBegin,
+                          rowEnd, memKind, hp, "set_rmse_ratings");
+  if (rc) return rc;
+  const int64_t base = hp[0];
+  for (auto &v : hp) v -= base;
+  HIP_TRY(hipMalloc(&R.dRowPtr, sizeof(int64_t) * hp.size()));
+  HIP_TRY(hipMemcpy(R.dRowPtr, hp.data(), sizeof(int64_t) * hp.size(), hipMemcpyHostToDevice));
+  return YCNR_OK;
+}
+
+int ycnr_als_set_factors(ycnr_als *h, int side, const void *src, int memKind) {
+  if (!h || !src) return fail(YCNR_ERR_INVALID, "null argument");
+  if (side != 0 && side != 1) return fail(YCNR_ERR_INVALID, "bad side %d", side);
+  HIP_TRY(hipSetDevice(h->opt.device));
+  int rc = copy_in(h->factors[side], src, (size_t)h->rows(side) * h->opt.factorsCount * h->ts(), memKind, h->stream);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return YCNR_OK;
+}
+
+int ycnr_als_get_factors(ycnr_als *h, int side, void *dst, int64_t rowBegin, int64_t rowCount, int memKind) {
+  if (!h || !dst) return fail(YCNR_ERR_INVALID, "null argument");
+  if (side != 0 && side != 1) return fail(YCNR_ERR_INVALID, "bad side %d", side);
+  if (rowBegin < 0 || rowCount < 0 || rowBegin + rowCount > h->rows(side))
+    return fail(YCNR_ERR_INVALID, "get_factors: rows [%lld, +%lld) outside the matrix", (long long)rowBegin,
+                (long long)rowCount);
+  HIP_TRY(hipSetDevice(h->opt.device));
+  const size_t rowBytes = (size_t)h->opt.factorsCount * h->ts();
+  HIP_TRY(hipMemcpyAsync(dst, (const char *)h->factors[side] + (size_t)rowBegin * rowBytes, (size_t)rowCount * rowBytes,
+                         memKind == YCNR_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return YCNR_OK;
+}
+
+int ycnr_als_factors_ptr(ycnr_als *h, int side, void **p) {
+  if (!h || !p) return fail(YCNR_ERR_INVALID, "null argument");
+  if (side != 0 && side != 1) return fail(YCNR_ERR_INVALID, "bad side %d", side);
+  *p = h->factors[side];
+  return YCNR_OK;
+}
+
+int ycnr_als_bind_factors(ycnr_als *h, int side, void *p) {
+  if (!h || !p) return fail(YCNR_ERR_INVALID, "null argument");
+  if (side != 0 && side != 1) return fail(YCNR_ERR_INVALID, "bad side %d", side);
+  HIP_TRY(hipSetDevice(h->opt.device));
+  hipPointerAttribute_t attr;
+  hipError_t e = hipPointerGetAttributes(&attr, p);
+  if (e != hipSuccess || attr.type != hipMemoryTypeDevice) {
+    (void)hipGetLastError();
+    return fail(YCNR_ERR_INVALID, "bind_factors: not a device pointer");
+  }
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (h->ownFactors[side] && h->factors[side]) (void)hipFree(h->factors[side]);
+  h->factors[side] = p;
+  h->ownFactors[side] = false;
+  return YCNR_OK;
+}
+
+int ycnr_als_step_async(ycnr_als *h, int side) {
+  if (!h) return fail(YCNR_ERR_INVALID, "null handle");
+  if (side != YCNR_BY_USER && side != YCNR_BY_ITEM) return fail(YCNR_ERR_INVALID, "bad side %d", side);
+  if (!h->ratings[side].loaded) return fail(YCNR_ERR_STATE, "step: set_ratings was not called for this side");
+  HIP_TRY(hipSetDevice(h->opt.device));
+  const Ratings &R = h->ratings[side];
+  const Schedule &S = h->sched[side];
+  HIP_TRY(hipMemsetAsync(h->dErr, 0, sizeof(ErrInfo), h->stream));
+  const double lambda = side == YCNR_BY_USER ? h->opt.userFactReg : h->opt.itemFactReg;
+  int rc;
+  if (h->opt.dtype == YCNR_F32) {
+    StepArgs<float> a{S.dUnits, S.dSplit, R.dIndx, (const float *)R.dVals, (const float *)h->factors[1 - side],
+                      (const float *)h->dZeros, (float *)h->factors[side], (float *)S.dSlabs, h->dErr, lambda, h->opt.factorsCount};
+    rc = launch_step<float>(a, S.nUnits, S.nSplit, h->stream, h->ev);
+  } else {
+    StepArgs<double> a{S.dUnits, S.dSplit, R.dIndx, (const double *)R.dVals, (const double *)h->factors[1 - side],
+                       (const double *)h->dZeros, (double *)h->factors[side], (double *)S.dSlabs, h->dErr, lambda, h->opt.factorsCount};
+    rc = launch_step<double>(a, S.nUnits, S.nSplit, h->stream, h->ev);
+  }
+  if (rc) return rc;
+  memset(&h->info, 0, sizeof h->info);
+  h->info.struct_size = (int32_t)sizeof(ycnr_als_step_info);
+  h->info.side = side;
+  h->info.rows = S.solvedRows;
+  h->info.ratings = R.nnz;
+  h->info.units = S.nUnits;
+  h->info.splitRows = S.nSplit;
+  h->infoPending = true;
+  h->infoHasSplit = S.nSplit > 0;
+  return YCNR_OK;
+}
+
+int ycnr_als_sync(ycnr_als *h) {
+  if (!h) return fail(YCNR_ERR_INVALID, "null handle");
+  HIP_TRY(hipSetDevice(h->opt.device));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (h->infoPending) {
+    h->infoPending = false;
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
+    h->info.gramSolveMs = ms;
+    h->info.totalMs = ms;
+    if (h->infoHasSplit) {
+      HIP_TRY(hipEventElapsedTime(&ms, h->ev[2], h->ev[3]));
+      h->info.reduceSolveMs = ms;
+      HIP_TRY(hipEventElapsedTime(&ms, h->ev[0], h->ev[3]));
+      h->info.totalMs = ms;
+    }
+    ErrInfo ei{};
+    HIP_TRY(hipMemcpy(&ei, h->dErr, sizeof ei, hipMemcpyDeviceToHost));
+    h->info.numericErrors = ei.count;
+    if (ei.count > 0)
+      return fail(YCNR_ERR_NUMERIC, "%d row(s) had a normal matrix that is not positive definite (e.g. row %d)",
+                  ei.count, ei.firstRow);
+  }
+  return YCNR_OK;
+}
+
+int ycnr_als_step(ycnr_als *h, int side) {
+  int rc = ycnr_als_step_async(h, side);
+  if (rc) return rc;
+  return ycnr_als_sync(h);
+}
+
+int ycnr_als_last_step_info(ycnr_als *h, ycnr_als_step_info *info) {
+  if (!h || !info) return fail(YCNR_ERR_INVALID, "null argument");
+  if (h->infoPending) return fail(YCNR_ERR_STATE, "last_step_info: call ycnr_als_sync first");
+  *info = h->info;
+  return YCNR_OK;
+}
+
+int ycnr_als_rmse(ycnr_als *h, int which, double shift, int nPortions, const int64_t *portionRowEnd, double *out) {
+  if (!h || !out) return fail(YCNR_ERR_INVALID, "null argument");
+  if (which != YCNR_RMSE_VALIDATE && which != YCNR_RMSE_TEST) return fail(YCNR_ERR_INVALID, "bad rmse set %d", which);
+  const Ratings &R = h->rmse[which];
+  if (!R.loaded) return fail(YCNR_ERR_STATE, "rmse: set_rmse_ratings was not called for this set");
+  if (nPortions < 0 || (nPortions > 0 && !portionRowEnd)) return fail(YCNR_ERR_INVALID, "bad portions");
+  HIP_TRY(hipSetDevice(h->opt.device));
+  const int64_t nRows = R.rowEnd - R.rowBegin;
+  std::vector<int64_t> ends;
+  if (nPortions == 0) {
+    ends.push_back(nRows);
+  } else {
+    int64_t prev = 0;
+    for (int p = 0; p < nPortions; ++p) {
+      int64_t e = portionRowEnd[p] - R.rowBegin;  // global -> local, clipped to the shard
+      e = std::max<int64_t>(0, std::min(nRows, e));
+      if (e < prev) return fail(YCNR_ERR_INVALID, "rmse: portionRowEnd must be ascending");
+      ends.push_back(e);
+      prev = e;
+    }
+  }
+  const int np = (int)ends.size();
+  int64_t *dEnds = nullptr;
+  double *dOut = nullptr;
+  HIP_TRY(hipMalloc(&dEnds, sizeof(int64_t) * np));
+  hipError_t e = hipMalloc(&dOut, sizeof(double) * 3 * np);
+  if (e == hipSuccess) e = hipMemcpyAsync(dEnds, ends.data(), sizeof(int64_t) * np, hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess) {
+    if (h->opt.dtype == YCNR_F32) {
+      RmseArgs<float> a{R.dRowPtr, R.dIndx, (const float *)R.dVals, (const float *)h->factors[0],
+                        (const float *)h->factors[1], dEnds, dOut, shift, R.rowBegin, h->opt.factorsCount};
+      hipLaunchKernelGGL(als_rmse_kernel<float>, dim3(np), dim3(256), 0, h->stream, a);
+    } else {
+      RmseArgs<double> a{R.dRowPtr, R.dIndx, (const double *)R.dVals, (const double *)h->factors[0],
+                         (const double *)h->factors[1], dEnds, dOut, shift, R.rowBegin, h->opt.factorsCount};
+      hipLaunchKernelGGL(als_rmse_kernel<double>, dim3(np), dim3(256), 0, h->stream, a);
+    }
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(out, dOut, sizeof(double) * 3 * np, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (dEnds) (void)hipFree(dEnds);
+  if (dOut) (void)hipFree(dOut);
+  if (e != hipSuccess) return fail(YCNR_ERR_HIP, "rmse: %s", hipGetErrorString(e));
+  return YCNR_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------ level 1
+
+namespace {
+
+// Shared body of ycnr_{s,d}AlsCalcPortion.  The portion only touches the fixed rows its
+// column ids name, so those rows are compacted on the host before upload (a 10 000-rating
+// portion never needs more than 10 000 of them) and the solved rows are scattered back.
+template <typename T>
+int64_t als_calc_portion(double lambda, int k, const int32_t *alsRows, const int32_t *alsIndx, const T *alsVals,
+                         const T *fixedFactors, int64_t fixedRows, T *solvedFactors, int64_t solvedRows, int dtype) {
+  if (!alsRows || !alsIndx || !alsVals || !fixedFactors || !solvedFactors)
+    return fail(YCNR_ERR_INVALID, "AlsCalcPortion: null argument");
+  if (k < 1) return fail(YCNR_ERR_INVALID, "AlsCalcPortion: k < 1");
+  if (k > kMaxFactors) return fail(YCNR_ERR_UNSUPPORTED, "factorsCount %d > %d is not supported by this build", k, kMaxFactors);
+  if (!(lambda >= 0)) return fail(YCNR_ERR_INVALID, "AlsCalcPortion: negative lambda");
+  const int nRows = alsRows[0];
+  if (nRows < 0) return fail(YCNR_ERR_INVALID, "AlsCalcPortion: alsRows[0] < 0");
+  if (nRows == 0) return 0;
+  std::vector<int64_t> rowPtr((size_t)nRows + 1, 0);
+  for (int r = 0; r < nRows; ++r) {
+    const int rowId = alsRows[1 + 2 * r], cols = alsRows[2 + 2 * r];
+    if (rowId < 0 || rowId >= solvedRows) return fail(YCNR_ERR_INVALID, "AlsCalcPortion: rowId %d outside [0, %lld)", rowId, (long long)solvedRows);
+    if (cols < 0) return fail(YCNR_ERR_INVALID, "AlsCalcPortion: negative cols");
+    rowPtr[r + 1] = rowPtr[r] + cols;
+  }
+  const int64_t total = rowPtr[nRows];
+  if (total == 0) return 0;
+  // compact the referenced fixed rows
+  std::vector<int32_t> uniq(alsIndx, alsIndx + total);
+  std::sort(uniq.begin(), uniq.end());
+  uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+  if (uniq.front() < 0 || uniq.back() >= fixedRows)
+    return fail(YCNR_ERR_INVALID, "AlsCalcPortion: column id out of range (min %d, max %d, fixedRows %lld)", uniq.front(),
+                uniq.back(), (long long)fixedRows);
+  std::vector<int32_t> cidx((size_t)total);
+  for (int64_t i = 0; i < total; ++i)
+    cidx[i] = (int32_t)(std::lower_bound(uniq.begin(), uniq.end(), alsIndx[i]) - uniq.begin());
+  std::vector<T> cfix(uniq.size() * (size_t)k);
+  for (size_t u = 0; u < uniq.size(); ++u) memcpy(&cfix[u * k], fixedFactors + (size_t)uniq[u] * k, sizeof(T) * k);
+
+  std::vector<Unit> units;
+  std::vector<SplitRow> split;
+  int64_t nSlabs = 0, solved = 0;
+  build_schedule(rowPtr.data(), 0, nRows, kDefaultChunk, units, split, nSlabs, solved);
+
+  const int nb = slab_nb(k);
+  Unit *dUnits = nullptr;
+  SplitRow *dSplit = nullptr;
+  int32_t *dIndx = nullptr;
+  T *dVals = nullptr, *dFixed = nullptr, *dSolved = nullptr, *dSlabs = nullptr, *dZeros = nullptr;
+  ErrInfo *dErr = nullptr;
+  hipStream_t stream = nullptr;
+  std::vector<T> hostSolved((size_t)nRows * k);
+  ErrInfo ei{};
+  int rc = YCNR_OK;
+  auto cleanup = [&]() {
+    if (dUnits) (void)hipFree(dUnits);
+    if (dSplit) (void)hipFree(dSplit);
+    if (dIndx) (void)hipFree(dIndx);
+    if (dVals) (void)hipFree(dVals);
+    if (dFixed) (void)hipFree(dFixed);
+    if (dSolved) (void)hipFree(dSolved);
+    if (dSlabs) (void)hipFree(dSlabs);
+    if (dZeros) (void)hipFree(dZeros);
+    if (dErr) (void)hipFree(dErr);
+    if (stream) (void)hipStreamDestroy(stream);
+  };
+#define L1_TRY(expr)                                                                                  \
+  do {                                                                                                \
+    hipError_t e_ = (expr);                                                                           \
+    if (e_ != hipSuccess) {                                                                           \
+      rc = fail(e_ == hipErrorOutOfMemory ? YCNR_ERR_NOMEM : YCNR_ERR_HIP, "%s failed: %s", #expr,    \
+                hipGetErrorString(e_));                                                               \
+      cleanup();                                                                                      \
+      return rc;                                                                                      \
+    }                                                                                                 \
+  } while (0)
+  L1_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  L1_TRY(hipMalloc(&dUnits, sizeof(Unit) * std::max<size_t>(1, units.size())));
+  L1_TRY(hipMalloc(&dSplit, sizeof(SplitRow) * std::max<size_t>(1, split.size())));
+  L1_TRY(hipMalloc(&dIndx, sizeof(int32_t) * (size_t)total));
+  L1_TRY(hipMalloc(&dVals, sizeof(T) * (size_t)total));
+  L1_TRY(hipMalloc(&dFixed, sizeof(T) * cfix.size()));
+  L1_TRY(hipMalloc(&dSolved, sizeof(T) * hostSolved.size()));
+  L1_TRY(hipMalloc(&dSlabs, sizeof(T) * std::max<size_t>(1, (size_t)nSlabs * slab_elems(nb))));
+  L1_TRY(hipMalloc(&dErr, sizeof(ErrInfo)));
+  L1_TRY(hipMalloc(&dZeros, kZeroRowBytes));
+  L1_TRY(hipMemsetAsync(dZeros, 0, kZeroRowBytes, stream));
+  L1_TRY(hipMemsetAsync(dErr, 0, sizeof(ErrInfo), stream));
+  L1_TRY(hipMemsetAsync(dSolved, 0, sizeof(T) * hostSolved.size(), stream));
+  if (!units.empty()) L1_TRY(hipMemcpyAsync(dUnits, units.data(), sizeof(Unit) * units.size(), hipMemcpyHostToDevice, stream));
+  if (!split.empty()) L1_TRY(hipMemcpyAsync(dSplit, split.data(), sizeof(SplitRow) * split.size(), hipMemcpyHostToDevice, stream));
+  L1_TRY(hipMemcpyAsync(dIndx, cidx.data(), sizeof(int32_t) * (size_t)total, hipMemcpyHostToDevice, stream));
+  L1_TRY(hipMemcpyAsync(dVals, alsVals, sizeof(T) * (size_t)total, hipMemcpyHostToDevice, stream));
+  L1_TRY(hipMemcpyAsync(dFixed, cfix.data(), sizeof(T) * cfix.size(), hipMemcpyHostToDevice, stream));
+  {
+    // rows are numbered 0..nRows-1 on the device and scattered to rowId on the host
+    StepArgs<T> a{dUnits, dSplit, dIndx, dVals, dFixed, dZeros, dSolved, dSlabs, dErr, lambda, k};
+    rc = launch_step<T>(a, (int64_t)units.size(), (int64_t)split.size(), stream, nullptr);
+    if (rc) {
+      cleanup();
+      return rc;
+    }
+  }
+  L1_TRY(hipMemcpyAsync(hostSolved.data(), dSolved, sizeof(T) * hostSolved.size(), hipMemcpyDeviceToHost, stream));
+  L1_TRY(hipMemcpyAsync(&ei, dErr, sizeof ei, hipMemcpyDeviceToHost, stream));
+  L1_TRY(hipStreamSynchronize(stream));
+#undef L1_TRY
+  cleanup();
+  (void)dtype;
+  if (ei.count > 0)
+    return fail(YCNR_ERR_NUMERIC, "%d row(s) of the portion had a normal matrix that is not positive definite", ei.count);
+  for (int r = 0; r < nRows; ++r) {
+    if (rowPtr[r + 1] == rowPtr[r]) continue;  // cols == 0: left untouched
+    memcpy(solvedFactors + (size_t)alsRows[1 + 2 * r] * k, &hostSolved[(size_t)r * k], sizeof(T) * k);
+  }
+  return total;
+}
+
+template <typename T>
+int rmse_portion(int k, const int32_t *rows, const int32_t *indx, const T *vals, const T *uF, int64_t usersRows,
+                 const T *iF, int64_t itemsRows, double shift, double *out3, int dtype) {
+  if (!rows || !indx || !vals || !uF || !iF || !out3) return fail(YCNR_ERR_INVALID, "RmsePortion: null argument");
+  if (k < 1) return fail(YCNR_ERR_INVALID, "RmsePortion: k < 1");
+  const int nRows = rows[0];
+  out3[0] = out3[1] = out3[2] = 0;
+  if (nRows < 0) return fail(YCNR_ERR_INVALID, "RmsePortion: rmseRows[0] < 0");
+  if (nRows == 0) return YCNR_OK;
+  // compact users and items, then run the resident kernel on the compacted problem
+  std::vector<int64_t> rowPtr((size_t)nRows + 1, 0);
+  for (int r = 0; r < nRows; ++r) {
+    const int u = rows[1 + 2 * r], cols = rows[2 + 2 * r];
+    if (u < 0 || u >= usersRows || cols < 0) return fail(YCNR_ERR_INVALID, "RmsePortion: bad row entry %d", r);
+    rowPtr[r + 1] = rowPtr[r] + cols;
+  }
+  const int64_t total = rowPtr[nRows];
+  if (total == 0) return YCNR_OK;
+  std::vector<int32_t> uniq(indx, indx + total);
+  std::sort(uniq.begin(), uniq.end());
+  uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+  if (uniq.front() < 0 || uniq.back() >= itemsRows) return fail(YCNR_ERR_INVALID, "RmsePortion: item id out of range");
+  std::vector<int32_t> cidx((size_t)total);
+  for (int64_t i = 0; i < total; ++i)
+    cidx[i] = (int32_t)(std::lower_bound(uniq.begin(), uniq.end(), indx[i]) - uniq.begin());
+  std::vector<T> cI(uniq.size() * (size_t)k), cU((size_t)nRows * k);
+  for (size_t j = 0; j < uniq.size(); ++j) memcpy(&cI[j * k], iF + (size_t)uniq[j] * k, sizeof(T) * k);
+  for (int r = 0; r < nRows; ++r) memcpy(&cU[(size_t)r * k], uF + (size_t)rows[1 + 2 * r] * k, sizeof(T) * k);
+
+  ycnr_als_options o{};
+  o.struct_size = (int32_t)sizeof o;
+  o.device = 0;
+  o.dtype = dtype;
+  o.factorsCount = k;
+  o.totalUsersCount = nRows;
+  o.totalItemsCount = (int64_t)uniq.size();
+  ycnr_als *h = nullptr;
+  int rc = ycnr_als_create(&o, &h);
+  if (rc) return rc;
+  rc = ycnr_als_set_factors(h, YCNR_BY_USER, cU.data(), YCNR_MEM_HOST);
+  if (!rc) rc = ycnr_als_set_factors(h, YCNR_BY_ITEM, cI.data(), YCNR_MEM_HOST);
+  if (!rc) rc = ycnr_als_set_rmse_ratings(h, YCNR_RMSE_VALIDATE, rowPtr.data(), cidx.data(), vals, 0, nRows, YCNR_MEM_HOST);
+  if (!rc) rc = ycnr_als_rmse(h, YCNR_RMSE_VALIDATE, shift, 0, nullptr, out3);
+  ycnr_als_destroy(h);
+  return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t ycnr_sAlsCalcPortion(double lambda, int k, const int32_t *alsRows, const int32_t *alsIndx, const float *alsVals,
+                             const float *fixedFactors, int64_t fixedRows, float *solvedFactors, int64_t solvedRows) {
+  return als_calc_portion<float>(lambda, k, alsRows, alsIndx, alsVals, fixedFactors, fixedRows, solvedFactors,
+                                 solvedRows, YCNR_F32);
+}
+
+int64_t ycnr_dAlsCalcPortion(double lambda, int k, const int32_t *alsRows, const int32_t *alsIndx, const double *alsVals,
+                             const double *fixedFactors, int64_t fixedRows, double *solvedFactors, int64_t solvedRows) {
+  return als_calc_portion<double>(lambda, k, alsRows, alsIndx, alsVals, fixedFactors, fixedRows, solvedFactors,
+                                  solvedRows, YCNR_F64);
+}
+
+int ycnr_sRmsePortion(int k, const int32_t *rmseRows, const int32_t *rmseIndx, const float *rmseVals,
+                      const float *userFactors, int64_t usersRows, const float *itemFactors, int64_t itemsRows,
+                      double globalAvgShift, double *out3) {
+  return rmse_portion<float>(k, rmseRows, rmseIndx, rmseVals, userFactors, usersRows, itemFactors, itemsRows,
+                             globalAvgShift, out3, YCNR_F32);
+}
+
+int ycnr_dRmsePortion(int k, const int32_t *rmseRows, const int32_t *rmseIndx, const double *rmseVals,
+                      const double *userFactors, int64_t usersRows, const double *itemFactors, int64_t itemsRows,
+                      double globalAvgShift, double *out3) {
+  return rmse_portion<double>(k, rmseRows, rmseIndx, rmseVals, userFactors, usersRows, itemFactors, itemsRows,
+                              globalAvgShift, out3, YCNR_F64);
+}
+
+}  // extern "C"

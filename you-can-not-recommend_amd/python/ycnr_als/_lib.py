@@ -1,0 +1,111 @@
+"""ctypes binding of libycnr_als.so (include/ycnr_als.h).
+
+There is no fallback: if the HIP library is missing this module raises at load time, and
+every call that fails raises YcnrError carrying ycnr_last_error().
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.normpath(os.path.join(_HERE, "..", "..", "csrc"))
+SO_PATH = os.path.join(CSRC, "libycnr_als.so")
+
+OK = 0
+ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_UNSUPPORTED, ERR_NUMERIC, ERR_STATE = -1, -2, -3, -4, -5, -6
+BY_USER, BY_ITEM = 0, 1
+F32, F64 = 0, 1
+MEM_HOST, MEM_DEVICE = 0, 1
+RMSE_VALIDATE, RMSE_TEST = 0, 1
+
+# every symbol include/ycnr_als.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "ycnr_last_error", "ycnr_version", "ycnr_device_count",
+    "ycnr_sAlsCalcPortion", "ycnr_dAlsCalcPortion", "ycnr_sRmsePortion", "ycnr_dRmsePortion",
+    "ycnr_als_create", "ycnr_als_destroy", "ycnr_als_set_stream", "ycnr_als_set_ratings",
+    "ycnr_als_set_rmse_ratings", "ycnr_als_set_factors", "ycnr_als_get_factors", "ycnr_als_factors_ptr",
+    "ycnr_als_bind_factors", "ycnr_als_step", "ycnr_als_step_async", "ycnr_als_sync",
+    "ycnr_als_last_step_info", "ycnr_als_rmse",
+]
+
+
+class YcnrError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"ycnr_als error {code}: {msg}")
+        self.code = code
+
+
+class Options(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("dtype", C.c_int32),
+                ("factorsCount", C.c_int32), ("totalUsersCount", C.c_int64), ("totalItemsCount", C.c_int64),
+                ("userFactReg", C.c_double), ("itemFactReg", C.c_double), ("chunkRatings", C.c_int32),
+                ("flags", C.c_int32)]
+
+
+class StepInfo(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("side", C.c_int32), ("rows", C.c_int64), ("ratings", C.c_int64),
+                ("units", C.c_int64), ("splitRows", C.c_int64), ("gramSolveMs", C.c_float),
+                ("reduceSolveMs", C.c_float), ("totalMs", C.c_float), ("numericErrors", C.c_int32)]
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library and declare prototypes. Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise ImportError(
+            f"{SO_PATH} is missing: build it with `make -C {CSRC}` (or __graft_entry__.build()). "
+            "The ALS path has no CPU fallback.")
+    L = C.CDLL(SO_PATH)
+    vp, i32, i64, dbl = C.c_void_p, C.c_int, C.c_int64, C.c_double
+    L.ycnr_last_error.restype = C.c_char_p
+    L.ycnr_last_error.argtypes = []
+    L.ycnr_version.restype = i32
+    L.ycnr_device_count.restype = i32
+    for p in "sd":
+        f = getattr(L, f"ycnr_{p}AlsCalcPortion")
+        f.restype = i64
+        f.argtypes = [dbl, i32, vp, vp, vp, vp, i64, vp, i64]
+        f = getattr(L, f"ycnr_{p}RmsePortion")
+        f.restype = i32
+        f.argtypes = [i32, vp, vp, vp, vp, i64, vp, i64, dbl, vp]
+    L.ycnr_als_create.restype = i32
+    L.ycnr_als_create.argtypes = [C.POINTER(Options), C.POINTER(vp)]
+    L.ycnr_als_destroy.restype = i32
+    L.ycnr_als_destroy.argtypes = [vp]
+    L.ycnr_als_set_stream.restype = i32
+    L.ycnr_als_set_stream.argtypes = [vp, vp]
+    for name in ("ycnr_als_set_ratings", "ycnr_als_set_rmse_ratings"):
+        f = getattr(L, name)
+        f.restype = i32
+        f.argtypes = [vp, i32, vp, vp, vp, i64, i64, i32]
+    L.ycnr_als_set_factors.restype = i32
+    L.ycnr_als_set_factors.argtypes = [vp, i32, vp, i32]
+    L.ycnr_als_get_factors.restype = i32
+    L.ycnr_als_get_factors.argtypes = [vp, i32, vp, i64, i64, i32]
+    L.ycnr_als_factors_ptr.restype = i32
+    L.ycnr_als_factors_ptr.argtypes = [vp, i32, C.POINTER(vp)]
+    L.ycnr_als_bind_factors.restype = i32
+    L.ycnr_als_bind_factors.argtypes = [vp, i32, vp]
+    for name in ("ycnr_als_step", "ycnr_als_step_async"):
+        f = getattr(L, name)
+        f.restype = i32
+        f.argtypes = [vp, i32]
+    L.ycnr_als_sync.restype = i32
+    L.ycnr_als_sync.argtypes = [vp]
+    L.ycnr_als_last_step_info.restype = i32
+    L.ycnr_als_last_step_info.argtypes = [vp, C.POINTER(StepInfo)]
+    L.ycnr_als_rmse.restype = i32
+    L.ycnr_als_rmse.argtypes = [vp, i32, dbl, i32, vp, vp]
+    _lib = L
+    return L
+
+
+def check(rc):
+    """Raise YcnrError for a negative return code; pass the value through otherwise."""
+    if rc < 0:
+        raise YcnrError(rc, load().ycnr_last_error().decode("utf-8", "replace"))
+    return rc

@@ -1,0 +1,445 @@
+"""Host-side mirror of the reference's trainer classes for the ALS path, in Python.
+
+Same method names, argument meaning and result files as lib/emf/EmfLord.js /
+EmfMaster.js / EmfManager.js, minus everything outside the hot path (PostgreSQL, worker
+processes, TCP cluster).  The NodeJS twin lives in ../../lib/emf/.  One process drives one
+GPU; with torch.distributed initialised, rows are sharded over the ranks and the solved
+shards are exchanged after every half-step (the role of 'alsSaveCalcedFactors',
+lib/emf/EmfMaster.js:711-723).
+"""
+import copy
+import datetime
+import json
+import math
+import os
+import shutil
+import time
+
+import numpy as np
+
+from .data import Csr
+from .trainer import AlsDevice
+
+
+def default_options():
+    """The path's subset of EmfBase.DefaultOptions (lib/emf/EmfBase.js:52-140)."""
+    return {
+        "dbType": "ml",
+        "maxRating": {"mal": 10, "ml": 5},
+        "als": {"userFactReg": 0.05, "itemFactReg": 0.05, "initFirstFactorAsAvgRating": False},
+        "factorsCount": 100,
+        "trainIters": 10,
+        "alg": "als",
+        "dataSetDistr": [85, 10, 5],
+        "ratingsInPortionForRmse": 10 * 1000,
+        "ratingsInPortionForAls": {"byUser": 10 * 1000, "byItem": 10 * 1000},
+        "numThreadsForTrain": {"als": os.cpu_count() or 1, "sgd": 1},
+        "numThreadsForRmse": os.cpu_count() or 1,
+        "useDoublePrecision": False,
+        # not in the reference: where the factor directories live (reference: <repo>/data)
+        "dataDir": "data",
+        # ratings per wave-level work unit on the GPU (0 = library default)
+        "chunkRatings": 0,
+    }
+
+
+def deepmerge(*dicts):
+    """deepmerge.all([...]) as used by EmfBase.init (lib/emf/EmfBase.js:284-287)."""
+    out = {}
+    for d in dicts:
+        for k, v in (d or {}).items():
+            if isinstance(v, dict) and isinstance(out.get(k), dict):
+                out[k] = deepmerge(out[k], v)
+            else:
+                out[k] = copy.deepcopy(v)
+    return out
+
+
+def split_to_portions(cnt_per_row, rows_cnt, ratings_in_portion, num_threads, pct=0):
+    """Row partitioner of EmfLord.splitToPortions (lib/emf/EmfLord.js:510-612) for one step.
+
+    cnt_per_row[id] <= 0 are the holes of the reference's sparse array.  pct: 0 for the ALS
+    steps, dataSetDistr[1]+1 / dataSetDistr[2]+1 for rmseValidate / rmseTest.
+    Returns (portionsRowIdTo [1-based inclusive upper ids], maxRatingsInPortion, maxRowsInPortion)."""
+    cnt = np.asarray(cnt_per_row, np.int64)
+    pos = cnt[cnt > 0]
+    if len(pos) == 0:
+        return np.zeros(0, np.int64), ratings_in_portion, 0
+    ratings_count = int(pos.sum())
+    max_per_row = int(pos.max())
+    if pct > 0:
+        ratings_count = math.ceil(ratings_count * (pct / 100))
+        max_per_row = math.ceil(max_per_row * (pct / 100))
+    avg_portions = math.ceil(ratings_count / ratings_in_portion)
+    if avg_portions < num_threads:
+        avg_portions = num_threads
+        ratings_in_portion = math.ceil(ratings_count / avg_portions)
+    if rows_cnt // max(avg_portions, 1) < 1:
+        avg_portions = rows_cnt
+        ratings_in_portion = math.ceil(ratings_count / avg_portions)
+    if ratings_in_portion < max_per_row:
+        ratings_in_portion = max_per_row
+    ids = np.nonzero(cnt > 0)[0]
+    c = cnt[ids]
+    if pct > 0:
+        c = np.ceil(c * (pct / 100)).astype(np.int64)
+    # greedy: open a new portion when the next row would overflow (EmfLord.js:582-591)
+    row_id_to, rtgs, rows, max_rows = [], 0, 0, 0
+    for j in range(len(ids)):
+        if rtgs + c[j] > ratings_in_portion:
+            rtgs, rows = 0, 0
+            row_id_to.append(0)
+        if not row_id_to:
+            row_id_to.append(0)
+        rtgs += int(c[j])
+        rows += 1
+        max_rows = max(max_rows, rows)
+        row_id_to[-1] = int(ids[j]) + 1
+    return np.asarray(row_id_to, np.int64), ratings_in_portion, max_rows
+
+
+def shard_ranges(counts, world):
+    """Contiguous, nnz-balanced row ranges for `world` ranks: the greedy cumulative cut of
+    splitToPortions (EmfLord.js:571-592) with one portion per GPU.  Returns int64[world+1]."""
+    counts = np.asarray(counts, np.int64)
+    cum = np.concatenate([[0], np.cumsum(counts)])
+    total = cum[-1]
+    b = [0]
+    for r in range(1, world):
+        b.append(int(np.searchsorted(cum, total * r / world, side="left")))
+    b.append(len(counts))
+    b = np.maximum.accumulate(np.asarray(b, np.int64))
+    return b
+
+
+class Dataset:
+    """What prepareToTrain leaves behind in the reference: the split ratings and stats
+    (EmfLord.getStats / splitToSets, lib/emf/EmfLord.js:48-250), here given directly.
+
+    train_by_user / train_by_item: Csr of dataset_type IN (1, 2) (EmfMaster.js:502-503);
+    validate / test: Csr by user of dataset_type 2 / 3 (may be None)."""
+
+    def __init__(self, train_by_user, train_by_item, validate=None, test=None, total_ratings_avg=None):
+        self.train_by_user, self.train_by_item = train_by_user, train_by_item
+        self.validate, self.test = validate, test
+        self.totalUsersCount = train_by_user.rows
+        self.totalItemsCount = train_by_user.cols
+        if total_ratings_avg is None:
+            v = train_by_user.vals
+            total_ratings_avg = float(v.double().mean()) if hasattr(v, "double") else float(np.mean(v, dtype=np.float64))
+        self.totalRatingsAvg = total_ratings_avg
+
+
+class HipBackend:
+    """The product compute backend: libycnr_als.so on cuda:<device>.  Factor matrices are
+    torch CUDA tensors bound into the handle so collectives run on them in place."""
+
+    def __init__(self, opts, users, items, device=0):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("ycnr_als needs a HIP device; there is no CPU fallback")
+        self.torch = torch
+        self.device = torch.device("cuda", device)
+        self.dtype_np = np.float64 if opts["useDoublePrecision"] else np.float32
+        tdt = torch.float64 if opts["useDoublePrecision"] else torch.float32
+        k = opts["factorsCount"]
+        self.dev = AlsDevice(k, users, items, opts["useDoublePrecision"], opts["als"]["userFactReg"],
+                             opts["als"]["itemFactReg"], device=device, chunkRatings=opts.get("chunkRatings", 0))
+        self.fac = [torch.zeros(users, k, dtype=tdt, device=self.device),
+                    torch.zeros(items, k, dtype=tdt, device=self.device)]
+        self.dev.bind_factors(0, self.fac[0])
+        self.dev.bind_factors(1, self.fac[1])
+
+    def factors(self, side):
+        return self.fac[side]
+
+    def set_factors(self, side, arr):
+        self.fac[side].copy_(self.torch.from_numpy(np.ascontiguousarray(arr, self.dtype_np)))
+        self.torch.cuda.synchronize(self.device)
+
+    def get_factors(self, side):
+        return self.fac[side].cpu().numpy()
+
+    def _vals(self, csr):
+        return csr.astype(self.dtype_np)
+
+    def set_ratings(self, side, csr, rb, re):
+        c = self._vals(csr)
+        self.dev.set_ratings(side, c.rowPtr, c.indx, c.vals, rb, re)
+
+    def set_rmse_ratings(self, which, csr, rb, re):
+        c = self._vals(csr)
+        self.dev.set_rmse_ratings(which, c.rowPtr, c.indx, c.vals, rb, re)
+
+    def step(self, side):
+        self.torch.cuda.synchronize(self.device)  # collectives on torch's stream are done
+        return self.dev.step(side)
+
+    def rmse(self, which, shift, portion_row_end):
+        return self.dev.rmse(which, shift, portion_row_end)
+
+    def destroy(self):
+        self.dev.destroy()
+
+
+class EmfLord:
+    """train() / alsTrainIter() / alsTrainStep() / calcRmse() of lib/emf/EmfLord.js:864-1081
+    and the result files of lib/emf/EmfManager.js:158-176,463-570, driving one GPU per process."""
+
+    STEP_SIDE = {"byUser": 0, "byItem": 1}
+
+    def __init__(self, config=None, options=None, backend_factory=None, dist=None):
+        config = config or {}
+        self.options = deepmerge(default_options(), config.get("common"), config.get("emf"), options)
+        self._status = ""
+        self.globalAvgShift = 0
+        self.globalBias = 0
+        self.calcCnt = 0
+        self.calcDate = None
+        self.trainIter = 0
+        self.rmse = None
+        self.predAvg = None
+        self.history = []
+        self.stepTimes = []
+        self._backend_factory = backend_factory or (lambda o, u, i, d: HipBackend(o, u, i, d))
+        self._dist = dist  # torch.distributed module when initialised, else None
+        self.rank = dist.get_rank() if dist else 0
+        self.world = dist.get_world_size() if dist else 1
+        self.backend = None
+        self.userFactorsFilename = "user_factors"  # EmfBase.js:289-293
+        self.itemFactorsFilename = "item_factors"
+        self.calcInfoFilename = "calc_info.json"
+
+    # -- EmfBase getters ---------------------------------------------------------------
+    @property
+    def status(self):
+        return self._status
+
+    @property
+    def factorsCount(self):
+        return self.options["factorsCount"]
+
+    @property
+    def factorsReadyPath(self):
+        return os.path.join(self.options["dataDir"], self.options["dbType"] + "_factors_ready")
+
+    @property
+    def factorsTempPath(self):
+        return os.path.join(self.options["dataDir"], self.options["dbType"] + "_factors_tmp")
+
+    # -- prepareToTrain (EmfLord.js:617-653, without the db) ---------------------------
+    def prepareToTrain(self, dataset, userFactors=None, itemFactors=None, seed=1, device=0):
+        """Upload the ratings (sharded by row over the ranks), build the RMSE portions and
+        create / load the factor matrices (prepareSharedFactors, EmfMaster.js:347-358)."""
+        if self.options["alg"] != "als":
+            raise ValueError("only alg='als' is implemented (sgd is obsolete in the reference, README.md:13)")
+        self._status = "preparing"
+        ds = self.dataset = dataset
+        self.totalUsersCount, self.totalItemsCount = ds.totalUsersCount, ds.totalItemsCount
+        self.totalRatingsAvg = ds.totalRatingsAvg
+        self.calcDate = datetime.datetime.now(datetime.timezone.utc).isoformat()
+        cu = _to_np(ds.train_by_user.counts())
+        ci = _to_np(ds.train_by_item.counts())
+        self.ratingsCntPerUser, self.ratingsCntPerItem = cu, ci
+        self.shards = {0: shard_ranges(cu, self.world), 1: shard_ranges(ci, self.world)}
+        self.backend = self._backend_factory(self.options, self.totalUsersCount, self.totalItemsCount, device)
+        ub, ue = self.shards[0][self.rank], self.shards[0][self.rank + 1]
+        ib, ie = self.shards[1][self.rank], self.shards[1][self.rank + 1]
+        self.backend.set_ratings(0, ds.train_by_user, int(ub), int(ue))
+        self.backend.set_ratings(1, ds.train_by_item, int(ib), int(ie))
+        self.trainRatingsCount = int(cu.sum())
+        # portions of the RMSE passes (EmfLord.js:523-598); kept as exclusive 0-based row ends
+        self.portionsRowIdTo = {}
+        nthreads = self.options["numThreadsForTrain"]["als"]
+        distr = self.options["dataSetDistr"]
+        for name, csr, pct in (("rmseValidate", ds.validate, distr[1] + 1), ("rmseTest", ds.test, distr[2] + 1)):
+            if csr is None:
+                continue
+            self.backend.set_rmse_ratings(name, csr, int(ub), int(ue))
+            ends, _, _ = split_to_portions(cu, self.totalUsersCount, self.options["ratingsInPortionForRmse"],
+                                           nthreads, pct)
+            if len(ends):
+                ends[-1] = self.totalUsersCount
+            self.portionsRowIdTo[name] = ends
+        from .data import init_factors
+        dt = np.float64 if self.options["useDoublePrecision"] else np.float32
+        k = self.factorsCount
+        if userFactors is None:
+            userFactors = init_factors(self.totalUsersCount, k, seed * 2 + 0, dt)
+        if itemFactors is None:
+            itemFactors = init_factors(self.totalItemsCount, k, seed * 2 + 1, dt)
+        self.backend.set_factors(0, userFactors)
+        self.backend.set_factors(1, itemFactors)
+        self._status = "ready"
+
+    # -- training ----------------------------------------------------------------------
+    def getCanTrainError(self):
+        if self._status == "training":
+            return "Training is already in progress"
+        if self._status != "ready":
+            return "Not ready to train. Status is " + self._status
+        return None
+
+    def train(self):
+        """EmfLord.train (lib/emf/EmfLord.js:864-926): trainIters x (alsTrainIter, rmseValidate,
+        rmseTest, rmseTest with shift), then saveCalcResults."""
+        err = self.getCanTrainError()
+        if err is not None:
+            raise RuntimeError(err)
+        self._status = "training"
+        self.trainIter = 0
+        while self.trainIter < self.options["trainIters"]:
+            self.alsTrainIter()
+            rec = {"iter": self.trainIter}
+            for name, shift in (("rmseValidate", False), ("rmseTest", False), ("rmseTest", True)):
+                r = self.calcRmse(name, shift)
+                if r is not None:
+                    rec[name + ("Shifted" if shift else "")] = r
+            rec["globalAvgShift"] = self.globalAvgShift
+            self.history.append(rec)
+            self.trainIter += 1
+        self.calcCnt += 1
+        if self.rank == 0:
+            self.saveCalcResults(self.getCalcInfo())
+        self._status = "ready"
+        return self.history
+
+    def alsTrainIter(self):
+        """2 steps - first fix item vectors and calc user vectors, then vice versa (EmfLord.js:954-958)."""
+        self.alsTrainStep("byUser")
+        self.alsTrainStep("byItem")
+
+    def alsTrainStep(self, stepType):
+        """EmfLord.alsTrainStep (lib/emf/EmfLord.js:963-984): resolves once every row of the side
+        has been re-solved everywhere, i.e. after the local step AND the exchange."""
+        side = self.STEP_SIDE[stepType]
+        t0 = time.perf_counter()
+        info = self.backend.step(side)
+        self._exchange(side)
+        self.stepTimes.append({"stepType": stepType, "iter": self.trainIter, "info": info,
+                               "wall": time.perf_counter() - t0})
+        return info
+
+    def _exchange(self, side):
+        """All-gather of the freshly solved shard into every rank's replica of the matrix."""
+        if self.world == 1:
+            return
+        dist = self._dist
+        b = self.shards[side]
+        sizes = (b[1:] - b[:-1]).astype(np.int64)
+        mx = int(sizes.max())
+        fac = self.backend.factors(side)  # torch tensor [rows, k]
+        k = fac.shape[1]
+        torch = _torch()
+        if not hasattr(self, "_xbuf") or self._xbuf.get(side) is None or self._xbuf[side].shape[1] != mx:
+            self._xbuf = getattr(self, "_xbuf", {})
+            self._xbuf[side] = torch.zeros(self.world, mx, k, dtype=fac.dtype, device=fac.device)
+        buf = self._xbuf[side]
+        lo, hi = int(b[self.rank]), int(b[self.rank + 1])
+        buf[self.rank, : hi - lo].copy_(fac[lo:hi])
+        dist.all_gather_into_tensor(buf.view(-1), buf[self.rank].reshape(-1))
+        for r in range(self.world):
+            if r == self.rank:
+                continue
+            lo, hi = int(b[r]), int(b[r + 1])
+            if hi > lo:
+                fac[lo:hi].copy_(buf[r, : hi - lo])
+
+    # -- RMSE ----------------------------------------------------------------------------
+    def calcRmse(self, stepType, useGlobalAvgShift):
+        """EmfLord.calcRmse + EmfMaster._startCalcRmse / m_completedPortion
+        (lib/emf/EmfLord.js:1043-1081, EmfMaster.js:389-412,757-786)."""
+        distr = self.options["dataSetDistr"]
+        if distr[1] == 0 and stepType == "rmseValidate":
+            return None
+        if distr[2] == 0 and stepType == "rmseTest":
+            return None
+        if stepType not in self.portionsRowIdTo:
+            return None
+        calcGlobalAvgShift = not useGlobalAvgShift
+        if calcGlobalAvgShift:
+            self.globalAvgShift = 0
+        parts = self.backend.rmse(stepType, self.globalAvgShift, self.portionsRowIdTo[stepType])
+        if self.world > 1:
+            torch = _torch()
+            t = torch.from_numpy(parts).to(self.backend.factors(0).device)
+            self._dist.all_reduce(t)
+            parts = t.cpu().numpy()
+        rSumDiff2, rCnt, rSum = parts[:, 0].sum(), parts[:, 1].sum(), parts[:, 2].sum()
+        self.rSumDiff2, self.rCnt, self.rSum = float(rSumDiff2), float(rCnt), float(rSum)
+        self.rmse = math.sqrt(1.0 * rSumDiff2 / rCnt) if rCnt > 0 else float("nan")
+        # reference quirk (EmfMaster.js:779): predAvg comes from the LAST completed portion's
+        # sums, not the totals.  Portions complete in any order there; here "last" is the
+        # highest-numbered non-empty portion.
+        nz = np.nonzero(parts[:, 1] > 0)[0]
+        if len(nz):
+            last = parts[nz[-1]]
+            self.predAvg = float(last[2] / last[1])
+            if calcGlobalAvgShift:
+                self.globalAvgShift = self.totalRatingsAvg - self.predAvg
+        return self.rmse
+
+    # -- results (EmfManager.js:158-176,463-570) ---------------------------------------------
+    def getCalcInfo(self):
+        o = self.options
+        return {
+            "alg": o["alg"],
+            "algOptions": o[o["alg"]],
+            "useDoublePrecision": o["useDoublePrecision"],
+            "factorsCount": self.factorsCount,
+            "dataSetDistr": o["dataSetDistr"],
+            "totalUsersCount": self.totalUsersCount,
+            "totalItemsCount": self.totalItemsCount,
+            "dbType": o["dbType"],
+            "calcDate": self.calcDate,
+            "calcCnt": self.calcCnt,
+            "globalAvgShift": self.globalAvgShift,
+            "globalBias": self.globalBias,
+        }
+
+    def saveCalcResults(self, calcInfo):
+        """Headerless raw dumps user_factors / item_factors + calc_info.json, written to
+        <dbType>_factors_tmp and renamed to <dbType>_factors_ready
+        (EmfManager._saveCalcResultsToRecommender, lib/emf/EmfManager.js:531-568)."""
+        tmp, ready = self.factorsTempPath, self.factorsReadyPath
+        os.makedirs(tmp, exist_ok=True)
+        self.backend.get_factors(0).tofile(os.path.join(tmp, self.userFactorsFilename))
+        self.backend.get_factors(1).tofile(os.path.join(tmp, self.itemFactorsFilename))
+        with open(os.path.join(tmp, self.calcInfoFilename), "w") as f:
+            f.write(json.dumps(calcInfo, indent=2))
+        if os.path.isdir(ready):
+            shutil.rmtree(ready)
+        os.rename(tmp, ready)
+
+    def loadCalcResults(self):
+        """(calc_info, userFactors, itemFactors) from <dbType>_factors_ready, or None when the
+        files cannot be reused (EmfManager._canReuseCalcResults, lib/emf/EmfManager.js:179-191)."""
+        p = os.path.join(self.factorsReadyPath, self.calcInfoFilename)
+        if not os.path.exists(p):
+            return None
+        ci = json.load(open(p))
+        o = self.options
+        if not (ci.get("alg") == o["alg"] and ci.get("dbType") == o["dbType"]
+                and ci.get("factorsCount") == self.factorsCount
+                and ci.get("useDoublePrecision") == o["useDoublePrecision"]):
+            return None
+        dt = np.float64 if ci["useDoublePrecision"] else np.float32
+        k = ci["factorsCount"]
+        U = np.fromfile(os.path.join(self.factorsReadyPath, self.userFactorsFilename), dt).reshape(-1, k)
+        V = np.fromfile(os.path.join(self.factorsReadyPath, self.itemFactorsFilename), dt).reshape(-1, k)
+        return ci, U, V
+
+    def destroy(self):
+        if self.backend is not None:
+            self.backend.destroy()
+            self.backend = None
+        self._status = "destroyed"
+
+
+def _to_np(x):
+    return x if isinstance(x, np.ndarray) else x.cpu().numpy()
+
+
+def _torch():
+    import torch
+    return torch

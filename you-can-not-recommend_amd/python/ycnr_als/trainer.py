@@ -1,0 +1,196 @@
+"""Thin object wrapper over the level-1 and level-2 C ABI (include/ycnr_als.h).
+
+Accepts numpy arrays (host memory) or torch CUDA tensors (device memory) for ratings and
+factors.  All arithmetic happens in libycnr_als.so on the GPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import BY_ITEM, BY_USER, F32, F64, MEM_DEVICE, MEM_HOST, RMSE_TEST, RMSE_VALIDATE, check
+
+SIDES = {"byUser": BY_USER, "byItem": BY_ITEM, BY_USER: BY_USER, BY_ITEM: BY_ITEM}
+RMSE_SETS = {"rmseValidate": RMSE_VALIDATE, "rmseTest": RMSE_TEST, RMSE_VALIDATE: RMSE_VALIDATE,
+             RMSE_TEST: RMSE_TEST}
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def _ptr_kind(x, dtype=None):
+    """(address, memKind) of a numpy array or torch tensor; checks dtype and contiguity."""
+    if _is_torch(x):
+        import torch
+        want = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64,
+                np.dtype(np.int32): torch.int32, np.dtype(np.int64): torch.int64}
+        if dtype is not None and x.dtype != want[np.dtype(dtype)]:
+            raise TypeError("invalid type!")  # cpp_utils/cpp_utils.js:12
+        if not x.is_contiguous():
+            raise ValueError("tensor must be contiguous")
+        return x.data_ptr(), (MEM_DEVICE if x.is_cuda else MEM_HOST)
+    a = x
+    if dtype is not None and a.dtype != np.dtype(dtype):
+        raise TypeError("invalid type!")
+    if not a.flags["C_CONTIGUOUS"]:
+        raise ValueError("array must be C-contiguous")
+    return a.ctypes.data, MEM_HOST
+
+
+def _portion_prefix(vals):
+    if vals.dtype == np.float32:
+        return "s"
+    if vals.dtype == np.float64:
+        return "d"
+    raise TypeError("invalid type!")
+
+
+def als_calc_portion(lam, k, alsRows, alsIndx, alsVals, fixedFactors, solvedFactors):
+    """Level 1: drop-in for the body of EmfWorker.mw_calcTrainAlsPortion (EmfWorker.js:176-251).
+
+    Host numpy buffers; solvedFactors rows named in alsRows are overwritten in place.
+    Returns ratingsInPortion."""
+    L = _lib.load()
+    p = _portion_prefix(alsVals)
+    for a, dt in ((alsRows, np.int32), (alsIndx, np.int32), (fixedFactors, alsVals.dtype),
+                  (solvedFactors, alsVals.dtype)):
+        if a.dtype != np.dtype(dt) or not a.flags["C_CONTIGUOUS"]:
+            raise TypeError("invalid type!")
+    f = getattr(L, f"ycnr_{p}AlsCalcPortion")
+    return check(f(float(lam), int(k), alsRows.ctypes.data, alsIndx.ctypes.data, alsVals.ctypes.data,
+                   fixedFactors.ctypes.data, fixedFactors.size // k, solvedFactors.ctypes.data,
+                   solvedFactors.size // k))
+
+
+def rmse_portion(k, rmseRows, rmseIndx, rmseVals, userFactors, itemFactors, globalAvgShift=0.0):
+    """Level 1: drop-in for EmfWorker.mw_calcRmsePortion (EmfWorker.js:266-315).
+    Returns np.array([rSumDiff2, rCnt, rSum])."""
+    L = _lib.load()
+    p = _portion_prefix(rmseVals)
+    out = np.zeros(3, np.float64)
+    f = getattr(L, f"ycnr_{p}RmsePortion")
+    check(f(int(k), rmseRows.ctypes.data, rmseIndx.ctypes.data, rmseVals.ctypes.data, userFactors.ctypes.data,
+            userFactors.size // k, itemFactors.ctypes.data, itemFactors.size // k, float(globalAvgShift),
+            out.ctypes.data))
+    return out
+
+
+class AlsDevice:
+    """Level 2: resident trainer handle (one per GPU / process)."""
+
+    def __init__(self, factorsCount, totalUsersCount, totalItemsCount, useDoublePrecision=False,
+                 userFactReg=0.05, itemFactReg=0.05, device=0, chunkRatings=0):
+        self._L = _lib.load()
+        self.k = int(factorsCount)
+        self.users = int(totalUsersCount)
+        self.items = int(totalItemsCount)
+        self.dtype = np.float64 if useDoublePrecision else np.float32
+        o = _lib.Options()
+        o.struct_size = C.sizeof(_lib.Options)
+        o.device = int(device)
+        o.dtype = F64 if useDoublePrecision else F32
+        o.factorsCount = self.k
+        o.totalUsersCount = self.users
+        o.totalItemsCount = self.items
+        o.userFactReg = float(userFactReg)
+        o.itemFactReg = float(itemFactReg)
+        o.chunkRatings = int(chunkRatings)
+        h = C.c_void_p()
+        check(self._L.ycnr_als_create(C.byref(o), C.byref(h)))
+        self._h = h
+        self._keep = {}  # bound external tensors stay alive with the handle
+
+    # -- lifetime -------------------------------------------------------------------
+    def destroy(self):
+        if getattr(self, "_h", None):
+            self._L.ycnr_als_destroy(self._h)
+            self._h = None
+            self._keep = {}
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+    def rows(self, side):
+        return self.users if SIDES[side] == BY_USER else self.items
+
+    # -- data -----------------------------------------------------------------------
+    def set_stream(self, hip_stream):
+        check(self._L.ycnr_als_set_stream(self._h, C.c_void_p(hip_stream or 0)))
+
+    def _upload(self, fn, key, rowPtr, indx, vals, rowBegin, rowEnd):
+        n = (len(rowPtr) if not _is_torch(rowPtr) else rowPtr.numel()) - 1
+        if rowEnd is None:
+            rowEnd = n
+        p0, k0 = _ptr_kind(rowPtr, np.int64)
+        p1, k1 = _ptr_kind(indx, np.int32)
+        p2, k2 = _ptr_kind(vals, self.dtype)
+        if not (k0 == k1 == k2):
+            raise ValueError("rowPtr, indx and vals must live in the same kind of memory")
+        check(fn(self._h, key, p0, p1, p2, int(rowBegin), int(rowEnd), k0))
+
+    def set_ratings(self, side, rowPtr, indx, vals, rowBegin=0, rowEnd=None):
+        self._upload(self._L.ycnr_als_set_ratings, SIDES[side], rowPtr, indx, vals, rowBegin, rowEnd)
+
+    def set_rmse_ratings(self, which, rowPtr, indx, vals, rowBegin=0, rowEnd=None):
+        self._upload(self._L.ycnr_als_set_rmse_ratings, RMSE_SETS[which], rowPtr, indx, vals, rowBegin, rowEnd)
+
+    def set_factors(self, side, src):
+        p, kind = _ptr_kind(src, self.dtype)
+        n = src.numel() if _is_torch(src) else src.size
+        if n != self.rows(side) * self.k:
+            raise ValueError("factor matrix has the wrong size")
+        check(self._L.ycnr_als_set_factors(self._h, SIDES[side], p, kind))
+
+    def get_factors(self, side, rowBegin=0, rowCount=None):
+        if rowCount is None:
+            rowCount = self.rows(side) - rowBegin
+        out = np.empty((rowCount, self.k), self.dtype)
+        check(self._L.ycnr_als_get_factors(self._h, SIDES[side], out.ctypes.data, int(rowBegin), int(rowCount),
+                                           MEM_HOST))
+        return out
+
+    def factors_ptr(self, side):
+        p = C.c_void_p()
+        check(self._L.ycnr_als_factors_ptr(self._h, SIDES[side], C.byref(p)))
+        return p.value
+
+    def bind_factors(self, side, tensor):
+        """Adopt a torch CUDA tensor [rows, k] as the side's factor matrix (no copy)."""
+        p, kind = _ptr_kind(tensor, self.dtype)
+        if kind != MEM_DEVICE or tensor.numel() != self.rows(side) * self.k:
+            raise ValueError("bind_factors needs a CUDA tensor of shape [rows, k]")
+        check(self._L.ycnr_als_bind_factors(self._h, SIDES[side], p))
+        self._keep[SIDES[side]] = tensor
+
+    # -- compute --------------------------------------------------------------------
+    def step(self, side):
+        """One half-step = EmfLord.alsTrainStep(stepType) (EmfLord.js:963-984). Returns StepInfo."""
+        check(self._L.ycnr_als_step(self._h, SIDES[side]))
+        return self.last_step_info()
+
+    def step_async(self, side):
+        check(self._L.ycnr_als_step_async(self._h, SIDES[side]))
+
+    def sync(self):
+        check(self._L.ycnr_als_sync(self._h))
+
+    def last_step_info(self):
+        info = _lib.StepInfo()
+        check(self._L.ycnr_als_last_step_info(self._h, C.byref(info)))
+        return info
+
+    def rmse(self, which, globalAvgShift=0.0, portionRowEnd=None):
+        """Partial sums per portion: array [nPortions, 3] of {rSumDiff2, rCnt, rSum}."""
+        if portionRowEnd is None or len(portionRowEnd) == 0:
+            out = np.zeros((1, 3), np.float64)
+            check(self._L.ycnr_als_rmse(self._h, RMSE_SETS[which], float(globalAvgShift), 0, None, out.ctypes.data))
+            return out
+        ends = np.ascontiguousarray(portionRowEnd, np.int64)
+        out = np.zeros((len(ends), 3), np.float64)
+        check(self._L.ycnr_als_rmse(self._h, RMSE_SETS[which], float(globalAvgShift), len(ends), ends.ctypes.data,
+                                    out.ctypes.data))
+        return out
