@@ -193,22 +193,31 @@ def cpu_baseline(lord, by_user, by_item, k, args):
     dt = np.float64 if args.double else np.float32
     U = lord.backend.get_factors(0)
     V = lord.backend.get_factors(1)
-    # rough speed model to size the sample: ~1.5 GFLOP/s per core for the scalar port
-    budget = args.cpu_seconds * 0.5 * 1.5e9 * cores
+    def cost_of(cnt):
+        return cnt * (2.0 * k * k + 2 * k) + (cnt > 0) * (2.0 / 3 * k ** 3 + 2 * k * k)
 
-    def sample(csr, fixed, solved, lam):
-        rp = csr.rowPtr.cpu().numpy()
-        cnt = rp[1:] - rp[:-1]
-        cost = np.cumsum(cnt * (2.0 * k * k + 2 * k) + (cnt > 0) * (2.0 / 3 * k ** 3 + 2 * k * k))
-        rows = int(np.searchsorted(cost, budget)) + 1
-        rows = max(1, min(rows, csr.rows))
+    def run(csr, rp, rows, fixed, solved, lam):
         e = int(rp[rows])
         indx = csr.indx[:e].cpu().numpy()
         vals = csr.vals[:e].cpu().numpy().astype(dt)
         out = solved.copy()
         t = time.perf_counter()
         n = orc.als_step_csr(lam, k, np.ascontiguousarray(rp[:rows + 1]), indx, vals, fixed, out, 0, rows, threads=cores)
-        return n, time.perf_counter() - t, rows
+        return n, time.perf_counter() - t
+
+    def sample(csr, fixed, solved, lam):
+        """Probe a small prefix to measure this box's flop rate, then time a prefix sized for
+        about cpu_seconds / 2 of CPU work (bounded: the default run must finish in minutes)."""
+        rp = csr.rowPtr.cpu().numpy()
+        cost = np.cumsum(cost_of(rp[1:] - rp[:-1]))
+        probe_rows = max(1, min(csr.rows, int(np.searchsorted(cost, 2e9 * min(cores, 16))) + 1))
+        n, t = run(csr, rp, probe_rows, fixed, solved, lam)
+        rate = cost[probe_rows - 1] / max(t, 1e-3)
+        rows = max(1, min(csr.rows, int(np.searchsorted(cost, rate * args.cpu_seconds * 0.5)) + 1))
+        if rows <= probe_rows:
+            return n, t, probe_rows
+        n, t = run(csr, rp, rows, fixed, solved, lam)
+        return n, t, rows
 
     nu, tu, ru = sample(by_user, V, U, 0.05)
     ni, ti, ri = sample(by_item, U, V, 0.05)

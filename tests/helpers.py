@@ -34,12 +34,18 @@ def csr_of(R, mask):
 
 
 def numpy_row_solve(lam, k, cols_idx, vals, fixed):
-    """Independent second opinion (LAPACK through numpy, float64): returns x and cond(A)."""
+    """Independent second opinion (LAPACK through numpy, float64): returns x and the
+    amplification factor of a working-precision solve of this row,
+        amp = cond(A) * || |Y|^T |r| || / || Y^T r ||,
+    i.e. the conditioning of the solve times the cancellation in forming b = Y^T r
+    (forward error of x <= c * amp * eps, Higham, Accuracy and Stability, thm 7.2 + 3.5)."""
     Y = fixed[cols_idx].astype(np.float64)
+    r = vals.astype(np.float64)
     n = len(cols_idx)
     A = Y.T @ Y + (lam * n) * np.eye(k)
-    b = Y.T @ vals.astype(np.float64)
-    return np.linalg.solve(A, b), np.linalg.cond(A)
+    b = Y.T @ r
+    kb = np.linalg.norm(np.abs(Y).T @ np.abs(r)) / max(np.linalg.norm(b), 1e-300)
+    return np.linalg.solve(A, b), np.linalg.cond(A) * max(kb, 1.0)
 
 
 def numpy_step(lam, k, csr, fixed, solved):

@@ -1,0 +1,128 @@
+"""Host logic of the product (options, partitioners, train loop, result files) exercised on
+CPU with the oracle standing in for the GPU backend."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import OracleBackend, make_problem
+from ycnr_als.data import Csr, csr_to_portion, init_factors
+from ycnr_als.emf import Dataset, EmfLord, deepmerge, default_options, shard_ranges
+
+
+def oracle_factory(o, u, i, d):
+    return OracleBackend(o, u, i, d)
+
+
+def small_dataset(seed=0, users=50, items=35, dt=np.float32):
+    bu, bi, U, V = make_problem(users, items, 8, density=0.3, seed=seed, dtype=dt, min_per_row=2)
+    # validate = every 4th rating, test = a disjoint every 9th
+    sel = np.arange(bu.nnz)
+    val = pick(bu, sel % 4 == 0)
+    tst = pick(bu, sel % 9 == 1)
+    return Dataset(bu, bi, val, tst, float(bu.vals.mean())), U, V
+
+
+def pick(c, mask):
+    rows_of = np.repeat(np.arange(c.rows), c.counts())
+    cnt = np.bincount(rows_of[mask], minlength=c.rows)
+    rp = np.zeros(c.rows + 1, np.int64)
+    rp[1:] = np.cumsum(cnt)
+    return Csr(c.rows, c.cols, rp, c.indx[mask].copy(), c.vals[mask].copy())
+
+
+def test_option_names_follow_the_reference():
+    o = default_options()
+    for key in ("factorsCount", "trainIters", "useDoublePrecision", "dataSetDistr", "ratingsInPortionForAls",
+                "ratingsInPortionForRmse", "numThreadsForTrain", "alg", "dbType"):
+        assert key in o
+    assert o["als"]["userFactReg"] == 0.05 and o["als"]["itemFactReg"] == 0.05  # EmfBase.js:67-69
+    assert o["factorsCount"] == 100 and o["trainIters"] == 10 and o["useDoublePrecision"] is False
+    m = deepmerge(o, {"als": {"userFactReg": 0.1}}, {"factorsCount": 20})
+    assert m["als"] == {"userFactReg": 0.1, "itemFactReg": 0.05, "initFirstFactorAsAvgRating": False}
+    assert m["factorsCount"] == 20 and o["factorsCount"] == 100
+
+
+def test_shard_ranges_are_contiguous_and_balanced():
+    rng = np.random.default_rng(0)
+    cnt = rng.integers(0, 100, 1000)
+    for w in (1, 2, 3, 8):
+        b = shard_ranges(cnt, w)
+        assert b[0] == 0 and b[-1] == 1000 and (np.diff(b) >= 0).all() and len(b) == w + 1
+        loads = [cnt[b[i]:b[i + 1]].sum() for i in range(w)]
+        assert max(loads) - min(loads) <= 2 * cnt.max()
+    assert list(shard_ranges(np.array([5, 0, 0, 0]), 2)) == [0, 1, 4]  # one heavy row, rest empty
+    assert list(shard_ranges(np.zeros(4, np.int64), 2)) [0] == 0
+
+
+def test_portion_views_of_a_csr():
+    bu, _, _, _ = make_problem(20, 15, 4, density=0.3, seed=3, empty_rows=(0, 7, 19))
+    rows, indx, vals = csr_to_portion(bu, 0, 20)
+    assert rows[0] == 17 and rows[2::2].sum() == bu.nnz
+    assert 0 not in rows[1::2] and 7 not in rows[1::2]
+    assert np.array_equal(indx, bu.indx) and np.array_equal(vals, bu.vals)
+
+
+def test_train_loop_and_result_files(tmp_path):
+    ds, U, V = small_dataset()
+    lord = EmfLord(options={"factorsCount": 8, "trainIters": 4, "dataDir": str(tmp_path), "dbType": "ml",
+                            "ratingsInPortionForRmse": 40}, backend_factory=oracle_factory)
+    with pytest.raises(RuntimeError, match="Not ready to train"):
+        lord.train()
+    lord.prepareToTrain(ds, U, V)
+    assert lord.status == "ready"
+    hist = lord.train()
+    assert len(hist) == 4 and [h["iter"] for h in hist] == [0, 1, 2, 3]
+    assert hist[-1]["rmseValidate"] < hist[0]["rmseValidate"]
+    for h in hist:
+        assert set(h) >= {"rmseValidate", "rmseTest", "rmseTestShifted", "globalAvgShift"}
+    ready = tmp_path / "ml_factors_ready"
+    assert sorted(os.listdir(ready)) == ["calc_info.json", "item_factors", "user_factors"]
+    assert not (tmp_path / "ml_factors_tmp").exists()  # renamed, EmfManager.js:557
+    assert os.path.getsize(ready / "user_factors") == 50 * 8 * 4  # headerless raw dump, EmfBase.js:384
+    assert os.path.getsize(ready / "item_factors") == 35 * 8 * 4
+    text = (ready / "calc_info.json").read_text()
+    ci = json.loads(text)
+    assert text == json.dumps(ci, indent=2)  # JSON.stringify(calcInfo, null, 2), EmfManager.js:549
+    assert list(ci) == ["alg", "algOptions", "useDoublePrecision", "factorsCount", "dataSetDistr", "totalUsersCount",
+                        "totalItemsCount", "dbType", "calcDate", "calcCnt", "globalAvgShift", "globalBias"]
+    assert ci["calcCnt"] == 1 and ci["totalUsersCount"] == 50 and ci["totalItemsCount"] == 35
+    got = np.fromfile(ready / "user_factors", np.float32).reshape(50, 8)
+    assert np.array_equal(got, lord.backend.get_factors(0))
+    # warm start is possible only with matching alg / dbType / factorsCount / precision (EmfManager.js:179-191)
+    assert lord.loadCalcResults() is not None
+    other = EmfLord(options={"factorsCount": 9, "dataDir": str(tmp_path), "dbType": "ml"}, backend_factory=oracle_factory)
+    assert other.loadCalcResults() is None
+
+
+def test_rmse_reduce_and_shift_quirk(oracle):
+    """rmse = sqrt(sum / cnt) over all portions, but predAvg (hence globalAvgShift) uses the LAST
+    portion's sums only (EmfMaster.js:778-782)."""
+    ds, U, V = small_dataset(seed=2)
+    lord = EmfLord(options={"factorsCount": 8, "ratingsInPortionForRmse": 25, "numThreadsForTrain": {"als": 1}},
+                   backend_factory=oracle_factory)
+    lord.prepareToTrain(ds, U, V)
+    ends = lord.portionsRowIdTo["rmseTest"]
+    assert len(ends) > 2
+    r = lord.calcRmse("rmseTest", False)
+    t = ds.test
+    tot = oracle.rmse_csr(8, t.rowPtr, t.indx, t.vals, U, V, 0.0)
+    assert abs(r - np.sqrt(tot[0] / tot[1])) < 1e-12
+    last = oracle.rmse_csr(8, t.rowPtr, t.indx, t.vals, U, V, 0.0, int(ends[-2]), 50)
+    assert abs(lord.predAvg - last[2] / last[1]) < 1e-12
+    assert abs(lord.globalAvgShift - (ds.totalRatingsAvg - lord.predAvg)) < 1e-12
+    shift = lord.globalAvgShift
+    r2 = lord.calcRmse("rmseTest", True)  # applies, does not recompute
+    assert lord.globalAvgShift == shift
+    tot2 = oracle.rmse_csr(8, t.rowPtr, t.indx, t.vals, U, V, shift)
+    assert abs(r2 - np.sqrt(tot2[0] / tot2[1])) < 1e-12
+    lord.options["dataSetDistr"] = [90, 10, 0]
+    assert lord.calcRmse("rmseTest", False) is None  # EmfLord.js:1048
+
+
+def test_init_factors_are_seeded_and_scaled():
+    a = init_factors(1000, 50, 3)
+    b = init_factors(1000, 50, 3)
+    assert np.array_equal(a, b) and a.dtype == np.float32
+    assert abs(a.std() - 1 / 50) < 2e-3  # randomNormal(1 / factorsCount), EmfBase.js:486
