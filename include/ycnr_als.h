@@ -109,8 +109,12 @@ typedef struct ycnr_als_options {
   double userFactReg;      /* options.als.userFactReg (EmfBase.js:67) */
   double itemFactReg;      /* options.als.itemFactReg (EmfBase.js:69) */
   int32_t chunkRatings;    /* ratings per work unit for split rows; 0 = default */
-  int32_t flags;           /* reserved, 0 */
+  int32_t flags;           /* YCNR_FLAG_* bits, normally 0 */
 } ycnr_als_options;
+
+/* options.flags: use the plain LDS Cholesky for float32 too (float64 always uses it); the
+ * default float32 solve is the register-resident MFMA block Cholesky. For A/B tests. */
+#define YCNR_FLAG_LDS_SOLVER 1
 
 /* Timing / accounting of the last ycnr_als_step, measured with HIP events on the
  * handle's stream around each kernel (DESIGN.md "Measurement"). */

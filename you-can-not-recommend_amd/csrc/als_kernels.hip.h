@@ -248,6 +248,227 @@ struct SolveLds {
   }
 };
 
+// ---------------------------------------------------------------------------------------
+// Version 2 of the float32 solve: block Cholesky that never leaves the register file.
+//
+// A (upper 16x16 tiles, MFMA C/D layout: lane (g = l>>4, c = l&15), reg t <-> row 4g+t, col c)
+// is factored as A = U^T U block row by block row (right-looking, NB block steps):
+//   1. the 16x16 diagonal tile D goes through a 1.25 KB LDS image to a lane-per-row form;
+//      lanes 0-15 run a right-looking Cholesky of D (lane i = row i of L) while lanes 16-31
+//      apply the very same instruction stream to the identity (lane 16+c = column c of
+//      L^-1): per pivot one v_rsq, one scale and (15-p) v_readlane + v_fma pairs;
+//   2. W = L^-1 comes back through LDS twice: in C/D layout (kept in place of D, used by
+//      the triangular solves) and in MFMA A-operand layout;
+//   3. panel: U[J][bj] = W * T[J][bj] -- 4 MFMAs per tile; the B operand is T's own
+//      registers after a 4x4 (register <-> lane-group) transpose made of two
+//      v_permlane16_swap + two v_permlane32_swap;
+//   4. trailing update: T[bi][bj] -= U[J][bi]^T U[J][bj] -- 4 MFMAs per tile from the
+//      transposed panel registers;
+//   5. the right-hand side rides along on the VALU: z_J = W b_J (row sums by DPP row_ror),
+//      b_bj -= U[J][bj]^T z_J (sums over lane groups); back substitution mirrors it.
+// Only MFMA, VALU, DPP and ~20 LDS instructions per block step; no barrier other than the
+// wave's own LDS ordering.  k need not be a multiple of 16: the padded diagonal is 1.
+template <int NB>
+struct SolveMfmaF32 {
+  using Tr = MfmaTraits<float>;
+  using acc_t = typename Tr::acc_t;
+  static constexpr int NT = tile_count(NB);
+  static constexpr int LDW = 20;  // floats per LDS image row: 80 B keeps b128 accesses aligned
+  static constexpr size_t lds_bytes() { return 2 * 16 * LDW * sizeof(float); }
+
+  template <int N>
+  static __device__ __forceinline__ float row_ror(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xF, 0xF, false));
+  }
+  // sum over the 16 lanes of each lane group, result in every lane of the group
+  static __device__ __forceinline__ float row_sum(float v) {
+    v += row_ror<8>(v);
+    v += row_ror<4>(v);
+    v += row_ror<2>(v);
+    v += row_ror<1>(v);
+    return v;
+  }
+  // sum over the 4 lane groups (same c), result in every group
+  static __device__ __forceinline__ float group_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+  }
+  static __device__ __forceinline__ float readlane(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+  }
+  // out[q] at lane (g, c) = in[g] at lane (q, c): 4x4 transpose between the register index
+  // and the lane-group index
+  static __device__ __forceinline__ void transpose_rg(const acc_t &in, float (&out)[4]) {
+    // Written as inline asm: with ROCm 7.2's __builtin_amdgcn_permlane{16,32}_swap hipcc folded
+    // the four inputs into one (devtest/panelprobe.hip shows a single load feeding all swaps).
+    // v_permlane16_swap a, b: a.row1 <-> b.row0, a.row3 <-> b.row2 (row = 16 lanes)
+    // v_permlane32_swap a, b: a.rows{2,3} <-> b.rows{0,1}
+    // The s_nop covers the VALU-write -> permlane-swap-read wait states hipcc does not insert
+    // around inline asm.
+    float r0 = in[0], r1 = in[1], r2 = in[2], r3 = in[3];
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(r0), "+v"(r1));
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(r2), "+v"(r3));
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(r0), "+v"(r2));
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(r1), "+v"(r3));
+    out[0] = r0;
+    out[1] = r1;
+    out[2] = r2;
+    out[3] = r3;
+  }
+
+  static __device__ __forceinline__ void run(acc_t (&acc)[NT], const float (&bacc)[NB], float *S, int k, float lam,
+                                             float *__restrict__ out_row, int row, ErrInfo *err, int lane) {
+    const int g = lane >> 4, c = lane & 15;
+    float *Dt = S;             // D image, [row][col], row stride LDW
+    float *Wt = S + 16 * LDW;  // W image stored transposed: Wt[col][row] = W[row][col]
+    // right-hand side in column form: bcol[cb] = b[16 cb + c], the same in all four lane groups
+    float bcol[NB];
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) bcol[cb] = group_sum(bacc[cb]);
+    // A += lam I on the real diagonal, 1 on the padded one (rows/cols >= k are otherwise 0)
+    {
+      const bool mine = (c >> 2) == g;
+      const int t0 = c & 3;
+#pragma unroll
+      for (int bi = 0; bi < NB; ++bi) {
+        const float add = (bi * 16 + c < k) ? lam : 1.0f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[tile_index(bi, bi, NB)][t] += (mine && t == t0) ? add : 0.0f;
+      }
+    }
+    bool bad = false;
+    float zrow[NB][4];  // z in row form: zrow[J][t] = z[16 J + 4 g + t] in every lane of group g
+#pragma unroll
+    for (int J = 0; J < NB; ++J) {
+      // ---- 1. diagonal tile -> LDS -> lane-per-row Cholesky + inverse
+      {
+        const acc_t d = acc[tile_index(J, J, NB)];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) Dt[(4 * g + t) * LDW + c] = d[t];
+      }
+      __syncthreads();
+      float R[16];
+      {
+        const bool xlane = (g & 1) != 0;  // groups 1 and 3 carry the identity, 0 and 2 carry D
+        const float4 *src = reinterpret_cast<const float4 *>(Dt + c * LDW);
+#pragma unroll
+        for (int m4 = 0; m4 < 4; ++m4) {
+          const float4 v = src[m4];
+          R[4 * m4 + 0] = xlane ? (c == 4 * m4 + 0 ? 1.0f : 0.0f) : v.x;
+          R[4 * m4 + 1] = xlane ? (c == 4 * m4 + 1 ? 1.0f : 0.0f) : v.y;
+          R[4 * m4 + 2] = xlane ? (c == 4 * m4 + 2 ? 1.0f : 0.0f) : v.z;
+          R[4 * m4 + 3] = xlane ? (c == 4 * m4 + 3 ? 1.0f : 0.0f) : v.w;
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < 16; ++p) {
+        float d = readlane(R[p], p);  // D[p][p] after the updates of pivots < p (lane p, group 0)
+        if (!(d > 0.0f)) {
+          bad = bad || (J * 16 + p < k);
+          d = 1.0f;
+        }
+        float rs = __builtin_amdgcn_rsqf(d);
+        rs = rs * (1.5f - 0.5f * d * rs * rs);  // one Newton step: full float accuracy
+        R[p] *= rs;                             // L[i][p] in lanes 0-15, Linv[p][c] in lanes 16-31
+#pragma unroll
+        for (int j = p + 1; j < 16; ++j) {
+          const float s = readlane(R[p], j);  // L[j][p]
+          R[j] = fmaf(-R[p], s, R[j]);
+        }
+      }
+      // ---- 2. W = L^-1 (column c in lanes 16-31) -> LDS -> C/D layout and A-operand layout
+      if (g == 1) {
+        float4 *dst = reinterpret_cast<float4 *>(Wt + c * LDW);
+#pragma unroll
+        for (int m4 = 0; m4 < 4; ++m4) dst[m4] = float4{R[4 * m4], R[4 * m4 + 1], R[4 * m4 + 2], R[4 * m4 + 3]};
+      }
+      __syncthreads();
+      acc_t W;  // W[4g+t][c]
+      {
+        const float4 v = *reinterpret_cast<const float4 *>(Wt + c * LDW + 4 * g);
+        W = acc_t{v.x, v.y, v.z, v.w};
+      }
+      float Aop[4];  // A operand of MFMA q: W[i = c][kk = 4q + g]
+#pragma unroll
+      for (int q = 0; q < 4; ++q) Aop[q] = Wt[(4 * q + g) * LDW + c];
+      acc[tile_index(J, J, NB)] = W;
+      // ---- 5a. z_J = W b_J, row form
+#pragma unroll
+      for (int t = 0; t < 4; ++t) zrow[J][t] = row_sum(W[t] * bcol[J]);
+      // ---- 3. panel tiles and 5b. rhs update
+      float Pt[NB > 1 ? NB - 1 : 1][4];  // transposed panel tiles, index bj - J - 1
+#pragma unroll
+      for (int bj = J + 1; bj < NB; ++bj) {
+        float Bop[4];
+        transpose_rg(acc[tile_index(J, bj, NB)], Bop);
+        acc_t P = acc_t{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) P = Tr::mma(Aop[q], Bop[q], P);
+        acc[tile_index(J, bj, NB)] = P;  // U[J][bj]
+        transpose_rg(P, Pt[bj - J - 1]);
+        float s = P[0] * zrow[J][0];
+        s = fmaf(P[1], zrow[J][1], s);
+        s = fmaf(P[2], zrow[J][2], s);
+        s = fmaf(P[3], zrow[J][3], s);
+        bcol[bj] -= group_sum(s);
+      }
+      // ---- 4. trailing update
+#pragma unroll
+      for (int bi = J + 1; bi < NB; ++bi) {
+        float nA[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) nA[q] = -Pt[bi - J - 1][q];
+#pragma unroll
+        for (int bj = bi; bj < NB; ++bj) {
+          acc_t t = acc[tile_index(bi, bj, NB)];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) t = Tr::mma(nA[q], Pt[bj - J - 1][q], t);
+          acc[tile_index(bi, bj, NB)] = t;
+        }
+      }
+    }
+    // ---- back substitution: x_J = W_J^T (z_J - sum_{bj > J} U[J][bj] x_bj)
+    float xcol[NB];
+#pragma unroll
+    for (int J = NB - 1; J >= 0; --J) {
+      float part[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int bj = J + 1; bj < NB; ++bj) {
+        const acc_t u = acc[tile_index(J, bj, NB)];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) part[t] = fmaf(u[t], xcol[bj], part[t]);
+      }
+      const acc_t W = acc[tile_index(J, J, NB)];
+      float s = 0.0f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float y = (J + 1 < NB) ? zrow[J][t] - row_sum(part[t]) : zrow[J][t];
+        s = fmaf(W[t], y, s);
+      }
+      xcol[J] = group_sum(s);
+    }
+    // lane group g stores blocks g and g + 4: two full 256-byte stores per row for k >= 64
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) {
+      if ((cb & 3) == g && cb * 16 + c < k) out_row[cb * 16 + c] = xcol[cb];
+    }
+    if (bad && lane == 0) {
+      atomicAdd(&err->count, 1);
+      err->firstRow = row;
+    }
+  }
+};
+
+template <typename T, int NB, bool LDS_SOLVER>
+struct SolverFor {
+  using type = SolveLds<T, NB>;
+};
+template <int NB>
+struct SolverFor<float, NB, false> {
+  using type = SolveMfmaF32<NB>;
+};
+
 template <typename T>
 struct StepArgs {
   const Unit *units;
@@ -265,7 +486,7 @@ struct StepArgs {
 
 // Kernel 1 (dominant): one wave per unit -- gather + Gramian + rhs, then either the row's
 // solve or a partial slab.
-template <typename T, int NB>
+template <typename T, int NB, bool LDS_SOLVER>
 __global__ __launch_bounds__(64) void als_gram_solve_kernel(StepArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using G = Gram<T, NB>;
@@ -292,12 +513,12 @@ __global__ __launch_bounds__(64) void als_gram_solve_kernel(StepArgs<T> a) {
   }
   // lambda.diagonal(_lambda * _n): the product is formed in double and rounded to T once
   const T lam = (T)(a.lambda * (double)(u.end - u.beg));
-  SolveLds<T, NB>::run(acc, bacc, reinterpret_cast<T *>(smem), a.k, lam,
-                       a.solved + (int64_t)u.row * a.k, u.row, a.err, lane);
+  SolverFor<T, NB, LDS_SOLVER>::type::run(acc, bacc, reinterpret_cast<T *>(smem), a.k, lam,
+                                          a.solved + (int64_t)u.row * a.k, u.row, a.err, lane);
 }
 
 // Kernel 2: one wave per split row -- sum its slabs in slab order, then solve.
-template <typename T, int NB>
+template <typename T, int NB, bool LDS_SOLVER>
 __global__ __launch_bounds__(64) void als_reduce_solve_kernel(StepArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using G = Gram<T, NB>;
@@ -321,8 +542,8 @@ __global__ __launch_bounds__(64) void als_reduce_solve_kernel(StepArgs<T> a) {
     for (int cb = 0; cb < NB; ++cb) bacc[cb] += s[(G::NT * 4 + cb) * 64];
   }
   const T lam = (T)(a.lambda * (double)sr.n);
-  SolveLds<T, NB>::run(acc, bacc, reinterpret_cast<T *>(smem), a.k, lam,
-                       a.solved + (int64_t)sr.row * a.k, sr.row, a.err, lane);
+  SolverFor<T, NB, LDS_SOLVER>::type::run(acc, bacc, reinterpret_cast<T *>(smem), a.k, lam,
+                                          a.solved + (int64_t)sr.row * a.k, sr.row, a.err, lane);
 }
 
 // ---------------------------------------------------------------------------------------

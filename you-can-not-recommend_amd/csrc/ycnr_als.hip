@@ -123,12 +123,12 @@ void build_schedule(const int64_t *rowPtr, int64_t rowBegin, int64_t nRows, int 
   units.insert(units.end(), fused.begin(), fused.end());
 }
 
-template <typename T, int NB>
+template <typename T, int NB, bool LDS_SOLVER>
 int launch_nb(const StepArgs<T> &args, int64_t nUnits, int64_t nSplit, hipStream_t stream,
               hipEvent_t *ev /* 4 events or null */) {
-  const size_t lds = SolveLds<T, NB>::lds_bytes();
-  auto k1 = als_gram_solve_kernel<T, NB>;
-  auto k2 = als_reduce_solve_kernel<T, NB>;
+  const size_t lds = SolverFor<T, NB, LDS_SOLVER>::type::lds_bytes();
+  auto k1 = als_gram_solve_kernel<T, NB, LDS_SOLVER>;
+  auto k2 = als_reduce_solve_kernel<T, NB, LDS_SOLVER>;
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k1),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k2),
@@ -150,19 +150,27 @@ int launch_nb(const StepArgs<T> &args, int64_t nUnits, int64_t nSplit, hipStream
 
 template <typename T>
 int launch_step(const StepArgs<T> &args, int64_t nUnits, int64_t nSplit, hipStream_t stream,
-                hipEvent_t *ev) {
+                hipEvent_t *ev, bool ldsSolver = false) {
   if (nUnits > 0x7fffffffLL || nSplit > 0x7fffffffLL)
     return fail(YCNR_ERR_UNSUPPORTED, "too many work units for one launch (%lld)", (long long)nUnits);
   const int nb = (args.k + 15) / 16;
   switch (nb) {
-    case 1: return launch_nb<T, 1>(args, nUnits, nSplit, stream, ev);
-    case 2: return launch_nb<T, 2>(args, nUnits, nSplit, stream, ev);
-    case 3: return launch_nb<T, 3>(args, nUnits, nSplit, stream, ev);
-    case 4: return launch_nb<T, 4>(args, nUnits, nSplit, stream, ev);
-    case 5: return launch_nb<T, 5>(args, nUnits, nSplit, stream, ev);
-    case 6: return launch_nb<T, 6>(args, nUnits, nSplit, stream, ev);
-    case 7: return launch_nb<T, 7>(args, nUnits, nSplit, stream, ev);
-    case 8: return launch_nb<T, 8>(args, nUnits, nSplit, stream, ev);
+    case 1: return ldsSolver ? launch_nb<T, 1, true>(args, nUnits, nSplit, stream, ev)
+                             : launch_nb<T, 1, false>(args, nUnits, nSplit, stream, ev);
+    case 2: return ldsSolver ? launch_nb<T, 2, true>(args, nUnits, nSplit, stream, ev)
+                             : launch_nb<T, 2, false>(args, nUnits, nSplit, stream, ev);
+    case 3: return ldsSolver ? launch_nb<T, 3, true>(args, nUnits, nSplit, stream, ev)
+                             : launch_nb<T, 3, false>(args, nUnits, nSplit, stream, ev);
+    case 4: return ldsSolver ? launch_nb<T, 4, true>(args, nUnits, nSplit, stream, ev)
+                             : launch_nb<T, 4, false>(args, nUnits, nSplit, stream, ev);
+    case 5: return ldsSolver ? launch_nb<T, 5, true>(args, nUnits, nSplit, stream, ev)
+                             : launch_nb<T, 5, false>(args, nUnits, nSplit, stream, ev);
+    case 6: return ldsSolver ? launch_nb<T, 6, true>(args, nUnits, nSplit, stream, ev)
+                             : launch_nb<T, 6, false>(args, nUnits, nSplit, stream, ev);
+    case 7: return ldsSolver ? launch_nb<T, 7, true>(args, nUnits, nSplit, stream, ev)
+                             : launch_nb<T, 7, false>(args, nUnits, nSplit, stream, ev);
+    case 8: return ldsSolver ? launch_nb<T, 8, true>(args, nUnits, nSplit, stream, ev)
+                             : launch_nb<T, 8, false>(args, nUnits, nSplit, stream, ev);
     default:
       return fail(YCNR_ERR_UNSUPPORTED, "factorsCount %d > %d is not supported by this build", args.k,
                   kMaxFactors);
@@ -465,11 +473,11 @@ int ycnr_als_step_async(ycnr_als *h, int side) {
   if (h->opt.dtype == YCNR_F32) {
     StepArgs<float> a{S.dUnits, S.dSplit, R.dIndx, (const float *)R.dVals, (const float *)h->factors[1 - side],
                       (const float *)h->dZeros, (float *)h->factors[side], (float *)S.dSlabs, h->dErr, lambda, h->opt.factorsCount};
-    rc = launch_step<float>(a, S.nUnits, S.nSplit, h->stream, h->ev);
+    rc = launch_step<float>(a, S.nUnits, S.nSplit, h->stream, h->ev, (h->opt.flags & YCNR_FLAG_LDS_SOLVER) != 0);
   } else {
     StepArgs<double> a{S.dUnits, S.dSplit, R.dIndx, (const double *)R.dVals, (const double *)h->factors[1 - side],
                        (const double *)h->dZeros, (double *)h->factors[side], (double *)S.dSlabs, h->dErr, lambda, h->opt.factorsCount};
-    rc = launch_step<double>(a, S.nUnits, S.nSplit, h->stream, h->ev);
+    rc = launch_step<double>(a, S.nUnits, S.nSplit, h->stream, h->ev, true);
   }
   if (rc) return rc;
   memset(&h->info, 0, sizeof h->info);
