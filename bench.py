@@ -126,36 +126,56 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     value = nnz * args.steps / elapsed
 
-    # dominant kernel: als_gram_solve, both launches (byUser + byItem) of every timed iteration
+    # per-kernel accounting over the timed region, from the HIP-event durations libycnr_als.so
+    # records on its launch stream (ycnr_als_last_step_info)
     s = 8 if args.double else 4
-    kern_ms = {"byUser": 0.0, "byItem": 0.0}
-    red_ms = {"byUser": 0.0, "byItem": 0.0}
-    flops = 0.0
-    abytes = 0.0
-    launches = 0
-    for st in lord.stepTimes:
-        info = st["info"]
-        kern_ms[st["stepType"]] += info.gramSolveMs
-        red_ms[st["stepType"]] += info.reduceSolveMs
-        flops += algorithmic_flops(info.ratings, info.rows, k)
-        abytes += algorithmic_bytes(info.ratings, info.rows, k, s)
-        launches += 1
-    kern_total_ms = kern_ms["byUser"] + kern_ms["byItem"]
     peak = PEAK_FP64_TFLOPS if args.double else PEAK_FP32_TFLOPS
-    achieved_tflops = flops / (kern_total_ms * 1e-3) / 1e12 if kern_total_ms > 0 else 0.0
+    per_rating = k * (k + 1) + 2 * k            # symmetric Gramian + rhs
+    per_row = k ** 3 / 3.0 + 2 * k * k          # Cholesky + two triangular solves
+    bytes_rating = 4 + s + k * s                # index + value + gathered factor row
+    kern = {n: {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0} for n in
+            ("als_gram_solve_kernel", "als_gram_slab_kernel", "als_reduce_solve_kernel")}
+    step_ms = {"byUser": 0.0, "byItem": 0.0}
+    for st in lord.stepTimes:
+        i = st["info"]
+        step_ms[st["stepType"]] += i.totalMs
+        for name, ms, fl, by in (
+                ("als_gram_solve_kernel", i.gramSolveMs, i.fusedRatings * per_rating + i.fusedRows * per_row,
+                 i.fusedRatings * bytes_rating + i.fusedRows * (k * s + 8)),
+                ("als_gram_slab_kernel", i.gramSlabMs, (i.ratings - i.fusedRatings) * per_rating,
+                 (i.ratings - i.fusedRatings) * bytes_rating),
+                ("als_reduce_solve_kernel", i.reduceSolveMs, i.splitRows * per_row, i.splitRows * (k * s + 8))):
+            if fl > 0:
+                kern[name]["ms"] += ms
+                kern[name]["flops"] += fl
+                kern[name]["bytes"] += by
+                kern[name]["launches"] += 1
+    dom = max(kern, key=lambda n: kern[n]["ms"])
+
+    def describe(n):
+        d = kern[n]
+        t = d["ms"] * 1e-3
+        tf = d["flops"] / t / 1e12 if t > 0 else 0.0
+        gb = d["bytes"] / t / 1e9 if t > 0 else 0.0
+        return {"kernel": n, "launches": d["launches"], "avg_launch_ms": round(d["ms"] / max(d["launches"], 1), 4),
+                "achieved_TFLOPs": round(tf, 3), "mfma_frac": round(tf / peak, 4),
+                "algorithmic_GBs": round(gb, 1), "hbm_frac": round(gb / PEAK_HBM_GBS, 4)}
+
+    dd = describe(dom)
+    tot_ms = sum(d["ms"] for d in kern.values())
+    tot_fl = sum(d["flops"] for d in kern.values())
+    tot_by = sum(d["bytes"] for d in kern.values())
     roofline = {
-        "bound": "mfma", "kernel": "als_gram_solve_kernel", "achieved": round(achieved_tflops, 3), "peak": peak,
-        "unit": "TFLOP/s", "frac": round(achieved_tflops / peak, 4), "traffic": None,
-        "launches": launches, "avg_launch_ms": round(kern_total_ms / max(launches, 1), 4),
-        "flops_model": "k(k+1)+2k per rating + k^3/3+2k^2 per row (symmetric Gramian + Cholesky)",
-        # the HBM roof beside it (gather-model algorithmic bytes over the same kernel time)
-        "hbm_achieved_GBs": round(abytes / (kern_total_ms * 1e-3) / 1e9, 1) if kern_total_ms > 0 else 0.0,
-        "hbm_peak_GBs": PEAK_HBM_GBS,
-        "hbm_frac": round(abytes / (kern_total_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if kern_total_ms > 0 else 0.0,
-        "per_step_ms": {"byUser_gram_solve": round(kern_ms["byUser"] / args.steps, 3),
-                        "byItem_gram_solve": round(kern_ms["byItem"] / args.steps, 3),
-                        "byUser_reduce_solve": round(red_ms["byUser"] / args.steps, 3),
-                        "byItem_reduce_solve": round(red_ms["byItem"] / args.steps, 3)},
+        "bound": "mfma", "kernel": dom, "achieved": dd["achieved_TFLOPs"], "peak": peak, "unit": "TFLOP/s",
+        "frac": dd["mfma_frac"], "traffic": None, "launches": dd["launches"], "avg_launch_ms": dd["avg_launch_ms"],
+        "flops_model": "k(k+1)+2k per rating + k^3/3+2k^2 per solved row (symmetric Gramian + Cholesky), fp32 MFMA peak",
+        "kernels": [describe(n) for n in kern if kern[n]["launches"]],
+        # all kernels of the iteration together, against both roofs (gather-model bytes for HBM)
+        "iteration": {"kernel_ms_per_step": round(tot_ms / args.steps, 3),
+                      "mfma_frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / peak, 4) if tot_ms else 0.0,
+                      "hbm_frac": round(tot_by / (tot_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if tot_ms else 0.0,
+                      "byUser_ms": round(step_ms["byUser"] / args.steps, 3),
+                      "byItem_ms": round(step_ms["byItem"] / args.steps, 3)},
     }
 
     rmse = lord.calcRmse("rmseValidate", False)

@@ -125,10 +125,14 @@ typedef struct ycnr_als_step_info {
   int64_t ratings;       /* ratings consumed */
   int64_t units;         /* wave-level work units launched by the Gramian kernel */
   int64_t splitRows;     /* rows whose Gramian was split over several units */
-  float gramSolveMs;     /* als_gram_solve kernel (dominant) */
-  float reduceSolveMs;   /* als_reduce_solve kernel (split rows), 0 if not launched */
+  int64_t fusedRows;     /* rows handled whole by als_gram_solve (= rows - splitRows) */
+  int64_t fusedRatings;  /* their ratings (the rest went through als_gram_slab) */
+  float gramSlabMs;      /* als_gram_slab kernel: Gramian chunks of split rows */
+  float gramSolveMs;     /* als_gram_solve kernel: whole rows, Gramian + solve fused */
+  float reduceSolveMs;   /* als_reduce_solve kernel: slab sum + solve of split rows */
   float totalMs;         /* first kernel start -> last kernel end */
   int32_t numericErrors; /* rows whose matrix was not positive definite */
+  int32_t pad;
 } ycnr_als_step_info;
 
 int ycnr_als_create(const ycnr_als_options *opts, ycnr_als **out);

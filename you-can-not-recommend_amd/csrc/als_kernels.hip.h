@@ -25,6 +25,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Register budget of the fused Gramian + solve kernel: 2 waves per SIMD = at most 256
+// registers per lane (k = 100 needs 206 and does not spill; 3 would spill 220 B per lane).
+#ifndef YCNR_FUSED_WAVES_PER_SIMD
+#define YCNR_FUSED_WAVES_PER_SIMD 2
+#endif
+
 namespace ycnr {
 
 // A wave-level work unit: ratings [beg, end) of the local CSR belong to `row`.
@@ -482,13 +488,14 @@ struct StepArgs {
   ErrInfo *err;
   double lambda;
   int32_t k;
+  int32_t firstFused;  // units[0 .. firstFused) are split chunks, the rest whole rows
 };
 
-// Kernel 1 (dominant): one wave per unit -- gather + Gramian + rhs, then either the row's
-// solve or a partial slab.
-template <typename T, int NB, bool LDS_SOLVER>
-__global__ __launch_bounds__(64) void als_gram_solve_kernel(StepArgs<T> a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// Kernel 1a: one wave per SPLIT unit -- gather + Gramian + rhs of a chunk of a heavy row,
+// written as a partial slab.  Kept apart from the fused kernel so that its register
+// allocation (accumulators + two operand sets) is not inflated by the solve.
+template <typename T, int NB>
+__global__ __launch_bounds__(64) void als_gram_slab_kernel(StepArgs<T> a) {
   using G = Gram<T, NB>;
   using acc_t = typename G::acc_t;
   const int lane = threadIdx.x;
@@ -500,17 +507,32 @@ __global__ __launch_bounds__(64) void als_gram_solve_kernel(StepArgs<T> a) {
 #pragma unroll
   for (int cb = 0; cb < NB; ++cb) bacc[cb] = T(0);
   G::accumulate(acc, bacc, a.indx, a.vals, a.fixed, a.zeros, a.k, u.beg, u.end, lane);
-  if (u.slab >= 0) {
-    T *s = a.slabs + (int64_t)u.slab * slab_elems(NB) + lane;
+  T *s = a.slabs + (int64_t)u.slab * slab_elems(NB) + lane;
 #pragma unroll
-    for (int t = 0; t < G::NT; ++t) {
+  for (int t = 0; t < G::NT; ++t) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) s[(t * 4 + r) * 64] = acc[t][r];
-    }
-#pragma unroll
-    for (int cb = 0; cb < NB; ++cb) s[(G::NT * 4 + cb) * 64] = bacc[cb];
-    return;
+    for (int r = 0; r < 4; ++r) s[(t * 4 + r) * 64] = acc[t][r];
   }
+#pragma unroll
+  for (int cb = 0; cb < NB; ++cb) s[(G::NT * 4 + cb) * 64] = bacc[cb];
+}
+
+// Kernel 1b (dominant on the user side): one wave per row that fits one unit -- gather +
+// Gramian + rhs, then the row's solve, all in registers.
+template <typename T, int NB, bool LDS_SOLVER>
+__global__ __launch_bounds__(64, YCNR_FUSED_WAVES_PER_SIMD) void als_gram_solve_kernel(StepArgs<T> a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using G = Gram<T, NB>;
+  using acc_t = typename G::acc_t;
+  const int lane = threadIdx.x;
+  const Unit u = a.units[a.firstFused + blockIdx.x];
+  acc_t acc[G::NT];
+  T bacc[NB];
+#pragma unroll
+  for (int t = 0; t < G::NT; ++t) acc[t] = acc_t{T(0), T(0), T(0), T(0)};
+#pragma unroll
+  for (int cb = 0; cb < NB; ++cb) bacc[cb] = T(0);
+  G::accumulate(acc, bacc, a.indx, a.vals, a.fixed, a.zeros, a.k, u.beg, u.end, lane);
   // lambda.diagonal(_lambda * _n): the product is formed in double and rounded to T once
   const T lam = (T)(a.lambda * (double)(u.end - u.beg));
   SolverFor<T, NB, LDS_SOLVER>::type::run(acc, bacc, reinterpret_cast<T *>(smem), a.k, lam,

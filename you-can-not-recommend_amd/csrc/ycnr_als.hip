@@ -69,7 +69,7 @@ struct Schedule {
   Unit *dUnits = nullptr;
   SplitRow *dSplit = nullptr;
   void *dSlabs = nullptr;
-  int64_t nUnits = 0, nSplit = 0, nSlabs = 0, solvedRows = 0;
+  int64_t nUnits = 0, nSplit = 0, nSlabs = 0, solvedRows = 0, fusedRatings = 0;
   void release() {
     if (dUnits) (void)hipFree(dUnits);
     if (dSplit) (void)hipFree(dSplit);
@@ -77,7 +77,7 @@ struct Schedule {
     dUnits = nullptr;
     dSplit = nullptr;
     dSlabs = nullptr;
-    nUnits = nSplit = nSlabs = solvedRows = 0;
+    nUnits = nSplit = nSlabs = solvedRows = fusedRatings = 0;
   }
 };
 
@@ -87,6 +87,7 @@ struct Schedule {
 void build_schedule(const int64_t *rowPtr, int64_t rowBegin, int64_t nRows, int chunk,
                     std::vector<Unit> &units, std::vector<SplitRow> &split, int64_t &nSlabs,
                     int64_t &solvedRows) {
+  // on return units = [split chunks (nSlabs of them) | whole rows]
   const int64_t base = rowPtr[0];
   units.clear();
   split.clear();
@@ -124,53 +125,59 @@ void build_schedule(const int64_t *rowPtr, int64_t rowBegin, int64_t nRows, int 
 }
 
 template <typename T, int NB, bool LDS_SOLVER>
-int launch_nb(const StepArgs<T> &args, int64_t nUnits, int64_t nSplit, hipStream_t stream,
-              hipEvent_t *ev /* 4 events or null */) {
+int launch_nb(StepArgs<T> args, int64_t nUnits, int64_t nSplitUnits, int64_t nSplit, hipStream_t stream,
+              hipEvent_t *ev /* 6 events or null */) {
   const size_t lds = SolverFor<T, NB, LDS_SOLVER>::type::lds_bytes();
+  auto k0 = als_gram_slab_kernel<T, NB>;
   auto k1 = als_gram_solve_kernel<T, NB, LDS_SOLVER>;
   auto k2 = als_reduce_solve_kernel<T, NB, LDS_SOLVER>;
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k1),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k2),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  args.firstFused = (int32_t)nSplitUnits;
   if (ev) HIP_TRY(hipEventRecord(ev[0], stream));
-  if (nUnits > 0) {
-    hipLaunchKernelGGL(k1, dim3((unsigned)nUnits), dim3(64), lds, stream, args);
+  if (nSplitUnits > 0) {
+    hipLaunchKernelGGL(k0, dim3((unsigned)nSplitUnits), dim3(64), 0, stream, args);
     HIP_TRY(hipGetLastError());
   }
   if (ev) HIP_TRY(hipEventRecord(ev[1], stream));
+  if (nUnits > nSplitUnits) {
+    hipLaunchKernelGGL(k1, dim3((unsigned)(nUnits - nSplitUnits)), dim3(64), lds, stream, args);
+    HIP_TRY(hipGetLastError());
+  }
+  if (ev) HIP_TRY(hipEventRecord(ev[2], stream));
   if (nSplit > 0) {
-    if (ev) HIP_TRY(hipEventRecord(ev[2], stream));
     hipLaunchKernelGGL(k2, dim3((unsigned)nSplit), dim3(64), lds, stream, args);
     HIP_TRY(hipGetLastError());
-    if (ev) HIP_TRY(hipEventRecord(ev[3], stream));
   }
+  if (ev) HIP_TRY(hipEventRecord(ev[3], stream));
   return YCNR_OK;
 }
 
 template <typename T>
-int launch_step(const StepArgs<T> &args, int64_t nUnits, int64_t nSplit, hipStream_t stream,
+int launch_step(const StepArgs<T> &args, int64_t nUnits, int64_t nSplitUnits, int64_t nSplit, hipStream_t stream,
                 hipEvent_t *ev, bool ldsSolver = false) {
   if (nUnits > 0x7fffffffLL || nSplit > 0x7fffffffLL)
     return fail(YCNR_ERR_UNSUPPORTED, "too many work units for one launch (%lld)", (long long)nUnits);
   const int nb = (args.k + 15) / 16;
   switch (nb) {
-    case 1: return ldsSolver ? launch_nb<T, 1, true>(args, nUnits, nSplit, stream, ev)
-                             : launch_nb<T, 1, false>(args, nUnits, nSplit, stream, ev);
-    case 2: return ldsSolver ? launch_nb<T, 2, true>(args, nUnits, nSplit, stream, ev)
-                             : launch_nb<T, 2, false>(args, nUnits, nSplit, stream, ev);
-    case 3: return ldsSolver ? launch_nb<T, 3, true>(args, nUnits, nSplit, stream, ev)
-                             : launch_nb<T, 3, false>(args, nUnits, nSplit, stream, ev);
-    case 4: return ldsSolver ? launch_nb<T, 4, true>(args, nUnits, nSplit, stream, ev)
-                             : launch_nb<T, 4, false>(args, nUnits, nSplit, stream, ev);
-    case 5: return ldsSolver ? launch_nb<T, 5, true>(args, nUnits, nSplit, stream, ev)
-                             : launch_nb<T, 5, false>(args, nUnits, nSplit, stream, ev);
-    case 6: return ldsSolver ? launch_nb<T, 6, true>(args, nUnits, nSplit, stream, ev)
-                             : launch_nb<T, 6, false>(args, nUnits, nSplit, stream, ev);
-    case 7: return ldsSolver ? launch_nb<T, 7, true>(args, nUnits, nSplit, stream, ev)
-                             : launch_nb<T, 7, false>(args, nUnits, nSplit, stream, ev);
-    case 8: return ldsSolver ? launch_nb<T, 8, true>(args, nUnits, nSplit, stream, ev)
-                             : launch_nb<T, 8, false>(args, nUnits, nSplit, stream, ev);
+    case 1: return ldsSolver ? launch_nb<T, 1, true>(args, nUnits, nSplitUnits, nSplit, stream, ev)
+                             : launch_nb<T, 1, false>(args, nUnits, nSplitUnits, nSplit, stream, ev);
+    case 2: return ldsSolver ? launch_nb<T, 2, true>(args, nUnits, nSplitUnits, nSplit, stream, ev)
+                             : launch_nb<T, 2, false>(args, nUnits, nSplitUnits, nSplit, stream, ev);
+    case 3: return ldsSolver ? launch_nb<T, 3, true>(args, nUnits, nSplitUnits, nSplit, stream, ev)
+                             : launch_nb<T, 3, false>(args, nUnits, nSplitUnits, nSplit, stream, ev);
+    case 4: return ldsSolver ? launch_nb<T, 4, true>(args, nUnits, nSplitUnits, nSplit, stream, ev)
+                             : launch_nb<T, 4, false>(args, nUnits, nSplitUnits, nSplit, stream, ev);
+    case 5: return ldsSolver ? launch_nb<T, 5, true>(args, nUnits, nSplitUnits, nSplit, stream, ev)
+                             : launch_nb<T, 5, false>(args, nUnits, nSplitUnits, nSplit, stream, ev);
+    case 6: return ldsSolver ? launch_nb<T, 6, true>(args, nUnits, nSplitUnits, nSplit, stream, ev)
+                             : launch_nb<T, 6, false>(args, nUnits, nSplitUnits, nSplit, stream, ev);
+    case 7: return ldsSolver ? launch_nb<T, 7, true>(args, nUnits, nSplitUnits, nSplit, stream, ev)
+                             : launch_nb<T, 7, false>(args, nUnits, nSplitUnits, nSplit, stream, ev);
+    case 8: return ldsSolver ? launch_nb<T, 8, true>(args, nUnits, nSplitUnits, nSplit, stream, ev)
+                             : launch_nb<T, 8, false>(args, nUnits, nSplitUnits, nSplit, stream, ev);
     default:
       return fail(YCNR_ERR_UNSUPPORTED, "factorsCount %d > %d is not supported by this build", args.k,
                   kMaxFactors);
@@ -384,6 +391,8 @@ int ycnr_als_set_ratings(ycnr_als *h, int side, const int64_t *rowPtr, const int
   S.nSplit = (int64_t)split.size();
   S.nSlabs = nSlabs;
   S.solvedRows = solved;
+  S.fusedRatings = 0;
+  for (size_t i = (size_t)nSlabs; i < units.size(); ++i) S.fusedRatings += units[i].end - units[i].beg;
   if (S.nUnits) {
     HIP_TRY(hipMalloc(&S.dUnits, sizeof(Unit) * units.size()));
     HIP_TRY(hipMemcpy(S.dUnits, units.data(), sizeof(Unit) * units.size(), hipMemcpyHostToDevice));
@@ -472,12 +481,12 @@ int ycnr_als_step_async(ycnr_als *h, int side) {
   int rc;
   if (h->opt.dtype == YCNR_F32) {
     StepArgs<float> a{S.dUnits, S.dSplit, R.dIndx, (const float *)R.dVals, (const float *)h->factors[1 - side],
-                      (const float *)h->dZeros, (float *)h->factors[side], (float *)S.dSlabs, h->dErr, lambda, h->opt.factorsCount};
-    rc = launch_step<float>(a, S.nUnits, S.nSplit, h->stream, h->ev, (h->opt.flags & YCNR_FLAG_LDS_SOLVER) != 0);
+                      (const float *)h->dZeros, (float *)h->factors[side], (float *)S.dSlabs, h->dErr, lambda, h->opt.factorsCount, 0};
+    rc = launch_step<float>(a, S.nUnits, S.nSlabs, S.nSplit, h->stream, h->ev, (h->opt.flags & YCNR_FLAG_LDS_SOLVER) != 0);
   } else {
     StepArgs<double> a{S.dUnits, S.dSplit, R.dIndx, (const double *)R.dVals, (const double *)h->factors[1 - side],
-                       (const double *)h->dZeros, (double *)h->factors[side], (double *)S.dSlabs, h->dErr, lambda, h->opt.factorsCount};
-    rc = launch_step<double>(a, S.nUnits, S.nSplit, h->stream, h->ev, true);
+                       (const double *)h->dZeros, (double *)h->factors[side], (double *)S.dSlabs, h->dErr, lambda, h->opt.factorsCount, 0};
+    rc = launch_step<double>(a, S.nUnits, S.nSlabs, S.nSplit, h->stream, h->ev, true);
   }
   if (rc) return rc;
   memset(&h->info, 0, sizeof h->info);
@@ -487,6 +496,8 @@ int ycnr_als_step_async(ycnr_als *h, int side) {
   h->info.ratings = R.nnz;
   h->info.units = S.nUnits;
   h->info.splitRows = S.nSplit;
+  h->info.fusedRows = S.solvedRows - S.nSplit;
+  h->info.fusedRatings = S.fusedRatings;
   h->infoPending = true;
   h->infoHasSplit = S.nSplit > 0;
   return YCNR_OK;
@@ -500,14 +511,13 @@ int ycnr_als_sync(ycnr_als *h) {
     h->infoPending = false;
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
+    h->info.gramSlabMs = ms;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev[1], h->ev[2]));
     h->info.gramSolveMs = ms;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev[2], h->ev[3]));
+    h->info.reduceSolveMs = ms;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev[0], h->ev[3]));
     h->info.totalMs = ms;
-    if (h->infoHasSplit) {
-      HIP_TRY(hipEventElapsedTime(&ms, h->ev[2], h->ev[3]));
-      h->info.reduceSolveMs = ms;
-      HIP_TRY(hipEventElapsedTime(&ms, h->ev[0], h->ev[3]));
-      h->info.totalMs = ms;
-    }
     ErrInfo ei{};
     HIP_TRY(hipMemcpy(&ei, h->dErr, sizeof ei, hipMemcpyDeviceToHost));
     h->info.numericErrors = ei.count;
@@ -677,8 +687,8 @@ int64_t als_calc_portion(double lambda, int k, const int32_t *alsRows, const int
   L1_TRY(hipMemcpyAsync(dFixed, cfix.data(), sizeof(T) * cfix.size(), hipMemcpyHostToDevice, stream));
   {
     // rows are numbered 0..nRows-1 on the device and scattered to rowId on the host
-    StepArgs<T> a{dUnits, dSplit, dIndx, dVals, dFixed, dZeros, dSolved, dSlabs, dErr, lambda, k};
-    rc = launch_step<T>(a, (int64_t)units.size(), (int64_t)split.size(), stream, nullptr);
+    StepArgs<T> a{dUnits, dSplit, dIndx, dVals, dFixed, dZeros, dSolved, dSlabs, dErr, lambda, k, 0};
+    rc = launch_step<T>(a, (int64_t)units.size(), nSlabs, (int64_t)split.size(), stream, nullptr);
     if (rc) {
       cleanup();
       return rc;

@@ -43,8 +43,10 @@ class Options(C.Structure):
 
 class StepInfo(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("side", C.c_int32), ("rows", C.c_int64), ("ratings", C.c_int64),
-                ("units", C.c_int64), ("splitRows", C.c_int64), ("gramSolveMs", C.c_float),
-                ("reduceSolveMs", C.c_float), ("totalMs", C.c_float), ("numericErrors", C.c_int32)]
+                ("units", C.c_int64), ("splitRows", C.c_int64), ("fusedRows", C.c_int64),
+                ("fusedRatings", C.c_int64), ("gramSlabMs", C.c_float),
+                ("gramSolveMs", C.c_float), ("reduceSolveMs", C.c_float), ("totalMs", C.c_float),
+                ("numericErrors", C.c_int32), ("pad", C.c_int32)]
 
 
 _lib = None
