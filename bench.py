@@ -134,14 +134,19 @@ def main():
     per_row = k ** 3 / 3.0 + 2 * k * k          # Cholesky + two triangular solves
     bytes_rating = 4 + s + k * s                # index + value + gathered factor row
     kern = {n: {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0} for n in
-            ("als_gram_solve_kernel", "als_gram_slab_kernel", "als_reduce_solve_kernel")}
+            ("als_gram_solve_kernel", "als_dual_solve_kernel", "als_gram_slab_kernel", "als_reduce_solve_kernel")}
     step_ms = {"byUser": 0.0, "byItem": 0.0}
     for st in lord.stepTimes:
         i = st["info"]
         step_ms[st["stepType"]] += i.totalMs
         for name, ms, fl, by in (
-                ("als_gram_solve_kernel", i.gramSolveMs, i.fusedRatings * per_rating + i.fusedRows * per_row,
-                 i.fusedRatings * bytes_rating + i.fusedRows * (k * s + 8)),
+                ("als_gram_solve_kernel", i.gramSolveMs,
+                 (i.fusedRatings - i.dualRatings) * per_rating + (i.fusedRows - i.dualRows) * per_row,
+                 (i.fusedRatings - i.dualRatings) * bytes_rating + (i.fusedRows - i.dualRows) * (k * s + 8)),
+                # dual-form rows are priced with the same (primal) algorithmic model: work the
+                # reference does for those rows, not the smaller n x n work the kernel executes
+                ("als_dual_solve_kernel", i.dualSolveMs, i.dualRatings * per_rating + i.dualRows * per_row,
+                 i.dualRatings * bytes_rating + i.dualRows * (k * s + 8)),
                 ("als_gram_slab_kernel", i.gramSlabMs, (i.ratings - i.fusedRatings) * per_rating,
                  (i.ratings - i.fusedRatings) * bytes_rating),
                 ("als_reduce_solve_kernel", i.reduceSolveMs, i.splitRows * per_row, i.splitRows * (k * s + 8))):

@@ -115,6 +115,8 @@ typedef struct ycnr_als_options {
 /* options.flags: use the plain LDS Cholesky for float32 too (float64 always uses it); the
  * default float32 solve is the register-resident MFMA block Cholesky. For A/B tests. */
 #define YCNR_FLAG_LDS_SOLVER 1
+/* options.flags: never use the dual (n x n) form for rows with fewer ratings than factors */
+#define YCNR_FLAG_NO_DUAL 2
 
 /* Timing / accounting of the last ycnr_als_step, measured with HIP events on the
  * handle's stream around each kernel (DESIGN.md "Measurement"). */
@@ -127,12 +129,14 @@ typedef struct ycnr_als_step_info {
   int64_t splitRows;     /* rows whose Gramian was split over several units */
   int64_t fusedRows;     /* rows handled whole by als_gram_solve (= rows - splitRows) */
   int64_t fusedRatings;  /* their ratings (the rest went through als_gram_slab) */
+  int64_t dualRows;      /* of the fused rows, those short enough for the dual-form kernel */
+  int64_t dualRatings;   /* and their ratings */
   float gramSlabMs;      /* als_gram_slab kernel: Gramian chunks of split rows */
   float gramSolveMs;     /* als_gram_solve kernel: whole rows, Gramian + solve fused */
+  float dualSolveMs;     /* als_dual_solve kernels: whole rows with fewer ratings than factors */
   float reduceSolveMs;   /* als_reduce_solve kernel: slab sum + solve of split rows */
   float totalMs;         /* first kernel start -> last kernel end */
   int32_t numericErrors; /* rows whose matrix was not positive definite */
-  int32_t pad;
 } ycnr_als_step_info;
 
 int ycnr_als_create(const ycnr_als_options *opts, ycnr_als **out);

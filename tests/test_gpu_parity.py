@@ -136,6 +136,45 @@ def test_split_rows_and_chunk_edges(als, dt):
     dev2.destroy()
 
 
+@pytest.mark.parametrize("k", [20, 64, 100, 128])
+def test_every_row_length_class(als, k):
+    """Rows of 1..130 ratings at one k: short rows take the dual (n x n) form, grouped by their
+    number of 16-rating blocks, longer ones the primal form; all against float64, and the three
+    float32 solver variants (dual+MFMA, MFMA only, LDS) against each other."""
+    from ycnr_als import _lib
+    items = 400
+    lens = list(range(1, 131)) + [0, 16, 32, 48, 64, 80, 96, 97, 112, 300]
+    rng = np.random.default_rng(k)
+    rowPtr = np.zeros(len(lens) + 1, np.int64)
+    rowPtr[1:] = np.cumsum(lens)
+    indx = np.concatenate([np.sort(rng.choice(items, n, replace=False)) for n in lens]).astype(np.int32)
+    vals = rng.integers(1, 11, rowPtr[-1]).astype(np.float32)
+    bu = Csr(len(lens), items, rowPtr, indx, vals)
+    U = (rng.standard_normal((len(lens), k)) / k).astype(np.float32)
+    V = (rng.standard_normal((items, k)) / np.sqrt(k)).astype(np.float32)
+    want, conds = numpy_step(0.05, k, bu, V, U)
+    got = {}
+    for name, flags in (("dual", 0), ("primal", _lib.FLAG_NO_DUAL), ("lds", _lib.FLAG_LDS_SOLVER)):
+        dev = als.AlsDevice(k, len(lens), items, flags=flags)
+        dev.set_ratings("byUser", bu.rowPtr, bu.indx, bu.vals)
+        dev.set_factors("byUser", U)
+        dev.set_factors("byItem", V)
+        info = dev.step("byUser")
+        if name == "dual":
+            nb = (k + 15) // 16
+            dual_max = 16 * min(6, nb - 1)
+            assert info.dualRows == sum(1 for n in lens if 0 < n <= dual_max)
+        else:
+            assert info.dualRows == 0
+        got[name] = dev.get_factors("byUser")
+        check_rows(got[name], want, conds, np.float32)
+        assert np.array_equal(got[name][130], U[130])  # the empty row
+        dev.destroy()
+    for a, b in (("dual", "primal"), ("primal", "lds")):
+        err = row_rel_err(got[a], got[b])
+        assert (err <= np.maximum(16 * conds * EPS32, 2e-6)).all()
+
+
 def test_sharded_rows_equal_unsharded(als):
     """Solving a row shard [rowBegin, rowEnd) gives bit-identical rows to the full solve:
     the per-row schedule does not depend on which GPU owns the row (determinism)."""

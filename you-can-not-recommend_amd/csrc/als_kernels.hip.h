@@ -323,8 +323,11 @@ struct SolveMfmaF32 {
     out[3] = r3;
   }
 
-  static __device__ __forceinline__ void run(acc_t (&acc)[NT], const float (&bacc)[NB], float *S, int k, float lam,
-                                             float *__restrict__ out_row, int row, ErrInfo *err, int lane) {
+  // Solves (A + lam I) x = b.  In: upper tiles of A in acc, per-lane-group partials of b in
+  // bacc.  Out: xcol[cb] = x[16 cb + c] in every lane group; returns true when a real pivot
+  // was not positive.  acc is destroyed.
+  static __device__ __forceinline__ bool solve(acc_t (&acc)[NT], const float (&bacc)[NB], float *S, int k, float lam,
+                                               float (&xcol)[NB], int lane) {
     const int g = lane >> 4, c = lane & 15;
     float *Dt = S;             // D image, [row][col], row stride LDW
     float *Wt = S + 16 * LDW;  // W image stored transposed: Wt[col][row] = W[row][col]
@@ -435,7 +438,6 @@ struct SolveMfmaF32 {
       }
     }
     // ---- back substitution: x_J = W_J^T (z_J - sum_{bj > J} U[J][bj] x_bj)
-    float xcol[NB];
 #pragma unroll
     for (int J = NB - 1; J >= 0; --J) {
       float part[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -454,6 +456,14 @@ struct SolveMfmaF32 {
       }
       xcol[J] = group_sum(s);
     }
+    return bad;
+  }
+
+  static __device__ __forceinline__ void run(acc_t (&acc)[NT], const float (&bacc)[NB], float *S, int k, float lam,
+                                             float *__restrict__ out_row, int row, ErrInfo *err, int lane) {
+    const int g = lane >> 4, c = lane & 15;
+    float xcol[NB];
+    const bool bad = solve(acc, bacc, S, k, lam, xcol, lane);
     // lane group g stores blocks g and g + 4: two full 256-byte stores per row for k >= 64
 #pragma unroll
     for (int cb = 0; cb < NB; ++cb) {
@@ -489,6 +499,7 @@ struct StepArgs {
   double lambda;
   int32_t k;
   int32_t firstFused;  // units[0 .. firstFused) are split chunks, the rest whole rows
+  int32_t firstDual;   // first unit of the dual-form launch in flight
 };
 
 // Kernel 1a: one wave per SPLIT unit -- gather + Gramian + rhs of a chunk of a heavy row,
@@ -537,6 +548,101 @@ __global__ __launch_bounds__(64, YCNR_FUSED_WAVES_PER_SIMD) void als_gram_solve_
   const T lam = (T)(a.lambda * (double)(u.end - u.beg));
   SolverFor<T, NB, LDS_SOLVER>::type::run(acc, bacc, reinterpret_cast<T *>(smem), a.k, lam,
                                           a.solved + (int64_t)u.row * a.k, u.row, a.err, lane);
+}
+
+// Kernel 1c: the same row solve in its DUAL form, for rows with fewer ratings than factors.
+//   x = (Y^T Y + lam I)^-1 Y^T r  =  Y^T (Y Y^T + lam I)^-1 r        (push-through identity)
+// so a row with n <= 16 NBN ratings needs the n x n matrix G = Y Y^T (NBN (NBN+1)/2 tiles,
+// contraction over the k factors) and an n x n Cholesky instead of the k x k ones, then
+// x = Y^T w.  Same arithmetic class (exact f32 MFMA chains), far fewer of them: at k = 100 a
+// row with 30 ratings costs 75 + 8 MFMAs and 2 diagonal tiles instead of 224 + 308 and 7.
+// Operands: lane (g, c) of block ba holds the float4 Y[idx[16 ba + c]][16 s + 4 g .. +3];
+// element j feeds MFMA step (s, j), whose 4 contraction indices are {16 s + 4 g + j : g}.
+// Requires k % 4 == 0 (16-byte aligned rows).
+template <int NBN>
+__global__ __launch_bounds__(64) void als_dual_solve_kernel(StepArgs<float> a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using Sv = SolveMfmaF32<NBN>;
+  using Tr = MfmaTraits<float>;
+  using acc_t = typename Tr::acc_t;
+  constexpr int NT = tile_count(NBN);
+  const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+  const Unit u = a.units[a.firstDual + blockIdx.x];
+  const int n = (int)(u.end - u.beg);
+  const int k = a.k;
+  const int ksteps = (k + 15) >> 4;
+  // this lane's rating of each 16-rating block: its factor row and its value
+  const float *rowp[NBN];
+  float bacc[NBN];
+#pragma unroll
+  for (int ba = 0; ba < NBN; ++ba) {
+    const int i = ba * 16 + c;
+    const int64_t q = u.beg + (i < n ? i : n - 1);
+    rowp[ba] = i < n ? a.fixed + (int64_t)a.indx[q] * k : a.zeros;
+    const float r = a.vals[q];
+    bacc[ba] = (i < n && g == 0) ? r : 0.0f;  // group_sum in the solver restores r in all groups
+  }
+  acc_t acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = acc_t{0.0f, 0.0f, 0.0f, 0.0f};
+  float4 ya[NBN], yb[NBN];
+  // lanes whose 4 factors lie past k read zeros; rows past n point at zeros already
+  auto load = [&](float4 (&y)[NBN], int s) {
+    const int f = 16 * s + 4 * g;
+#pragma unroll
+    for (int ba = 0; ba < NBN; ++ba) {
+      const float *p = f < k ? rowp[ba] + f : a.zeros;
+      y[ba] = *reinterpret_cast<const float4 *>(p);
+    }
+  };
+  auto mma4 = [&](const float4 (&y)[NBN]) {
+#pragma unroll
+    for (int ba = 0; ba < NBN; ++ba) {
+#pragma unroll
+      for (int bb = ba; bb < NBN; ++bb) {
+        acc_t t = acc[tile_index(ba, bb, NBN)];
+        t = Tr::mma(y[ba].x, y[bb].x, t);
+        t = Tr::mma(y[ba].y, y[bb].y, t);
+        t = Tr::mma(y[ba].z, y[bb].z, t);
+        t = Tr::mma(y[ba].w, y[bb].w, t);
+        acc[tile_index(ba, bb, NBN)] = t;
+      }
+    }
+  };
+  load(ya, 0);
+  for (int s = 0; s < ksteps; ++s) {
+    if (s + 1 < ksteps) load(yb, s + 1);
+    mma4(ya);
+#pragma unroll
+    for (int ba = 0; ba < NBN; ++ba) ya[ba] = yb[ba];
+  }
+  const float lam = (float)(a.lambda * (double)n);
+  float wcol[NBN];
+  const bool bad = Sv::solve(acc, bacc, reinterpret_cast<float *>(smem), n, lam, wcol, lane);
+  // x[f] = sum_a Y[a][f] w[a]: per lane the 4 factors 16 s + 4 g + j of its NBN ratings,
+  // summed over the 16 lanes of the group; lane c == 0 of each group stores them
+  float *out = a.solved + (int64_t)u.row * k;
+  for (int s = 0; s < ksteps; ++s) {
+    load(ya, s);
+    float4 x = float4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int ba = 0; ba < NBN; ++ba) {
+      x.x = fmaf(ya[ba].x, wcol[ba], x.x);
+      x.y = fmaf(ya[ba].y, wcol[ba], x.y);
+      x.z = fmaf(ya[ba].z, wcol[ba], x.z);
+      x.w = fmaf(ya[ba].w, wcol[ba], x.w);
+    }
+    x.x = Sv::row_sum(x.x);
+    x.y = Sv::row_sum(x.y);
+    x.z = Sv::row_sum(x.z);
+    x.w = Sv::row_sum(x.w);
+    const int f = 16 * s + 4 * g;
+    if (c == 0 && f < k) *reinterpret_cast<float4 *>(out + f) = x;
+  }
+  if (bad && lane == 0) {
+    atomicAdd(&a.err->count, 1);
+    a.err->firstRow = u.row;
+  }
 }
 
 // Kernel 2: one wave per split row -- sum its slabs in slab order, then solve.

@@ -44,6 +44,7 @@ constexpr int kMaxFactors = 128;
 constexpr int kDefaultChunk = 1024;  // ratings per split unit (and the largest fused row)
 constexpr int kMaxSlabsPerRow = 64;  // heavier rows get proportionally longer chunks
 constexpr size_t kZeroRowBytes = 2048;  // >= kMaxFactors doubles
+constexpr int kMaxDualBlocks = 6;        // dual-form kernels exist for 1..6 blocks of 16 ratings
 
 size_t tsize(int dtype) { return dtype == YCNR_F64 ? 8 : 4; }
 
@@ -70,6 +71,9 @@ struct Schedule {
   SplitRow *dSplit = nullptr;
   void *dSlabs = nullptr;
   int64_t nUnits = 0, nSplit = 0, nSlabs = 0, solvedRows = 0, fusedRatings = 0;
+  // whole-row units: [nSlabs, nSlabs + nPrimal) primal form, then dual classes m = kMaxDualBlocks..1
+  int64_t nPrimal = 0, dualFirst[kMaxDualBlocks + 1] = {}, dualCount[kMaxDualBlocks + 1] = {};
+  int64_t dualRows = 0, dualRatings = 0;
   void release() {
     if (dUnits) (void)hipFree(dUnits);
     if (dSplit) (void)hipFree(dSplit);
@@ -77,7 +81,8 @@ struct Schedule {
     dUnits = nullptr;
     dSplit = nullptr;
     dSlabs = nullptr;
-    nUnits = nSplit = nSlabs = solvedRows = fusedRatings = 0;
+    nUnits = nSplit = nSlabs = solvedRows = fusedRatings = nPrimal = dualRows = dualRatings = 0;
+    for (int m = 0; m <= kMaxDualBlocks; ++m) dualFirst[m] = dualCount[m] = 0;
   }
 };
 
@@ -124,9 +129,38 @@ void build_schedule(const int64_t *rowPtr, int64_t rowBegin, int64_t nRows, int 
   units.insert(units.end(), fused.begin(), fused.end());
 }
 
+struct DualPlan {
+  int64_t nPrimal = -1;  // < 0: no dual classes, every whole row goes through the primal kernel
+  const int64_t *first = nullptr, *count = nullptr;
+};
+
+template <int M>
+int launch_dual(StepArgs<float> args, const DualPlan &dp, hipStream_t stream) {
+  if (dp.count[M] > 0) {
+    args.firstDual = (int32_t)dp.first[M];
+    hipLaunchKernelGGL(als_dual_solve_kernel<M>, dim3((unsigned)dp.count[M]), dim3(64), SolveMfmaF32<M>::lds_bytes(), stream,
+                       args);
+    HIP_TRY(hipGetLastError());
+  }
+  return YCNR_OK;
+}
+
+template <typename T>
+int launch_duals(const StepArgs<T> &, const DualPlan &, hipStream_t) { return YCNR_OK; }
+template <>
+int launch_duals<float>(const StepArgs<float> &args, const DualPlan &dp, hipStream_t stream) {
+  int rc = launch_dual<6>(args, dp, stream);
+  if (!rc) rc = launch_dual<5>(args, dp, stream);
+  if (!rc) rc = launch_dual<4>(args, dp, stream);
+  if (!rc) rc = launch_dual<3>(args, dp, stream);
+  if (!rc) rc = launch_dual<2>(args, dp, stream);
+  if (!rc) rc = launch_dual<1>(args, dp, stream);
+  return rc;
+}
+
 template <typename T, int NB, bool LDS_SOLVER>
 int launch_nb(StepArgs<T> args, int64_t nUnits, int64_t nSplitUnits, int64_t nSplit, hipStream_t stream,
-              hipEvent_t *ev /* 6 events or null */) {
+              hipEvent_t *ev /* 5 events or null */, const DualPlan &dp) {
   const size_t lds = SolverFor<T, NB, LDS_SOLVER>::type::lds_bytes();
   auto k0 = als_gram_slab_kernel<T, NB>;
   auto k1 = als_gram_solve_kernel<T, NB, LDS_SOLVER>;
@@ -142,42 +176,48 @@ int launch_nb(StepArgs<T> args, int64_t nUnits, int64_t nSplitUnits, int64_t nSp
     HIP_TRY(hipGetLastError());
   }
   if (ev) HIP_TRY(hipEventRecord(ev[1], stream));
-  if (nUnits > nSplitUnits) {
-    hipLaunchKernelGGL(k1, dim3((unsigned)(nUnits - nSplitUnits)), dim3(64), lds, stream, args);
+  const int64_t nPrimal = dp.nPrimal >= 0 ? dp.nPrimal : nUnits - nSplitUnits;
+  if (nPrimal > 0) {
+    hipLaunchKernelGGL(k1, dim3((unsigned)nPrimal), dim3(64), lds, stream, args);
     HIP_TRY(hipGetLastError());
   }
   if (ev) HIP_TRY(hipEventRecord(ev[2], stream));
+  if (dp.nPrimal >= 0) {
+    int rc = launch_duals<T>(args, dp, stream);
+    if (rc) return rc;
+  }
+  if (ev) HIP_TRY(hipEventRecord(ev[3], stream));
   if (nSplit > 0) {
     hipLaunchKernelGGL(k2, dim3((unsigned)nSplit), dim3(64), lds, stream, args);
     HIP_TRY(hipGetLastError());
   }
-  if (ev) HIP_TRY(hipEventRecord(ev[3], stream));
+  if (ev) HIP_TRY(hipEventRecord(ev[4], stream));
   return YCNR_OK;
 }
 
 template <typename T>
 int launch_step(const StepArgs<T> &args, int64_t nUnits, int64_t nSplitUnits, int64_t nSplit, hipStream_t stream,
-                hipEvent_t *ev, bool ldsSolver = false) {
+                hipEvent_t *ev, bool ldsSolver = false, const DualPlan &dp = DualPlan()) {
   if (nUnits > 0x7fffffffLL || nSplit > 0x7fffffffLL)
     return fail(YCNR_ERR_UNSUPPORTED, "too many work units for one launch (%lld)", (long long)nUnits);
   const int nb = (args.k + 15) / 16;
   switch (nb) {
-    case 1: return ldsSolver ? launch_nb<T, 1, true>(args, nUnits, nSplitUnits, nSplit, stream, ev)
-                             : launch_nb<T, 1, false>(args, nUnits, nSplitUnits, nSplit, stream, ev);
-    case 2: return ldsSolver ? launch_nb<T, 2, true>(args, nUnits, nSplitUnits, nSplit, stream, ev)
-                             : launch_nb<T, 2, false>(args, nUnits, nSplitUnits, nSplit, stream, ev);
-    case 3: return ldsSolver ? launch_nb<T, 3, true>(args, nUnits, nSplitUnits, nSplit, stream, ev)
-                             : launch_nb<T, 3, false>(args, nUnits, nSplitUnits, nSplit, stream, ev);
-    case 4: return ldsSolver ? launch_nb<T, 4, true>(args, nUnits, nSplitUnits, nSplit, stream, ev)
-                             : launch_nb<T, 4, false>(args, nUnits, nSplitUnits, nSplit, stream, ev);
-    case 5: return ldsSolver ? launch_nb<T, 5, true>(args, nUnits, nSplitUnits, nSplit, stream, ev)
-                             : launch_nb<T, 5, false>(args, nUnits, nSplitUnits, nSplit, stream, ev);
-    case 6: return ldsSolver ? launch_nb<T, 6, true>(args, nUnits, nSplitUnits, nSplit, stream, ev)
-                             : launch_nb<T, 6, false>(args, nUnits, nSplitUnits, nSplit, stream, ev);
-    case 7: return ldsSolver ? launch_nb<T, 7, true>(args, nUnits, nSplitUnits, nSplit, stream, ev)
-                             : launch_nb<T, 7, false>(args, nUnits, nSplitUnits, nSplit, stream, ev);
-    case 8: return ldsSolver ? launch_nb<T, 8, true>(args, nUnits, nSplitUnits, nSplit, stream, ev)
-                             : launch_nb<T, 8, false>(args, nUnits, nSplitUnits, nSplit, stream, ev);
+    case 1: return ldsSolver ? launch_nb<T, 1, true>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp)
+                             : launch_nb<T, 1, false>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp);
+    case 2: return ldsSolver ? launch_nb<T, 2, true>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp)
+                             : launch_nb<T, 2, false>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp);
+    case 3: return ldsSolver ? launch_nb<T, 3, true>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp)
+                             : launch_nb<T, 3, false>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp);
+    case 4: return ldsSolver ? launch_nb<T, 4, true>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp)
+                             : launch_nb<T, 4, false>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp);
+    case 5: return ldsSolver ? launch_nb<T, 5, true>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp)
+                             : launch_nb<T, 5, false>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp);
+    case 6: return ldsSolver ? launch_nb<T, 6, true>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp)
+                             : launch_nb<T, 6, false>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp);
+    case 7: return ldsSolver ? launch_nb<T, 7, true>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp)
+                             : launch_nb<T, 7, false>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp);
+    case 8: return ldsSolver ? launch_nb<T, 8, true>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp)
+                             : launch_nb<T, 8, false>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp);
     default:
       return fail(YCNR_ERR_UNSUPPORTED, "factorsCount %d > %d is not supported by this build", args.k,
                   kMaxFactors);
@@ -185,6 +225,14 @@ int launch_step(const StepArgs<T> &args, int64_t nUnits, int64_t nSplitUnits, in
 }
 
 int slab_nb(int k) { return (k + 15) / 16; }
+
+// Longest row solved in dual form (0 = never): float32 MFMA solver only, rows of 16-byte
+// multiples, and strictly fewer 16-blocks than the primal form would use.
+int dual_max_ratings(const ycnr_als_options &o) {
+  if (o.dtype != YCNR_F32 || (o.flags & (YCNR_FLAG_LDS_SOLVER | YCNR_FLAG_NO_DUAL)) || o.factorsCount % 4 != 0) return 0;
+  const int nb = slab_nb(o.factorsCount);
+  return 16 * std::min(kMaxDualBlocks, nb - 1);
+}
 
 // copy `bytes` from src (host or device) to a device destination
 int copy_in(void *dst, const void *src, size_t bytes, int memKind, hipStream_t stream) {
@@ -224,7 +272,7 @@ struct ycnr_als {
   ycnr_als_options opt{};
   hipStream_t ownStream = nullptr;
   hipStream_t stream = nullptr;
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   void *factors[2] = {nullptr, nullptr};
   bool ownFactors[2] = {false, false};
   Ratings ratings[2];
@@ -279,7 +327,7 @@ int ycnr_als_create(const ycnr_als_options *o, ycnr_als **out) {
   if (h->opt.chunkRatings == 0) h->opt.chunkRatings = kDefaultChunk;
   h->opt.chunkRatings = (h->opt.chunkRatings + 3) & ~3;
   hipError_t e = hipStreamCreateWithFlags(&h->ownStream, hipStreamNonBlocking);
-  for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&h->ev[i]);
+  for (int i = 0; i < 5 && e == hipSuccess; ++i) e = hipEventCreate(&h->ev[i]);
   for (int s = 0; s < 2 && e == hipSuccess; ++s) {
     e = hipMalloc(&h->factors[s], (size_t)h->rows(s) * o->factorsCount * h->ts());
     if (e == hipSuccess) {
@@ -315,7 +363,7 @@ int ycnr_als_destroy(ycnr_als *h) {
   }
   if (h->dErr) (void)hipFree(h->dErr);
   if (h->dZeros) (void)hipFree(h->dZeros);
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 5; ++i)
     if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
   if (h->ownStream) (void)hipStreamDestroy(h->ownStream);
   delete h;
@@ -393,6 +441,22 @@ int ycnr_als_set_ratings(ycnr_als *h, int side, const int64_t *rowPtr, const int
   S.solvedRows = solved;
   S.fusedRatings = 0;
   for (size_t i = (size_t)nSlabs; i < units.size(); ++i) S.fusedRatings += units[i].end - units[i].beg;
+  // whole rows are sorted by descending length: rows short enough for the dual form are the
+  // tail of the list, grouped by their number of 16-rating blocks
+  const int dualMax = dual_max_ratings(h->opt);
+  S.nPrimal = 0;
+  for (size_t i = (size_t)nSlabs; i < units.size(); ++i) {
+    const int64_t n = units[i].end - units[i].beg;
+    if (n > dualMax) {
+      ++S.nPrimal;
+      continue;
+    }
+    const int m = (int)((n + 15) / 16);
+    if (S.dualCount[m] == 0) S.dualFirst[m] = (int64_t)i;
+    ++S.dualCount[m];
+    ++S.dualRows;
+    S.dualRatings += n;
+  }
   if (S.nUnits) {
     HIP_TRY(hipMalloc(&S.dUnits, sizeof(Unit) * units.size()));
     HIP_TRY(hipMemcpy(S.dUnits, units.data(), sizeof(Unit) * units.size(), hipMemcpyHostToDevice));
@@ -481,11 +545,17 @@ int ycnr_als_step_async(ycnr_als *h, int side) {
   int rc;
   if (h->opt.dtype == YCNR_F32) {
     StepArgs<float> a{S.dUnits, S.dSplit, R.dIndx, (const float *)R.dVals, (const float *)h->factors[1 - side],
-                      (const float *)h->dZeros, (float *)h->factors[side], (float *)S.dSlabs, h->dErr, lambda, h->opt.factorsCount, 0};
-    rc = launch_step<float>(a, S.nUnits, S.nSlabs, S.nSplit, h->stream, h->ev, (h->opt.flags & YCNR_FLAG_LDS_SOLVER) != 0);
+                      (const float *)h->dZeros, (float *)h->factors[side], (float *)S.dSlabs, h->dErr, lambda, h->opt.factorsCount, 0, 0};
+    DualPlan dp;
+    if (dual_max_ratings(h->opt) > 0) {
+      dp.nPrimal = S.nPrimal;
+      dp.first = S.dualFirst;
+      dp.count = S.dualCount;
+    }
+    rc = launch_step<float>(a, S.nUnits, S.nSlabs, S.nSplit, h->stream, h->ev, (h->opt.flags & YCNR_FLAG_LDS_SOLVER) != 0, dp);
   } else {
     StepArgs<double> a{S.dUnits, S.dSplit, R.dIndx, (const double *)R.dVals, (const double *)h->factors[1 - side],
-                       (const double *)h->dZeros, (double *)h->factors[side], (double *)S.dSlabs, h->dErr, lambda, h->opt.factorsCount, 0};
+                       (const double *)h->dZeros, (double *)h->factors[side], (double *)S.dSlabs, h->dErr, lambda, h->opt.factorsCount, 0, 0};
     rc = launch_step<double>(a, S.nUnits, S.nSlabs, S.nSplit, h->stream, h->ev, true);
   }
   if (rc) return rc;
@@ -498,6 +568,10 @@ int ycnr_als_step_async(ycnr_als *h, int side) {
   h->info.splitRows = S.nSplit;
   h->info.fusedRows = S.solvedRows - S.nSplit;
   h->info.fusedRatings = S.fusedRatings;
+  if (h->opt.dtype == YCNR_F32 && dual_max_ratings(h->opt) > 0) {
+    h->info.dualRows = S.dualRows;
+    h->info.dualRatings = S.dualRatings;
+  }
   h->infoPending = true;
   h->infoHasSplit = S.nSplit > 0;
   return YCNR_OK;
@@ -515,8 +589,10 @@ int ycnr_als_sync(ycnr_als *h) {
     HIP_TRY(hipEventElapsedTime(&ms, h->ev[1], h->ev[2]));
     h->info.gramSolveMs = ms;
     HIP_TRY(hipEventElapsedTime(&ms, h->ev[2], h->ev[3]));
+    h->info.dualSolveMs = ms;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev[3], h->ev[4]));
     h->info.reduceSolveMs = ms;
-    HIP_TRY(hipEventElapsedTime(&ms, h->ev[0], h->ev[3]));
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev[0], h->ev[4]));
     h->info.totalMs = ms;
     ErrInfo ei{};
     HIP_TRY(hipMemcpy(&ei, h->dErr, sizeof ei, hipMemcpyDeviceToHost));
@@ -687,7 +763,7 @@ int64_t als_calc_portion(double lambda, int k, const int32_t *alsRows, const int
   L1_TRY(hipMemcpyAsync(dFixed, cfix.data(), sizeof(T) * cfix.size(), hipMemcpyHostToDevice, stream));
   {
     // rows are numbered 0..nRows-1 on the device and scattered to rowId on the host
-    StepArgs<T> a{dUnits, dSplit, dIndx, dVals, dFixed, dZeros, dSolved, dSlabs, dErr, lambda, k, 0};
+    StepArgs<T> a{dUnits, dSplit, dIndx, dVals, dFixed, dZeros, dSolved, dSlabs, dErr, lambda, k, 0, 0};
     rc = launch_step<T>(a, (int64_t)units.size(), nSlabs, (int64_t)split.size(), stream, nullptr);
     if (rc) {
       cleanup();

@@ -16,6 +16,7 @@ BY_USER, BY_ITEM = 0, 1
 F32, F64 = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
 RMSE_VALIDATE, RMSE_TEST = 0, 1
+FLAG_LDS_SOLVER, FLAG_NO_DUAL = 1, 2
 
 # every symbol include/ycnr_als.h declares (checked by tests/test_abi.py)
 EXPORTS = [
@@ -44,9 +45,9 @@ class Options(C.Structure):
 class StepInfo(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("side", C.c_int32), ("rows", C.c_int64), ("ratings", C.c_int64),
                 ("units", C.c_int64), ("splitRows", C.c_int64), ("fusedRows", C.c_int64),
-                ("fusedRatings", C.c_int64), ("gramSlabMs", C.c_float),
-                ("gramSolveMs", C.c_float), ("reduceSolveMs", C.c_float), ("totalMs", C.c_float),
-                ("numericErrors", C.c_int32), ("pad", C.c_int32)]
+                ("fusedRatings", C.c_int64), ("dualRows", C.c_int64), ("dualRatings", C.c_int64),
+                ("gramSlabMs", C.c_float), ("gramSolveMs", C.c_float), ("dualSolveMs", C.c_float),
+                ("reduceSolveMs", C.c_float), ("totalMs", C.c_float), ("numericErrors", C.c_int32)]
 
 
 _lib = None

@@ -80,7 +80,7 @@ class AlsDevice:
     """Level 2: resident trainer handle (one per GPU / process)."""
 
     def __init__(self, factorsCount, totalUsersCount, totalItemsCount, useDoublePrecision=False,
-                 userFactReg=0.05, itemFactReg=0.05, device=0, chunkRatings=0):
+                 userFactReg=0.05, itemFactReg=0.05, device=0, chunkRatings=0, flags=0):
         self._L = _lib.load()
         self.k = int(factorsCount)
         self.users = int(totalUsersCount)
@@ -96,6 +96,7 @@ class AlsDevice:
         o.userFactReg = float(userFactReg)
         o.itemFactReg = float(itemFactReg)
         o.chunkRatings = int(chunkRatings)
+        o.flags = int(flags)
         h = C.c_void_p()
         check(self._L.ycnr_als_create(C.byref(o), C.byref(h)))
         self._h = h
