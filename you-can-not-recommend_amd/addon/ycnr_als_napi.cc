@@ -1,0 +1,422 @@
+// ycnr_als_napi.cc -- thin N-API shim over the C ABI of libycnr_als.so (include/ycnr_als.h).
+//
+// It replaces the reference's node-gyp addon cpp_utils (binding.gyp:3-16,
+// cpp_utils/cpp_utils.cc:3-8): same shape -- s/d-prefixed functions that borrow the raw
+// memory of JS typed arrays for the duration of one synchronous call
+// (cpp_utils/cpp_utils.h:6-7 GET_CONTENTS) -- but written against N-API instead of the V8 API
+// the reference used (which no longer compiles on Node 12).  No arithmetic
+// happens here; every failure of the library is rethrown as a JS Error carrying
+// ycnr_last_error().
+#include <node_api.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ycnr_als.h"
+
+namespace {
+
+#define NAPI_OK(call)                                            \
+  do {                                                           \
+    if ((call) != napi_ok) {                                     \
+      napi_throw_error(env, nullptr, "N-API call failed: " #call); \
+      return nullptr;                                            \
+    }                                                            \
+  } while (0)
+
+napi_value throw_msg(napi_env env, const std::string &msg) {
+  napi_throw_error(env, nullptr, msg.c_str());
+  return nullptr;
+}
+
+napi_value throw_last(napi_env env, const char *where, long long code) {
+  char buf[1200];
+  snprintf(buf, sizeof buf, "%s failed (%lld): %s", where, code, ycnr_last_error());
+  napi_throw_error(env, nullptr, buf);
+  return nullptr;
+}
+
+struct View {
+  void *data = nullptr;
+  size_t length = 0;
+  napi_typedarray_type type = napi_int8_array;
+  bool ok = false;
+};
+
+// raw pointer of a typed array (the N-API spelling of GET_CONTENTS, cpp_utils/cpp_utils.h:6-7)
+View view_of(napi_env env, napi_value v) {
+  View w;
+  bool is = false;
+  if (napi_is_typedarray(env, v, &is) != napi_ok || !is) return w;
+  napi_value ab;
+  size_t off = 0;
+  if (napi_get_typedarray_info(env, v, &w.type, &w.length, &w.data, &ab, &off) != napi_ok) return w;
+  w.ok = true;
+  return w;
+}
+
+bool get_double(napi_env env, napi_value v, double *out) { return napi_get_value_double(env, v, out) == napi_ok; }
+bool get_int(napi_env env, napi_value v, int64_t *out) {
+  double d;
+  if (napi_get_value_double(env, v, &d) != napi_ok) return false;
+  *out = (int64_t)d;
+  return true;
+}
+
+napi_value num(napi_env env, double d) {
+  napi_value v;
+  napi_create_double(env, d, &v);
+  return v;
+}
+
+void set_num(napi_env env, napi_value obj, const char *key, double d) { napi_set_named_property(env, obj, key, num(env, d)); }
+
+// rowPtr may arrive as Int32Array, Float64Array (exact below 2^53) or BigInt64Array
+bool to_i64(const View &w, std::vector<int64_t> &out) {
+  out.resize(w.length);
+  switch (w.type) {
+    case napi_int32_array:
+      for (size_t i = 0; i < w.length; ++i) out[i] = static_cast<const int32_t *>(w.data)[i];
+      return true;
+    case napi_float64_array:
+      for (size_t i = 0; i < w.length; ++i) out[i] = (int64_t) static_cast<const double *>(w.data)[i];
+      return true;
+    case napi_bigint64_array:
+      memcpy(out.data(), w.data, sizeof(int64_t) * w.length);
+      return true;
+    default:
+      return false;
+  }
+}
+
+template <bool DOUBLE>
+napi_value AlsCalcPortion(napi_env env, napi_callback_info info) {
+  size_t argc = 7;
+  napi_value a[7];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, a, nullptr, nullptr));
+  if (argc < 7) return throw_msg(env, "AlsCalcPortion(lambda, k, alsRows, alsIndx, alsVals, fixedFactors, solvedFactors)");
+  double lambda;
+  int64_t k;
+  if (!get_double(env, a[0], &lambda) || !get_int(env, a[1], &k)) return throw_msg(env, "invalid type!");
+  const napi_typedarray_type ft = DOUBLE ? napi_float64_array : napi_float32_array;
+  View rows = view_of(env, a[2]), indx = view_of(env, a[3]), vals = view_of(env, a[4]), fixed = view_of(env, a[5]),
+       solved = view_of(env, a[6]);
+  if (!rows.ok || !indx.ok || !vals.ok || !fixed.ok || !solved.ok || rows.type != napi_int32_array ||
+      indx.type != napi_int32_array || vals.type != ft || fixed.type != ft || solved.type != ft)
+    return throw_msg(env, "invalid type!");  // cpp_utils/cpp_utils.js:12
+  if (k < 1 || rows.length < 1) return throw_msg(env, "invalid portion");
+  const int32_t *r = static_cast<const int32_t *>(rows.data);
+  if (r[0] < 0 || (size_t)(1 + 2 * (int64_t)r[0]) > rows.length) return throw_msg(env, "alsRows shorter than its row count");
+  int64_t total = 0;
+  for (int i = 0; i < r[0]; ++i) total += r[2 + 2 * i];
+  if ((size_t)total > indx.length || (size_t)total > vals.length) return throw_msg(env, "alsIndx / alsVals shorter than the portion");
+  int64_t n;
+  if (DOUBLE)
+    n = ycnr_dAlsCalcPortion(lambda, (int)k, r, static_cast<const int32_t *>(indx.data), static_cast<const double *>(vals.data),
+                             static_cast<const double *>(fixed.data), (int64_t)(fixed.length / k),
+                             static_cast<double *>(solved.data), (int64_t)(solved.length / k));
+  else
+    n = ycnr_sAlsCalcPortion(lambda, (int)k, r, static_cast<const int32_t *>(indx.data), static_cast<const float *>(vals.data),
+                             static_cast<const float *>(fixed.data), (int64_t)(fixed.length / k),
+                             static_cast<float *>(solved.data), (int64_t)(solved.length / k));
+  if (n < 0) return throw_last(env, DOUBLE ? "dAlsCalcPortion" : "sAlsCalcPortion", n);
+  return num(env, (double)n);
+}
+
+template <bool DOUBLE>
+napi_value RmsePortion(napi_env env, napi_callback_info info) {
+  size_t argc = 7;
+  napi_value a[7];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, a, nullptr, nullptr));
+  if (argc < 7) return throw_msg(env, "RmsePortion(k, rmseRows, rmseIndx, rmseVals, userFactors, itemFactors, globalAvgShift)");
+  int64_t k;
+  double shift;
+  if (!get_int(env, a[0], &k) || !get_double(env, a[6], &shift)) return throw_msg(env, "invalid type!");
+  const napi_typedarray_type ft = DOUBLE ? napi_float64_array : napi_float32_array;
+  View rows = view_of(env, a[1]), indx = view_of(env, a[2]), vals = view_of(env, a[3]), U = view_of(env, a[4]), I = view_of(env, a[5]);
+  if (!rows.ok || !indx.ok || !vals.ok || !U.ok || !I.ok || rows.type != napi_int32_array || indx.type != napi_int32_array ||
+      vals.type != ft || U.type != ft || I.type != ft)
+    return throw_msg(env, "invalid type!");
+  if (k < 1) return throw_msg(env, "invalid k");
+  double out[3];
+  int rc;
+  if (DOUBLE)
+    rc = ycnr_dRmsePortion((int)k, static_cast<const int32_t *>(rows.data), static_cast<const int32_t *>(indx.data),
+                           static_cast<const double *>(vals.data), static_cast<const double *>(U.data), (int64_t)(U.length / k),
+                           static_cast<const double *>(I.data), (int64_t)(I.length / k), shift, out);
+  else
+    rc = ycnr_sRmsePortion((int)k, static_cast<const int32_t *>(rows.data), static_cast<const int32_t *>(indx.data),
+                           static_cast<const float *>(vals.data), static_cast<const float *>(U.data), (int64_t)(U.length / k),
+                           static_cast<const float *>(I.data), (int64_t)(I.length / k), shift, out);
+  if (rc) return throw_last(env, "RmsePortion", rc);
+  napi_value o;
+  NAPI_OK(napi_create_object(env, &o));
+  set_num(env, o, "rSumDiff2", out[0]);  // the 'completedPortion' fields, EmfWorker.js:311-313
+  set_num(env, o, "rCnt", out[1]);
+  set_num(env, o, "rSum", out[2]);
+  return o;
+}
+
+napi_value DeviceCount(napi_env env, napi_callback_info) {
+  int n = ycnr_device_count();
+  if (n < 0) return throw_last(env, "deviceCount", n);
+  return num(env, n);
+}
+
+napi_value LastError(napi_env env, napi_callback_info) {
+  napi_value s;
+  napi_create_string_utf8(env, ycnr_last_error(), NAPI_AUTO_LENGTH, &s);
+  return s;
+}
+
+napi_value Version(napi_env env, napi_callback_info) { return num(env, ycnr_version()); }
+
+// ---------------------------------------------------------------- resident trainer
+
+struct Handle {
+  ycnr_als *h = nullptr;
+  int dtype = YCNR_F32;
+  int k = 0;
+  int64_t rows[2] = {0, 0};
+};
+
+void finalize_handle(napi_env, void *data, void *) {
+  Handle *hd = static_cast<Handle *>(data);
+  if (hd) {
+    if (hd->h) ycnr_als_destroy(hd->h);
+    delete hd;
+  }
+}
+
+Handle *handle_of(napi_env env, napi_value v) {
+  void *p = nullptr;
+  if (napi_get_value_external(env, v, &p) != napi_ok || !p) return nullptr;
+  Handle *hd = static_cast<Handle *>(p);
+  return hd->h ? hd : nullptr;
+}
+
+bool named_double(napi_env env, napi_value obj, const char *key, double *out, double dflt) {
+  napi_value v;
+  bool has = false;
+  *out = dflt;
+  if (napi_has_named_property(env, obj, key, &has) != napi_ok || !has) return true;
+  if (napi_get_named_property(env, obj, key, &v) != napi_ok) return false;
+  napi_valuetype t;
+  napi_typeof(env, v, &t);
+  if (t == napi_boolean) {
+    bool b;
+    napi_get_value_bool(env, v, &b);
+    *out = b ? 1 : 0;
+    return true;
+  }
+  if (t == napi_undefined || t == napi_null) return true;
+  return napi_get_value_double(env, v, out) == napi_ok;
+}
+
+// create({device, useDoublePrecision, factorsCount, totalUsersCount, totalItemsCount,
+//         userFactReg, itemFactReg, chunkRatings, flags}) -> handle
+napi_value Create(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value a[1];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, a, nullptr, nullptr));
+  if (argc < 1) return throw_msg(env, "create(options)");
+  double device, dbl, k, users, items, ur, ir, chunk, flags;
+  if (!named_double(env, a[0], "device", &device, 0) || !named_double(env, a[0], "useDoublePrecision", &dbl, 0) ||
+      !named_double(env, a[0], "factorsCount", &k, 100) || !named_double(env, a[0], "totalUsersCount", &users, 0) ||
+      !named_double(env, a[0], "totalItemsCount", &items, 0) || !named_double(env, a[0], "userFactReg", &ur, 0.05) ||
+      !named_double(env, a[0], "itemFactReg", &ir, 0.05) || !named_double(env, a[0], "chunkRatings", &chunk, 0) ||
+      !named_double(env, a[0], "flags", &flags, 0))
+    return throw_msg(env, "create: bad option value");
+  ycnr_als_options o;
+  memset(&o, 0, sizeof o);
+  o.struct_size = (int32_t)sizeof o;
+  o.device = (int32_t)device;
+  o.dtype = dbl != 0 ? YCNR_F64 : YCNR_F32;
+  o.factorsCount = (int32_t)k;
+  o.totalUsersCount = (int64_t)users;
+  o.totalItemsCount = (int64_t)items;
+  o.userFactReg = ur;
+  o.itemFactReg = ir;
+  o.chunkRatings = (int32_t)chunk;
+  o.flags = (int32_t)flags;
+  Handle *hd = new Handle();
+  int rc = ycnr_als_create(&o, &hd->h);
+  if (rc) {
+    delete hd;
+    return throw_last(env, "create", rc);
+  }
+  hd->dtype = o.dtype;
+  hd->k = o.factorsCount;
+  hd->rows[0] = o.totalUsersCount;
+  hd->rows[1] = o.totalItemsCount;
+  napi_value ext;
+  if (napi_create_external(env, hd, finalize_handle, nullptr, &ext) != napi_ok) {
+    finalize_handle(env, hd, nullptr);
+    return throw_msg(env, "napi_create_external failed");
+  }
+  return ext;
+}
+
+napi_value Destroy(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value a[1];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, a, nullptr, nullptr));
+  void *p = nullptr;
+  if (argc < 1 || napi_get_value_external(env, a[0], &p) != napi_ok || !p) return throw_msg(env, "destroy(handle)");
+  Handle *hd = static_cast<Handle *>(p);
+  if (hd->h) {
+    ycnr_als_destroy(hd->h);
+    hd->h = nullptr;
+  }
+  return nullptr;
+}
+
+template <bool RMSE>
+napi_value SetRatings(napi_env env, napi_callback_info info) {
+  size_t argc = 7;
+  napi_value a[7];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, a, nullptr, nullptr));
+  if (argc < 5) return throw_msg(env, "setRatings(handle, side, rowPtr, indx, vals[, rowBegin, rowEnd])");
+  Handle *hd = handle_of(env, a[0]);
+  int64_t side;
+  if (!hd || !get_int(env, a[1], &side)) return throw_msg(env, "bad handle or side");
+  View rp = view_of(env, a[2]), indx = view_of(env, a[3]), vals = view_of(env, a[4]);
+  const napi_typedarray_type ft = hd->dtype == YCNR_F64 ? napi_float64_array : napi_float32_array;
+  if (!rp.ok || !indx.ok || !vals.ok || indx.type != napi_int32_array || vals.type != ft) return throw_msg(env, "invalid type!");
+  std::vector<int64_t> rowPtr;
+  if (!to_i64(rp, rowPtr) || rowPtr.empty()) return throw_msg(env, "invalid type!");
+  const int64_t totalRows = RMSE ? hd->rows[0] : hd->rows[side == YCNR_BY_ITEM ? 1 : 0];
+  if ((int64_t)rowPtr.size() != totalRows + 1) return throw_msg(env, "rowPtr must have rows + 1 entries");
+  int64_t rb = 0, re = totalRows;
+  if (argc >= 7) {
+    if (!get_int(env, a[5], &rb) || !get_int(env, a[6], &re)) return throw_msg(env, "bad shard range");
+  }
+  if (rowPtr.back() < 0 || (size_t)rowPtr.back() > indx.length || (size_t)rowPtr.back() > vals.length)
+    return throw_msg(env, "indx / vals shorter than rowPtr says");
+  int rc = RMSE ? ycnr_als_set_rmse_ratings(hd->h, (int)side, rowPtr.data(), static_cast<const int32_t *>(indx.data), vals.data, rb,
+                                            re, YCNR_MEM_HOST)
+                : ycnr_als_set_ratings(hd->h, (int)side, rowPtr.data(), static_cast<const int32_t *>(indx.data), vals.data, rb, re,
+                                       YCNR_MEM_HOST);
+  if (rc) return throw_last(env, RMSE ? "setRmseRatings" : "setRatings", rc);
+  return nullptr;
+}
+
+napi_value SetFactors(napi_env env, napi_callback_info info) {
+  size_t argc = 3;
+  napi_value a[3];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, a, nullptr, nullptr));
+  if (argc < 3) return throw_msg(env, "setFactors(handle, side, array)");
+  Handle *hd = handle_of(env, a[0]);
+  int64_t side;
+  if (!hd || !get_int(env, a[1], &side) || (side != 0 && side != 1)) return throw_msg(env, "bad handle or side");
+  View v = view_of(env, a[2]);
+  const napi_typedarray_type ft = hd->dtype == YCNR_F64 ? napi_float64_array : napi_float32_array;
+  if (!v.ok || v.type != ft) return throw_msg(env, "invalid type!");
+  if ((int64_t)v.length != hd->rows[side] * hd->k) return throw_msg(env, "factor array has the wrong length");
+  int rc = ycnr_als_set_factors(hd->h, (int)side, v.data, YCNR_MEM_HOST);
+  if (rc) return throw_last(env, "setFactors", rc);
+  return nullptr;
+}
+
+napi_value GetFactors(napi_env env, napi_callback_info info) {
+  size_t argc = 5;
+  napi_value a[5];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, a, nullptr, nullptr));
+  if (argc < 3) return throw_msg(env, "getFactors(handle, side, array[, rowBegin, rowCount])");
+  Handle *hd = handle_of(env, a[0]);
+  int64_t side;
+  if (!hd || !get_int(env, a[1], &side) || (side != 0 && side != 1)) return throw_msg(env, "bad handle or side");
+  View v = view_of(env, a[2]);
+  const napi_typedarray_type ft = hd->dtype == YCNR_F64 ? napi_float64_array : napi_float32_array;
+  if (!v.ok || v.type != ft) return throw_msg(env, "invalid type!");
+  int64_t rb = 0, rc_ = hd->rows[side];
+  if (argc >= 5 && (!get_int(env, a[3], &rb) || !get_int(env, a[4], &rc_))) return throw_msg(env, "bad row range");
+  if ((int64_t)v.length < rc_ * hd->k) return throw_msg(env, "factor array too short");
+  int rc = ycnr_als_get_factors(hd->h, (int)side, v.data, rb, rc_, YCNR_MEM_HOST);
+  if (rc) return throw_last(env, "getFactors", rc);
+  return nullptr;
+}
+
+napi_value Step(napi_env env, napi_callback_info info) {
+  size_t argc = 2;
+  napi_value a[2];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, a, nullptr, nullptr));
+  Handle *hd = argc >= 2 ? handle_of(env, a[0]) : nullptr;
+  int64_t side;
+  if (!hd || !get_int(env, a[1], &side)) return throw_msg(env, "step(handle, side)");
+  int rc = ycnr_als_step(hd->h, (int)side);
+  if (rc) return throw_last(env, "step", rc);
+  ycnr_als_step_info si;
+  rc = ycnr_als_last_step_info(hd->h, &si);
+  if (rc) return throw_last(env, "lastStepInfo", rc);
+  napi_value o;
+  NAPI_OK(napi_create_object(env, &o));
+  set_num(env, o, "rows", (double)si.rows);
+  set_num(env, o, "ratings", (double)si.ratings);  // ratingsInPortion of 'completedPortion', summed
+  set_num(env, o, "units", (double)si.units);
+  set_num(env, o, "splitRows", (double)si.splitRows);
+  set_num(env, o, "dualRows", (double)si.dualRows);
+  set_num(env, o, "gramSlabMs", si.gramSlabMs);
+  set_num(env, o, "gramSolveMs", si.gramSolveMs);
+  set_num(env, o, "dualSolveMs", si.dualSolveMs);
+  set_num(env, o, "reduceSolveMs", si.reduceSolveMs);
+  set_num(env, o, "time", si.totalMs);  // 'time' of 'completedPortion', EmfWorker.js:258
+  return o;
+}
+
+// rmse(handle, which, globalAvgShift, portionRowEnd) -> Float64Array [rSumDiff2, rCnt, rSum] * nPortions
+napi_value Rmse(napi_env env, napi_callback_info info) {
+  size_t argc = 4;
+  napi_value a[4];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, a, nullptr, nullptr));
+  Handle *hd = argc >= 3 ? handle_of(env, a[0]) : nullptr;
+  int64_t which;
+  double shift;
+  if (!hd || !get_int(env, a[1], &which) || !get_double(env, a[2], &shift)) return throw_msg(env, "rmse(handle, which, shift[, portionRowEnd])");
+  std::vector<int64_t> ends;
+  if (argc >= 4) {
+    napi_valuetype t;
+    napi_typeof(env, a[3], &t);
+    if (t != napi_undefined && t != napi_null) {
+      View e = view_of(env, a[3]);
+      if (!e.ok || !to_i64(e, ends)) return throw_msg(env, "invalid type!");
+    }
+  }
+  const size_t np = ends.empty() ? 1 : ends.size();
+  napi_value ab, out;
+  void *buf = nullptr;
+  NAPI_OK(napi_create_arraybuffer(env, np * 3 * sizeof(double), &buf, &ab));
+  NAPI_OK(napi_create_typedarray(env, napi_float64_array, np * 3, ab, 0, &out));
+  int rc = ycnr_als_rmse(hd->h, (int)which, shift, (int)ends.size(), ends.empty() ? nullptr : ends.data(), static_cast<double *>(buf));
+  if (rc) return throw_last(env, "rmse", rc);
+  return out;
+}
+
+napi_value Init(napi_env env, napi_value exports) {
+  const napi_property_descriptor props[] = {
+      {"sAlsCalcPortion", nullptr, AlsCalcPortion<false>, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"dAlsCalcPortion", nullptr, AlsCalcPortion<true>, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"sRmsePortion", nullptr, RmsePortion<false>, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"dRmsePortion", nullptr, RmsePortion<true>, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"deviceCount", nullptr, DeviceCount, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"lastError", nullptr, LastError, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"version", nullptr, Version, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"create", nullptr, Create, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"destroy", nullptr, Destroy, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"setRatings", nullptr, SetRatings<false>, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"setRmseRatings", nullptr, SetRatings<true>, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"setFactors", nullptr, SetFactors, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"getFactors", nullptr, GetFactors, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"step", nullptr, Step, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"rmse", nullptr, Rmse, nullptr, nullptr, nullptr, napi_default, nullptr},
+  };
+  napi_define_properties(env, exports, sizeof(props) / sizeof(props[0]), props);
+  return exports;
+}
+
+}  // namespace
+
+NAPI_MODULE(ycnr_als, Init)
