@@ -1,0 +1,108 @@
+"""The NodeJS host (lib/emf/*.js + the N-API addon) -- the language the reference's host is
+written in.  CPU: API shape, error behaviour, partitioner parity with the Python mirror.
+GPU: a warm-started train() must reproduce the Python host's result files bit for bit (both
+drive the same libycnr_als.so)."""
+import json
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import make_problem
+from ycnr_als.emf import split_to_portions
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+ADDON = os.path.join(ROOT, "you-can-not-recommend_amd", "addon", "ycnr_als.node")
+
+pytestmark = pytest.mark.skipif(shutil.which("node") is None or not os.path.exists(ADDON),
+                                reason="node or the built addon is missing")
+
+
+def problem(seed=4, users=40, items=25):
+    bu, bi, U, V = make_problem(users, items, 8, density=0.35, seed=seed, min_per_row=1, empty_rows=(3,))
+    user = np.repeat(np.arange(users), bu.counts()).astype(np.int32)
+    rng = np.random.default_rng(seed)
+    typ = rng.choice([1, 1, 1, 1, 1, 1, 2, 3], size=bu.nnz).astype(np.int8)
+    return bu, user, typ, U, V
+
+
+def test_js_host_on_cpu(tmp_path):
+    bu, user, typ, U, V = problem()
+    inp = {"dir": str(tmp_path), "rip": 30, "threads": 2, "users": bu.rows, "items": bu.cols,
+           "user": user.tolist(), "item": bu.indx.tolist(), "rating": bu.vals.tolist(), "type": typ.tolist()}
+    r = subprocess.run(["node", os.path.join(HERE, "js", "host_cpu.js"), json.dumps(inp)], capture_output=True, text=True,
+                       timeout=120)
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    train = typ <= 2
+    cnt_u = np.bincount(user[train], minlength=bu.rows)
+    cnt_i = np.bincount(bu.indx[train], minlength=bu.cols)
+    assert out["trainNnz"] == int(train.sum())
+    for step, cnt, rows_cnt, pct in (("byUser", cnt_u, (cnt_u > 0).sum(), 0), ("byItem", cnt_i, (cnt_i > 0).sum(), 0),
+                                     ("rmseValidate", cnt_u, (cnt_u > 0).sum(), 11), ("rmseTest", cnt_u, (cnt_u > 0).sum(), 6)):
+        ends, rip, mrows = split_to_portions(cnt, int(rows_cnt), 30, 2, pct)
+        assert out["portionsRowIdTo"][step] == ends.tolist(), step
+        assert out["maxRatingsInPortion"][step] == rip and out["maxRowsInPortion"][step] == mrows
+    assert abs(out["totalRatingsAvg"] - float(bu.vals.mean())) < 1e-6
+    if "prepareError" in out:  # no GPU here: loud failure, carrying the library's message
+        assert "hip" in out["prepareError"].lower()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("double", [False, True])
+def test_js_train_matches_python_host(tmp_path, double):
+    from ycnr_als.data import Csr
+    from ycnr_als.emf import Dataset, EmfLord
+    import torch
+    dt = np.float64 if double else np.float32
+    bu, user, typ, U, V = problem(seed=6, users=60, items=45)
+    bu.vals = bu.vals.astype(dt)
+
+    def sub(mask):
+        cnt = np.bincount(user[mask], minlength=bu.rows)
+        rp = np.zeros(bu.rows + 1, np.int64)
+        rp[1:] = np.cumsum(cnt)
+        return Csr(bu.rows, bu.cols, rp, bu.indx[mask].copy(), bu.vals[mask].copy())
+
+    tr = sub(typ <= 2)
+    # by item: sort the train triplets by (item, user)
+    tu, ti, tv = user[typ <= 2], bu.indx[typ <= 2], bu.vals[typ <= 2]
+    o = np.lexsort((tu, ti))
+    rp = np.zeros(bu.cols + 1, np.int64)
+    rp[1:] = np.cumsum(np.bincount(ti, minlength=bu.cols))
+    tri = Csr(bu.cols, bu.rows, rp, tu[o].astype(np.int32), tv[o].copy())
+    ds = Dataset(tr, tri, sub(typ == 2), sub(typ == 3), float(bu.vals.mean()))
+    pydir, jsdir = tmp_path / "py", tmp_path / "js"
+    opts = {"factorsCount": 8, "trainIters": 3, "useDoublePrecision": double, "dbType": "ml",
+            "ratingsInPortionForRmse": 30, "numThreadsForTrain": {"als": 2}}
+    seedlord = EmfLord(options=dict(opts, dataDir=str(jsdir), trainIters=0))
+    seedlord.prepareToTrain(ds, U.astype(dt), V.astype(dt))
+    seedlord.train()  # zero iterations: just writes the starting factors as ml_factors_ready
+    seedlord.destroy()
+    lord = EmfLord(options=dict(opts, dataDir=str(pydir)))
+    lord.prepareToTrain(ds, U.astype(dt), V.astype(dt))
+    hist = lord.train()
+    lord.destroy()
+    inp = {"dir": str(jsdir), "k": 8, "iters": 3, "rip": 30, "threads": 2, "useDoublePrecision": double,
+           "users": bu.rows, "items": bu.cols, "user": user.tolist(), "item": bu.indx.tolist(),
+           "rating": bu.vals.tolist(), "type": typ.tolist()}
+    (tmp_path / "in.json").write_text(json.dumps(inp))
+    r = subprocess.run(["node", os.path.join(HERE, "js", "train_gpu.js"), str(tmp_path / "in.json")], capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    for name in ("user_factors", "item_factors"):
+        a = np.fromfile(pydir / "ml_factors_ready" / name, dt)
+        b = np.fromfile(jsdir / "ml_factors_ready" / name, dt)
+        assert np.array_equal(a, b), name
+    for hp, hj in zip(hist, out["history"]):
+        for key in ("rmseValidate", "rmseTest", "rmseTestShifted", "globalAvgShift"):
+            assert abs(hp[key] - hj[key]) < 1e-12, key
+    cj = json.loads((jsdir / "ml_factors_ready" / "calc_info.json").read_text())
+    cp = json.loads((pydir / "ml_factors_ready" / "calc_info.json").read_text())
+    assert list(cj) == list(cp)
+    assert cj["calcCnt"] == 2 and cp["calcCnt"] == 1  # the JS run warm-started from a saved calc
+    assert out["portionRatings"] > 0

@@ -397,21 +397,21 @@ napi_value Rmse(napi_env env, napi_callback_info info) {
 
 napi_value Init(napi_env env, napi_value exports) {
   const napi_property_descriptor props[] = {
-      {"sAlsCalcPortion", nullptr, AlsCalcPortion<false>, nullptr, nullptr, nullptr, napi_default, nullptr},
-      {"dAlsCalcPortion", nullptr, AlsCalcPortion<true>, nullptr, nullptr, nullptr, napi_default, nullptr},
-      {"sRmsePortion", nullptr, RmsePortion<false>, nullptr, nullptr, nullptr, napi_default, nullptr},
-      {"dRmsePortion", nullptr, RmsePortion<true>, nullptr, nullptr, nullptr, napi_default, nullptr},
-      {"deviceCount", nullptr, DeviceCount, nullptr, nullptr, nullptr, napi_default, nullptr},
-      {"lastError", nullptr, LastError, nullptr, nullptr, nullptr, napi_default, nullptr},
-      {"version", nullptr, Version, nullptr, nullptr, nullptr, napi_default, nullptr},
-      {"create", nullptr, Create, nullptr, nullptr, nullptr, napi_default, nullptr},
-      {"destroy", nullptr, Destroy, nullptr, nullptr, nullptr, napi_default, nullptr},
-      {"setRatings", nullptr, SetRatings<false>, nullptr, nullptr, nullptr, napi_default, nullptr},
-      {"setRmseRatings", nullptr, SetRatings<true>, nullptr, nullptr, nullptr, napi_default, nullptr},
-      {"setFactors", nullptr, SetFactors, nullptr, nullptr, nullptr, napi_default, nullptr},
-      {"getFactors", nullptr, GetFactors, nullptr, nullptr, nullptr, napi_default, nullptr},
-      {"step", nullptr, Step, nullptr, nullptr, nullptr, napi_default, nullptr},
-      {"rmse", nullptr, Rmse, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"sAlsCalcPortion", nullptr, AlsCalcPortion<false>, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+      {"dAlsCalcPortion", nullptr, AlsCalcPortion<true>, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+      {"sRmsePortion", nullptr, RmsePortion<false>, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+      {"dRmsePortion", nullptr, RmsePortion<true>, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+      {"deviceCount", nullptr, DeviceCount, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+      {"lastError", nullptr, LastError, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+      {"version", nullptr, Version, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+      {"create", nullptr, Create, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+      {"destroy", nullptr, Destroy, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+      {"setRatings", nullptr, SetRatings<false>, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+      {"setRmseRatings", nullptr, SetRatings<true>, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+      {"setFactors", nullptr, SetFactors, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+      {"getFactors", nullptr, GetFactors, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+      {"step", nullptr, Step, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+      {"rmse", nullptr, Rmse, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
   };
   napi_define_properties(env, exports, sizeof(props) / sizeof(props[0]), props);
   return exports;

@@ -1,0 +1,209 @@
+/**
+ * Train orchestration: train(), alsTrainIter(), alsTrainStep(), calcRmse(), stats and the
+ * row partitioner -- lib/emf/EmfLord.js:48-128,510-612,864-1081 without PostgreSQL and the
+ * TCP cluster.
+ */
+'use strict';
+
+const EmfMaster = require('./EmfMaster');
+
+class EmfLord extends EmfMaster {
+  /**
+   * getStats (EmfLord.js:48-128) from the data set instead of SQL: matrix row count is
+   * max(id), not count (EmfLord.js:81-82); rows without ratings are holes in the sparse
+   * arrays (EmfLord.js:99-100).
+   */
+  getStats() {
+    const ds = this.dataset, st = this.stats;
+    this.totalUsersCount = ds.totalUsersCount;
+    this.totalItemsCount = ds.totalItemsCount;
+    st.totalRatingsAvg = ds.totalRatingsAvg;
+    const one = (csr, cntArr, avgArr) => {
+      let used = 0, total = 0, max = 0;
+      for (let r = 0; r < csr.rows; r++) {
+        const b = csr.rowPtr[r], e = csr.rowPtr[r + 1], cnt = e - b;
+        if (cnt == 0) continue;
+        let s = 0;
+        for (let p = b; p < e; p++) s += csr.vals[p];
+        cntArr[r] = cnt; avgArr[r] = s / cnt;
+        used++; total += cnt;
+        if (cnt > max) max = cnt;
+      }
+      return [used, total, max];
+    };
+    st.ratingsCntPerUser = []; st.ratingsAvgPerUser = []; st.ratingsCntPerItem = []; st.ratingsAvgPerItem = [];
+    [this.trainUsersCount, st.trainUsersRatingsCount, st.maxRatingsPerUser] = one(ds.trainByUser, st.ratingsCntPerUser, st.ratingsAvgPerUser);
+    [this.trainItemsCount, st.trainItemsRatingsCount, st.maxRatingsPerItem] = one(ds.trainByItem, st.ratingsCntPerItem, st.ratingsAvgPerItem);
+    return Promise.resolve();
+  }
+
+  /** splitToPortions (EmfLord.js:510-612), statement for statement */
+  splitToPortions() {
+    if (this.stats.trainUsersRatingsCount == 0 || this.stats.trainItemsRatingsCount == 0)
+      return Promise.resolve();
+    this.portionsRowIdTo = {};
+    const steps = ['byUser', 'byItem', 'rmseValidate', 'rmseTest'];
+    for (const stepType of steps) {
+      const rowsCnt = (stepType == 'byItem' ? this.trainItemsCount : this.trainUsersCount);
+      const ratingsCntPer = (stepType == 'byItem' ? this.stats.ratingsCntPerItem : this.stats.ratingsCntPerUser);
+      let maxRatingsPerRow = (stepType == 'byItem' ? this.stats.maxRatingsPerItem : this.stats.maxRatingsPerUser);
+      let ratingsCount = (stepType == 'byItem' ? this.stats.trainItemsRatingsCount : this.stats.trainUsersRatingsCount);
+      if (stepType == 'rmseTest') {
+        ratingsCount = Math.ceil(ratingsCount * ((this.options.dataSetDistr[2] + 1) / 100));
+        maxRatingsPerRow = Math.ceil(maxRatingsPerRow * ((this.options.dataSetDistr[2] + 1) / 100));
+      } else if (stepType == 'rmseValidate') {
+        ratingsCount = Math.ceil(ratingsCount * ((this.options.dataSetDistr[1] + 1) / 100));
+        maxRatingsPerRow = Math.ceil(maxRatingsPerRow * ((this.options.dataSetDistr[1] + 1) / 100));
+      }
+      let ratingsInPortion = (stepType == 'rmseValidate' || stepType == 'rmseTest'
+        ? this.options.ratingsInPortionForRmse
+        : this.options.ratingsInPortionForAls[stepType]);
+      let avgPortionsCount = Math.ceil(ratingsCount / ratingsInPortion);
+      let avgRowsInPortion = Math.floor(rowsCnt / avgPortionsCount);
+      if (avgPortionsCount < this.options.numThreadsForTrain[this.options.alg]) {
+        avgPortionsCount = this.options.numThreadsForTrain[this.options.alg];
+        ratingsInPortion = Math.ceil(ratingsCount / avgPortionsCount);
+        avgRowsInPortion = Math.floor(rowsCnt / avgPortionsCount);
+      }
+      if (avgRowsInPortion < 1) {
+        avgRowsInPortion = 1;
+        avgPortionsCount = rowsCnt;
+        ratingsInPortion = Math.ceil(ratingsCount / avgPortionsCount);
+      }
+      if (ratingsInPortion < maxRatingsPerRow) {
+        ratingsInPortion = maxRatingsPerRow;
+        avgPortionsCount = Math.ceil(ratingsCount / ratingsInPortion);
+        avgRowsInPortion = Math.floor(rowsCnt / avgPortionsCount);
+      }
+
+      const portionsRowIdTo = [];
+      let p = 0, rtgs = 0, rows = 0, maxRows = 0;
+      for (let id in ratingsCntPer) {
+        let cnt = ratingsCntPer[id];
+        if (stepType == 'rmseTest') {
+          cnt = Math.ceil(cnt * ((this.options.dataSetDistr[2] + 1) / 100));
+        } else if (stepType == 'rmseValidate') {
+          cnt = Math.ceil(cnt * ((this.options.dataSetDistr[1] + 1) / 100));
+        }
+        id = parseInt(id);
+        if ((rtgs + cnt) > ratingsInPortion) {
+          rtgs = 0;
+          rows = 0;
+          p++;
+        }
+        rtgs += cnt;
+        rows++;
+        if (rows > maxRows) maxRows = rows;
+        portionsRowIdTo[p] = id + 1; //id is 0-based, for db we need 1-based
+      }
+      this.portionsRowIdTo[stepType] = portionsRowIdTo;
+      this.portionsCount[stepType] = portionsRowIdTo.length;
+      this.maxRatingsInPortion[stepType] = ratingsInPortion;
+      this.maxRowsInPortion[stepType] = maxRows;
+    }
+    return Promise.resolve();
+  }
+
+  /**
+   * prepareToTrain (EmfLord.js:617-653): stats -> portions -> factors -> ratings upload.
+   * @param dataset Dataset (lib/Dataset.js) standing in for the db tables
+   */
+  prepareToTrain(dataset) {
+    if (dataset) this.dataset = dataset;
+    if (!this.dataset) return Promise.reject({ code: 'no_data', error: 'No data to train' });
+    this._status = 'preparing';
+    this.calcDate = new Date().toISOString();
+    return this.getStats().then(() => {
+      if (this.trainUsersCount == 0 && this.trainItemsCount == 0)
+        return Promise.reject({ code: 'no_data', error: 'No data to train' });
+      return this.splitToPortions();
+    }).then(() => this.prepareSharedFactors())
+      .then(() => this.prepareWorkersToTrain())
+      .then(() => { this._status = 'ready'; });
+  }
+
+  getCanTrainError() {
+    let err = null;
+    if (this.status == 'training') {
+      err = 'Training is already in progress';
+    } else if (this.status != 'ready') {
+      err = 'Not ready to train. Status is ' + this.status;
+    }
+    return err;
+  }
+
+  /** train (EmfLord.js:864-926) */
+  train(dataset) {
+    const prep = (dataset || this.status != 'ready') ? this.prepareToTrain(dataset) : Promise.resolve();
+    return prep.then(() => {
+      const err = this.getCanTrainError();
+      if (err !== null) return Promise.reject(err);
+      this._status = 'training';
+      this.trainIter = 0;
+      this.history = [];
+      const loop = () => {
+        if (!(this.trainIter < this.options.trainIters)) return Promise.resolve();
+        const rec = { iter: this.trainIter };
+        return this.alsTrainIter()
+          .then(() => this.calcRmse('rmseValidate', false)).then((r) => { rec.rmseValidate = r; })
+          .then(() => this.calcRmse('rmseTest', false)).then((r) => { rec.rmseTest = r; })
+          .then(() => this.calcRmse('rmseTest', true)).then((r) => { rec.rmseTestShifted = r; })
+          .then(() => {
+            rec.globalAvgShift = this.globalAvgShift;
+            this.history.push(rec);
+            this.trainIter++;
+            return loop();
+          });
+      };
+      return loop();
+    }).then(() => {
+      this.calcCnt++;
+      return this.saveCalcResults(this.getCalcInfo());
+    }).then(() => {
+      this._status = 'ready';
+      return this.history;
+    });
+  }
+
+  /** 2 steps - first fix item vectors and calc user vectors, then vice versa (EmfLord.js:954-958) */
+  alsTrainIter() {
+    return this.alsTrainStep('byUser')
+      .then(() => this.alsTrainStep('byItem'));
+  }
+
+  /** @param string stepType 'byUser', 'byItem' (EmfLord.js:963-984) */
+  alsTrainStep(stepType) {
+    return new Promise((resolve, reject) => {
+      this.once('stepComplete', () => resolve(this.lastStepInfo));
+      try {
+        this._startAlsTrainStep(stepType);
+      } catch (e) {
+        this.removeAllListeners('stepComplete');
+        reject(e);
+      }
+    });
+  }
+
+  /** @param string stepType 'rmseValidate', 'rmseTest' (EmfLord.js:1043-1081) */
+  calcRmse(stepType, useGlobalAvgShift) {
+    if (useGlobalAvgShift && this.options.alg != 'als')
+      return Promise.resolve();
+    if (this.options.dataSetDistr[1] == 0 && stepType == 'rmseValidate')
+      return Promise.resolve();
+    if (this.options.dataSetDistr[2] == 0 && stepType == 'rmseTest')
+      return Promise.resolve();
+    if (!this.dataset[stepType == 'rmseValidate' ? 'validate' : 'test'])
+      return Promise.resolve();
+    return new Promise((resolve, reject) => {
+      this.once('stepComplete', () => resolve(this.rmse));
+      try {
+        this._startCalcRmse(stepType, useGlobalAvgShift);
+      } catch (e) {
+        this.removeAllListeners('stepComplete');
+        reject(e);
+      }
+    });
+  }
+}
+
+module.exports = EmfLord;
