@@ -74,7 +74,7 @@ def test_js_train_matches_python_host(tmp_path, double):
     rp = np.zeros(bu.cols + 1, np.int64)
     rp[1:] = np.cumsum(np.bincount(ti, minlength=bu.cols))
     tri = Csr(bu.cols, bu.rows, rp, tu[o].astype(np.int32), tv[o].copy())
-    ds = Dataset(tr, tri, sub(typ == 2), sub(typ == 3), float(bu.vals.mean()))
+    ds = Dataset(tr, tri, sub(typ == 2), sub(typ == 3), float(bu.vals.astype(np.float64).mean()))
     pydir, jsdir = tmp_path / "py", tmp_path / "js"
     opts = {"factorsCount": 8, "trainIters": 3, "useDoublePrecision": double, "dbType": "ml",
             "ratingsInPortionForRmse": 30, "numThreadsForTrain": {"als": 2}}
