@@ -31,6 +31,15 @@
 #define YCNR_FUSED_WAVES_PER_SIMD 2
 #endif
 
+// How many 4-rating steps ahead the Gramian-only kernel requests its gathered operands.
+// 0 selects the shallow (one step ahead) loop.
+#ifndef YCNR_SLAB_PREFETCH
+#define YCNR_SLAB_PREFETCH 3
+#endif
+#ifndef YCNR_SLAB_WAVES_PER_SIMD
+#define YCNR_SLAB_WAVES_PER_SIMD 2
+#endif
+
 namespace ycnr {
 
 // A wave-level work unit: ratings [beg, end) of the local CSR belong to `row`.
@@ -166,6 +175,59 @@ struct Gram {
       mma_step(acc, bacc, yA, ra);
 #pragma unroll
       for (int cb = 0; cb < NB; ++cb) yA[cb] = yB[cb];
+    }
+  }
+  // Deep-prefetch variant for long units whose gathered rows come from HBM (the item side:
+  // the user matrix does not fit the Infinity Cache).  Column ids and ratings are fetched 64
+  // at a time, one per lane, and handed to the step that needs them with a bpermute; the
+  // operands of step s + PF are requested while step s runs on the matrix cores, through a
+  // ring of PF + 1 register sets (PF + 1 divides 16, so ring positions are static).
+  template <int PF>
+  static __device__ __forceinline__ void accumulate_deep(acc_t (&acc)[NT], T (&bacc)[NB],
+                                                         const int32_t *__restrict__ indx,
+                                                         const T *__restrict__ vals,
+                                                         const T *__restrict__ fixed,
+                                                         const T *__restrict__ zeros, int k, int64_t beg,
+                                                         int64_t end, int lane) {
+    static_assert(16 % (PF + 1) == 0, "ring size must divide the 16 steps of a 64-rating block");
+    const int g = lane >> 4, c = lane & 15;
+    const int64_t n = end - beg;
+    const int64_t nblk = (n + 63) >> 6;
+    auto fetch_blk = [&](int64_t b, int32_t &id, T &r) {
+      const int64_t q = b * 64 + lane;
+      const bool v = q < n;
+      const int64_t qc = beg + (v ? q : n - 1);
+      const int32_t i = indx[qc];
+      const T t = vals[qc];
+      id = v ? i : -1;  // -1: past the end of the unit -> the zero row
+      r = v ? t : T(0);
+    };
+    auto row_of = [&](int32_t id) { return id >= 0 ? fixed + (int64_t)id * k : zeros; };
+    int32_t idc, idn;
+    T rc, rn;
+    fetch_blk(0, idc, rc);
+    fetch_blk(1, idn, rn);
+    T y[PF + 1][NB];
+#pragma unroll
+    for (int t = 0; t < PF; ++t) load_y(y[t], row_of(__shfl(idc, 4 * t + g, 64)), zeros, k, c);
+    const int64_t ngrp = nblk * (16 / (PF + 1));  // groups of PF + 1 steps
+#pragma unroll 1
+    for (int64_t grp = 0; grp < ngrp; ++grp) {
+      const int sbase = (int)(grp % (16 / (PF + 1))) * (PF + 1);
+      if (sbase == 0 && grp != 0) {  // entering the next 64-rating block
+        idc = idn;
+        rc = rn;
+        fetch_blk(grp / (16 / (PF + 1)) + 1, idn, rn);
+      }
+#pragma unroll
+      for (int u = 0; u <= PF; ++u) {
+        const int t = sbase + u + PF;  // step whose operands are requested now
+        const int32_t src = t < 16 ? idc : idn;
+        const int32_t id = __shfl(src, (4 * t + g) & 63, 64);
+        load_y(y[(u + PF) % (PF + 1)], row_of(id), zeros, k, c);
+        const T r = __shfl(rc, 4 * (sbase + u) + g, 64);
+        mma_step(acc, bacc, y[u % (PF + 1)], r);
+      }
     }
   }
 };
@@ -506,7 +568,7 @@ struct StepArgs {
 // written as a partial slab.  Kept apart from the fused kernel so that its register
 // allocation (accumulators + two operand sets) is not inflated by the solve.
 template <typename T, int NB>
-__global__ __launch_bounds__(64) void als_gram_slab_kernel(StepArgs<T> a) {
+__global__ __launch_bounds__(64, YCNR_SLAB_WAVES_PER_SIMD) void als_gram_slab_kernel(StepArgs<T> a) {
   using G = Gram<T, NB>;
   using acc_t = typename G::acc_t;
   const int lane = threadIdx.x;
@@ -517,7 +579,11 @@ __global__ __launch_bounds__(64) void als_gram_slab_kernel(StepArgs<T> a) {
   for (int t = 0; t < G::NT; ++t) acc[t] = acc_t{T(0), T(0), T(0), T(0)};
 #pragma unroll
   for (int cb = 0; cb < NB; ++cb) bacc[cb] = T(0);
+#if YCNR_SLAB_PREFETCH > 0
+  G::template accumulate_deep<YCNR_SLAB_PREFETCH>(acc, bacc, a.indx, a.vals, a.fixed, a.zeros, a.k, u.beg, u.end, lane);
+#else
   G::accumulate(acc, bacc, a.indx, a.vals, a.fixed, a.zeros, a.k, u.beg, u.end, lane);
+#endif
   T *s = a.slabs + (int64_t)u.slab * slab_elems(NB) + lane;
 #pragma unroll
   for (int t = 0; t < G::NT; ++t) {

@@ -8,7 +8,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.normpath(os.path.join(_HERE, "..", "..", "csrc"))
-SO_PATH = os.path.join(CSRC, "libycnr_als.so")
+# YCNR_ALS_LIB selects another build of the same library (A/B tests of kernel variants)
+SO_PATH = os.environ.get("YCNR_ALS_LIB") or os.path.join(CSRC, "libycnr_als.so")
 
 OK = 0
 ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_UNSUPPORTED, ERR_NUMERIC, ERR_STATE = -1, -2, -3, -4, -5, -6
