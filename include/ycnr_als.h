@@ -117,6 +117,8 @@ typedef struct ycnr_als_options {
 #define YCNR_FLAG_LDS_SOLVER 1
 /* options.flags: never use the dual (n x n) form for rows with fewer ratings than factors */
 #define YCNR_FLAG_NO_DUAL 2
+/* options.flags: sort split chunks by the first column id they touch instead of by length */
+#define YCNR_FLAG_LOCALITY_SORT 4
 
 /* Timing / accounting of the last ycnr_als_step, measured with HIP events on the
  * handle's stream around each kernel (DESIGN.md "Measurement"). */

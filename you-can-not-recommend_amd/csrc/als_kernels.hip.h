@@ -799,6 +799,11 @@ __global__ __launch_bounds__(256) void als_rmse_kernel(RmseArgs<T> a) {
   }
 }
 
+__global__ void gather_i32_kernel(const int32_t *src, const int64_t *pos, int32_t *out, int64_t n) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) out[i] = src[pos[i]];
+}
+
 // max over an int32 array (index validation after upload)
 __global__ void max_i32_kernel(const int32_t *x, int64_t n, int32_t *out_max, int32_t *out_min) {
   int32_t mx = INT32_MIN, mn = INT32_MAX;

@@ -242,6 +242,28 @@ int copy_in(void *dst, const void *src, size_t bytes, int memKind, hipStream_t s
   return YCNR_OK;
 }
 
+// out[i] = dSrc[pos[i]] for a host list of positions (one small gather kernel + two copies)
+int gather_i32(const int32_t *dSrc, const std::vector<int64_t> &pos, std::vector<int32_t> &out, hipStream_t stream) {
+  const size_t n = pos.size();
+  out.resize(n);
+  if (n == 0) return YCNR_OK;
+  int64_t *dPos = nullptr;
+  int32_t *dOut = nullptr;
+  HIP_TRY(hipMalloc(&dPos, n * sizeof(int64_t)));
+  hipError_t e = hipMalloc(&dOut, n * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMemcpyAsync(dPos, pos.data(), n * sizeof(int64_t), hipMemcpyHostToDevice, stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(gather_i32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dSrc, dPos, dOut, (int64_t)n);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(out.data(), dOut, n * sizeof(int32_t), hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  if (dPos) (void)hipFree(dPos);
+  if (dOut) (void)hipFree(dOut);
+  if (e != hipSuccess) return fail(YCNR_ERR_HIP, "gather_i32: %s", hipGetErrorString(e));
+  return YCNR_OK;
+}
+
 // validate 0 <= indx[i] < limit on the device
 int check_index_range(const int32_t *dIndx, int64_t n, int64_t limit, hipStream_t stream,
                       const char *what) {
@@ -433,6 +455,23 @@ int ycnr_als_set_ratings(ycnr_als *h, int side, const int64_t *rowPtr, const int
   std::vector<SplitRow> split;
   int64_t nSlabs = 0, solved = 0;
   build_schedule(hp.data(), rowBegin, rowEnd - rowBegin, h->opt.chunkRatings, units, split, nSlabs, solved);
+  // Optional (measured: no gain at MAL scale, 16.4 vs 16.0 ms for the item step, because the
+  // chunk kernel is bound by the matrix pipe, not by the gather): order the split chunks by
+  // the first column id they touch, so the waves in flight at any moment walk the same
+  // window of the fixed matrix.
+  if (nSlabs > 1 && (h->opt.flags & YCNR_FLAG_LOCALITY_SORT)) {
+    std::vector<int64_t> firstPos((size_t)nSlabs);
+    for (int64_t i = 0; i < nSlabs; ++i) firstPos[i] = units[i].beg;
+    std::vector<int32_t> firstId((size_t)nSlabs);
+    int rc2 = gather_i32(h->ratings[side].dIndx, firstPos, firstId, h->stream);
+    if (rc2) return rc2;
+    std::vector<int32_t> order((size_t)nSlabs);
+    for (int64_t i = 0; i < nSlabs; ++i) order[i] = (int32_t)i;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return firstId[a] < firstId[b]; });
+    std::vector<Unit> sorted((size_t)nSlabs);
+    for (int64_t i = 0; i < nSlabs; ++i) sorted[i] = units[order[i]];
+    std::copy(sorted.begin(), sorted.end(), units.begin());
+  }
   Schedule &S = h->sched[side];
   S.release();
   S.nUnits = (int64_t)units.size();
