@@ -2,7 +2,7 @@
 """bench.py -- ALS ratings/sec per iteration (U + I solve) on synthetic ratings of the
 shapes BASELINE.json names, one process per GPU.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload mal|c3|ml1m|ml100k] [--double]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload mal|c3|c5|c5shard|ml1m|ml100k] [--double]
 
 A "step" is one full ALS iteration = EmfLord.alsTrainIter(): the byUser half-step, the
 exchange of the solved user shard, the byItem half-step and its exchange.  Inputs (CSR by
@@ -32,6 +32,8 @@ WORKLOADS = {
     # name: users, items, nnz, k, max_rating, zipf_a, degree_sigma, description
     "mal": (1_750_000, 12_700, 121_000_000, 100, 10, 0.6, 1.2, "MAL-scale synthetic 1.75Mx12.7K, 121M nnz, k=100"),
     "c3": (200_000, 20_000, 20_000_000, 64, 10, 0.8, 1.0, "synthetic 200Kx20K, 20M nnz, k=64"),
+    "c5": (10_000_000, 100_000, 1_000_000_000, 256, 10, 0.7, 1.0, "synthetic 10Mx100K, 1B nnz, k=256"),
+    "c5shard": (1_250_000, 100_000, 125_000_000, 256, 10, 0.7, 1.0, "one GPU's eighth of the 10Mx100K, 1B nnz, k=256 config (1.25Mx100K, 125M nnz)"),
     "ml1m": (6040, 3883, 1_000_209, 100, 5, 0.9, 0.9, "MovieLens-1M-shaped synthetic 6040x3883, 1M nnz, k=100"),
     "ml100k": (943, 1682, 100_000, 20, 5, 0.8, 0.9, "MovieLens-100k-shaped synthetic 943x1682, 100K nnz, k=20"),
 }
@@ -134,7 +136,8 @@ def main():
     per_row = k ** 3 / 3.0 + 2 * k * k          # Cholesky + two triangular solves
     bytes_rating = 4 + s + k * s                # index + value + gathered factor row
     kern = {n: {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0} for n in
-            ("als_gram_solve_kernel", "als_dual_solve_kernel", "als_gram_slab_kernel", "als_reduce_solve_kernel")}
+            ("als_gram_solve_kernel", "als_dual_solve_kernel", "als_gram_slab_kernel", "als_gram_big+als_solve_big",
+             "als_reduce_solve_kernel")}
     step_ms = {"byUser": 0.0, "byItem": 0.0}
     for st in lord.stepTimes:
         i = st["info"]
@@ -147,9 +150,13 @@ def main():
                 # reference does for those rows, not the smaller n x n work the kernel executes
                 ("als_dual_solve_kernel", i.dualSolveMs, i.dualRatings * per_rating + i.dualRows * per_row,
                  i.dualRatings * bytes_rating + i.dualRows * (k * s + 8)),
-                ("als_gram_slab_kernel", i.gramSlabMs, (i.ratings - i.fusedRatings) * per_rating,
+                # k > 128: this interval holds als_gram_big + als_solve_big of every batch, so the
+                # rows' solve work is priced here too
+                ("als_gram_big+als_solve_big" if k > 128 else "als_gram_slab_kernel", i.gramSlabMs,
+                 (i.ratings - i.fusedRatings) * per_rating + (i.splitRows * per_row if k > 128 else 0),
                  (i.ratings - i.fusedRatings) * bytes_rating),
-                ("als_reduce_solve_kernel", i.reduceSolveMs, i.splitRows * per_row, i.splitRows * (k * s + 8))):
+                ("als_reduce_solve_kernel", i.reduceSolveMs, 0 if k > 128 else i.splitRows * per_row,
+                 i.splitRows * (k * s + 8))):
             if fl > 0:
                 kern[name]["ms"] += ms
                 kern[name]["flops"] += fl

@@ -136,7 +136,7 @@ def test_split_rows_and_chunk_edges(als, dt):
     dev2.destroy()
 
 
-@pytest.mark.parametrize("k", [20, 64, 100, 128])
+@pytest.mark.parametrize("k", [20, 64, 100, 128, 132, 200, 256])
 def test_every_row_length_class(als, k):
     """Rows of 1..130 ratings at one k: short rows take the dual (n x n) form, grouped by their
     number of 16-rating blocks, longer ones the primal form; all against float64, and the three
@@ -154,7 +154,10 @@ def test_every_row_length_class(als, k):
     V = (rng.standard_normal((items, k)) / np.sqrt(k)).astype(np.float32)
     want, conds = numpy_step(0.05, k, bu, V, U)
     got = {}
-    for name, flags in (("dual", 0), ("primal", _lib.FLAG_NO_DUAL), ("lds", _lib.FLAG_LDS_SOLVER)):
+    variants = (("dual", 0), ("primal", _lib.FLAG_NO_DUAL), ("lds", _lib.FLAG_LDS_SOLVER))
+    if k > 128:  # 4-wave kernels: with and without the dual form for short rows; no LDS-solver variant
+        variants = (("dual", 0), ("primal", _lib.FLAG_NO_DUAL))
+    for name, flags in variants:
         dev = als.AlsDevice(k, len(lens), items, flags=flags)
         dev.set_ratings("byUser", bu.rowPtr, bu.indx, bu.vals)
         dev.set_factors("byUser", U)
@@ -171,8 +174,36 @@ def test_every_row_length_class(als, k):
         assert np.array_equal(got[name][130], U[130])  # the empty row
         dev.destroy()
     for a, b in (("dual", "primal"), ("primal", "lds")):
+        if b not in got:
+            continue
         err = row_rel_err(got[a], got[b])
         assert (err <= np.maximum(16 * conds * EPS32, 2e-6)).all()
+
+
+def test_big_k_split_rows_and_batches(als):
+    """k = 256 through the 4-wave kernels: rows of many chunks, a row longer than 64 chunks, and
+    both half-steps; checked against float64."""
+    k, users, items = 256, 40, 3000
+    rng = np.random.default_rng(3)
+    lens = [0, 1, 50, 96, 97, 130, 500, 1024, 1025, 2500, 2999] + list(rng.integers(100, 400, 29))
+    rowPtr = np.zeros(users + 1, np.int64)
+    rowPtr[1:] = np.cumsum(lens)
+    indx = np.concatenate([np.sort(rng.choice(items, n, replace=False)) for n in lens]).astype(np.int32)
+    vals = rng.integers(1, 11, rowPtr[-1]).astype(np.float32)
+    bu = Csr(users, items, rowPtr, indx, vals)
+    U = (rng.standard_normal((users, k)) / k).astype(np.float32)
+    V = (rng.standard_normal((items, k)) / np.sqrt(k)).astype(np.float32)
+    dev = als.AlsDevice(k, users, items, chunkRatings=32)  # 2999 ratings -> 64 chunks of 48
+    dev.set_ratings("byUser", bu.rowPtr, bu.indx, bu.vals)
+    dev.set_factors("byUser", U)
+    dev.set_factors("byItem", V)
+    info = dev.step("byUser")
+    assert info.numericErrors == 0 and info.rows == users - 1
+    got = dev.get_factors("byUser")
+    want, conds = numpy_step(0.05, k, bu, V, U)
+    check_rows(got, want, conds, np.float32)
+    assert np.array_equal(got[0], U[0])
+    dev.destroy()
 
 
 def test_sharded_rows_equal_unsharded(als):
@@ -229,7 +260,13 @@ def test_rmse_portions(als, oracle, dt):
 def test_errors_are_reported_not_fatal(als):
     from ycnr_als import YcnrError, _lib
     with pytest.raises(YcnrError) as e:
-        als.AlsDevice(129, 10, 10)
+        als.AlsDevice(257, 10, 10)
+    assert e.value.code == _lib.ERR_UNSUPPORTED
+    with pytest.raises(YcnrError) as e:
+        als.AlsDevice(129, 10, 10, useDoublePrecision=True)  # float64 stops at 128
+    assert e.value.code == _lib.ERR_UNSUPPORTED
+    with pytest.raises(YcnrError) as e:
+        als.AlsDevice(130, 10, 10)  # the 4-wave path needs 16-byte rows
     assert e.value.code == _lib.ERR_UNSUPPORTED
     dev = als.AlsDevice(8, 4, 5)
     with pytest.raises(YcnrError) as e:

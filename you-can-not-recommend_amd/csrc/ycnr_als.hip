@@ -6,6 +6,7 @@
 // a HIP device every entry point fails with YCNR_ERR_HIP.
 #include "../../include/ycnr_als.h"
 #include "als_kernels.hip.h"
+#include "als_big_kernels.hip.h"
 
 #include <algorithm>
 #include <cstdarg>
@@ -40,7 +41,9 @@ int fail(int code, const char *fmt, ...) {
                   #expr, hipGetErrorString(e_), __FILE__, __LINE__);                            \
   } while (0)
 
-constexpr int kMaxFactors = 128;
+constexpr int kMaxFactors = 128;     // float64, and the one-wave-per-row float32 kernels
+constexpr int kMaxFactorsBig = 256;  // float32 through the 4-wave kernels of als_big_kernels.hip.h
+constexpr size_t kBigArenaBytes = (size_t)16 << 30;  // slabs of the big path are produced and consumed in batches
 constexpr int kDefaultChunk = 1024;  // ratings per split unit (and the largest fused row)
 constexpr int kMaxSlabsPerRow = 64;  // heavier rows get proportionally longer chunks
 constexpr size_t kZeroRowBytes = 2048;  // >= kMaxFactors doubles
@@ -74,7 +77,13 @@ struct Schedule {
   // whole-row units: [nSlabs, nSlabs + nPrimal) primal form, then dual classes m = kMaxDualBlocks..1
   int64_t nPrimal = 0, dualFirst[kMaxDualBlocks + 1] = {}, dualCount[kMaxDualBlocks + 1] = {};
   int64_t dualRows = 0, dualRatings = 0;
+  // big path (k > 128): consecutive rows whose slabs fit the arena together
+  struct Batch {
+    int64_t unitFirst, unitCount, splitFirst, splitCount;
+  };
+  std::vector<Batch> batches;
   void release() {
+    batches.clear();
     if (dUnits) (void)hipFree(dUnits);
     if (dSplit) (void)hipFree(dSplit);
     if (dSlabs) (void)hipFree(dSlabs);
@@ -91,7 +100,9 @@ struct Schedule {
 // rowPtr: local (length nRows + 1, any base).  Units index ratings relative to rowPtr[0].
 void build_schedule(const int64_t *rowPtr, int64_t rowBegin, int64_t nRows, int chunk,
                     std::vector<Unit> &units, std::vector<SplitRow> &split, int64_t &nSlabs,
-                    int64_t &solvedRows) {
+                    int64_t &solvedRows, int64_t splitAbove = -1) {
+  // splitAbove >= 0 (big path): every row longer than splitAbove goes through slabs, in row
+  // order (no longest-first sort, so that batches are contiguous)
   // on return units = [split chunks (nSlabs of them) | whole rows]
   const int64_t base = rowPtr[0];
   units.clear();
@@ -105,7 +116,7 @@ void build_schedule(const int64_t *rowPtr, int64_t rowBegin, int64_t nRows, int 
     if (n <= 0) continue;  // rows without ratings are never written
     ++solvedRows;
     const int32_t row = (int32_t)(rowBegin + r);
-    if (n <= chunk) {
+    if (splitAbove >= 0 ? n <= splitAbove : n <= chunk) {
       fused.push_back(Unit{b, e, row, -1});
       continue;
     }
@@ -122,8 +133,9 @@ void build_schedule(const int64_t *rowPtr, int64_t rowBegin, int64_t nRows, int 
   }
   // longest first: split chunks (all ~chunk long, longest chunks first), then fused rows by
   // descending length, so the tail of the launch is made of the cheapest units
-  std::stable_sort(units.begin(), units.end(),
-                   [](const Unit &a, const Unit &b) { return (a.end - a.beg) > (b.end - b.beg); });
+  if (splitAbove < 0)
+    std::stable_sort(units.begin(), units.end(),
+                     [](const Unit &a, const Unit &b) { return (a.end - a.beg) > (b.end - b.beg); });
   std::stable_sort(fused.begin(), fused.end(),
                    [](const Unit &a, const Unit &b) { return (a.end - a.beg) > (b.end - b.beg); });
   units.insert(units.end(), fused.begin(), fused.end());
@@ -191,6 +203,53 @@ int launch_nb(StepArgs<T> args, int64_t nUnits, int64_t nSplitUnits, int64_t nSp
     hipLaunchKernelGGL(k2, dim3((unsigned)nSplit), dim3(64), lds, stream, args);
     HIP_TRY(hipGetLastError());
   }
+  if (ev) HIP_TRY(hipEventRecord(ev[4], stream));
+  return YCNR_OK;
+}
+
+template <int NB>
+int launch_big_nb(StepArgs<float> args, const std::vector<Schedule::Batch> &batches, hipStream_t stream) {
+  auto kg = als_gram_big_kernel<NB>;
+  auto ks = als_solve_big_kernel<NB>;
+  const size_t lds = SolveBig<NB>::lds_bytes();
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  for (const Schedule::Batch &b : batches) {
+    if (b.unitCount == 0) continue;
+    args.firstFused = (int32_t)b.unitFirst;
+    args.firstDual = (int32_t)b.splitFirst;
+    hipLaunchKernelGGL(kg, dim3((unsigned)b.unitCount), dim3(256), 0, stream, args);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(ks, dim3((unsigned)b.splitCount), dim3(256), lds, stream, args);
+    HIP_TRY(hipGetLastError());
+  }
+  return YCNR_OK;
+}
+
+// 128 < k <= 256, float32: [big batches: Gramian slabs + LDS block Cholesky] then the dual classes
+int launch_step_big(const StepArgs<float> &args, const std::vector<Schedule::Batch> &batches, hipStream_t stream,
+                    hipEvent_t *ev, const DualPlan &dp) {
+  const int nb = (args.k + 15) / 16;
+  if (ev) HIP_TRY(hipEventRecord(ev[0], stream));
+  int rc;
+  switch (nb) {
+    case 9: rc = launch_big_nb<9>(args, batches, stream); break;
+    case 10: rc = launch_big_nb<10>(args, batches, stream); break;
+    case 11: rc = launch_big_nb<11>(args, batches, stream); break;
+    case 12: rc = launch_big_nb<12>(args, batches, stream); break;
+    case 13: rc = launch_big_nb<13>(args, batches, stream); break;
+    case 14: rc = launch_big_nb<14>(args, batches, stream); break;
+    case 15: rc = launch_big_nb<15>(args, batches, stream); break;
+    case 16: rc = launch_big_nb<16>(args, batches, stream); break;
+    default: return fail(YCNR_ERR_UNSUPPORTED, "factorsCount %d is outside the big path", args.k);
+  }
+  if (rc) return rc;
+  if (ev) HIP_TRY(hipEventRecord(ev[1], stream));
+  if (ev) HIP_TRY(hipEventRecord(ev[2], stream));
+  if (dp.nPrimal >= 0) {
+    rc = launch_duals<float>(args, dp, stream);
+    if (rc) return rc;
+  }
+  if (ev) HIP_TRY(hipEventRecord(ev[3], stream));
   if (ev) HIP_TRY(hipEventRecord(ev[4], stream));
   return YCNR_OK;
 }
@@ -330,9 +389,11 @@ int ycnr_als_create(const ycnr_als_options *o, ycnr_als **out) {
                 sizeof(ycnr_als_options));
   if (o->dtype != YCNR_F32 && o->dtype != YCNR_F64) return fail(YCNR_ERR_INVALID, "bad dtype %d", o->dtype);
   if (o->factorsCount < 1) return fail(YCNR_ERR_INVALID, "factorsCount must be >= 1");
-  if (o->factorsCount > kMaxFactors)
-    return fail(YCNR_ERR_UNSUPPORTED, "factorsCount %d > %d is not supported by this build", o->factorsCount,
-                kMaxFactors);
+  if (o->factorsCount > (o->dtype == YCNR_F32 ? kMaxFactorsBig : kMaxFactors))
+    return fail(YCNR_ERR_UNSUPPORTED, "factorsCount %d > %d is not supported by this build for %s", o->factorsCount,
+                o->dtype == YCNR_F32 ? kMaxFactorsBig : kMaxFactors, o->dtype == YCNR_F32 ? "float32" : "float64");
+  if (o->factorsCount > kMaxFactors && o->factorsCount % 4 != 0)
+    return fail(YCNR_ERR_UNSUPPORTED, "factorsCount %d > %d must be a multiple of 4", o->factorsCount, kMaxFactors);
   if (o->totalUsersCount < 1 || o->totalItemsCount < 1 || o->totalUsersCount > 0x7fffffffLL ||
       o->totalItemsCount > 0x7fffffffLL)
     return fail(YCNR_ERR_INVALID, "totalUsersCount / totalItemsCount must be in [1, 2^31)");
@@ -454,7 +515,35 @@ int ycnr_als_set_ratings(ycnr_als *h, int side, const int64_t *rowPtr, const int
   std::vector<Unit> units;
   std::vector<SplitRow> split;
   int64_t nSlabs = 0, solved = 0;
-  build_schedule(hp.data(), rowBegin, rowEnd - rowBegin, h->opt.chunkRatings, units, split, nSlabs, solved);
+  const bool big = h->opt.factorsCount > kMaxFactors;
+  build_schedule(hp.data(), rowBegin, rowEnd - rowBegin, h->opt.chunkRatings, units, split, nSlabs, solved,
+                 big ? dual_max_ratings(h->opt) : -1);
+  std::vector<Schedule::Batch> batches;
+  int64_t arenaSlabs = nSlabs;
+  if (big && nSlabs > 0) {
+    // cut the split rows into batches whose slabs fit the arena; slab numbers restart per batch
+    const int64_t slabBytes = slab_elems(slab_nb(h->opt.factorsCount)) * (int64_t)sizeof(float);
+    int64_t cap = std::max<int64_t>(1, (int64_t)(kBigArenaBytes / slabBytes));
+    for (const SplitRow &sr : split) cap = std::max<int64_t>(cap, sr.nslabs);
+    Schedule::Batch cur{0, 0, 0, 0};
+    int64_t used = 0, unitPos = 0;
+    arenaSlabs = 0;
+    for (size_t r = 0; r < split.size(); ++r) {
+      if (used + split[r].nslabs > cap) {
+        batches.push_back(cur);
+        cur = Schedule::Batch{unitPos, 0, (int64_t)r, 0};
+        used = 0;
+      }
+      split[r].slab0 = (int32_t)used;
+      for (int p = 0; p < split[r].nslabs; ++p) units[unitPos + p].slab = (int32_t)(used + p);
+      used += split[r].nslabs;
+      unitPos += split[r].nslabs;
+      cur.unitCount += split[r].nslabs;
+      cur.splitCount += 1;
+      arenaSlabs = std::max(arenaSlabs, used);
+    }
+    batches.push_back(cur);
+  }
   // Optional (measured: no gain at MAL scale, 16.4 vs 16.0 ms for the item step, because the
   // chunk kernel is bound by the matrix pipe, not by the gather): order the split chunks by
   // the first column id they touch, so the waves in flight at any moment walk the same
@@ -478,6 +567,7 @@ int ycnr_als_set_ratings(ycnr_als *h, int side, const int64_t *rowPtr, const int
   S.nSplit = (int64_t)split.size();
   S.nSlabs = nSlabs;
   S.solvedRows = solved;
+  S.batches = batches;
   S.fusedRatings = 0;
   for (size_t i = (size_t)nSlabs; i < units.size(); ++i) S.fusedRatings += units[i].end - units[i].beg;
   // whole rows are sorted by descending length: rows short enough for the dual form are the
@@ -503,7 +593,7 @@ int ycnr_als_set_ratings(ycnr_als *h, int side, const int64_t *rowPtr, const int
   if (S.nSplit) {
     HIP_TRY(hipMalloc(&S.dSplit, sizeof(SplitRow) * split.size()));
     HIP_TRY(hipMemcpy(S.dSplit, split.data(), sizeof(SplitRow) * split.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipMalloc(&S.dSlabs, (size_t)nSlabs * slab_elems(slab_nb(h->opt.factorsCount)) * h->ts()));
+    HIP_TRY(hipMalloc(&S.dSlabs, (size_t)arenaSlabs * slab_elems(slab_nb(h->opt.factorsCount)) * h->ts()));
   }
   return YCNR_OK;
 }
@@ -591,7 +681,10 @@ int ycnr_als_step_async(ycnr_als *h, int side) {
       dp.first = S.dualFirst;
       dp.count = S.dualCount;
     }
-    rc = launch_step<float>(a, S.nUnits, S.nSlabs, S.nSplit, h->stream, h->ev, (h->opt.flags & YCNR_FLAG_LDS_SOLVER) != 0, dp);
+    if (h->opt.factorsCount > kMaxFactors)
+      rc = launch_step_big(a, S.batches, h->stream, h->ev, dp);
+    else
+      rc = launch_step<float>(a, S.nUnits, S.nSlabs, S.nSplit, h->stream, h->ev, (h->opt.flags & YCNR_FLAG_LDS_SOLVER) != 0, dp);
   } else {
     StepArgs<double> a{S.dUnits, S.dSplit, R.dIndx, (const double *)R.dVals, (const double *)h->factors[1 - side],
                        (const double *)h->dZeros, (double *)h->factors[side], (double *)S.dSlabs, h->dErr, lambda, h->opt.factorsCount, 0, 0};
@@ -718,7 +811,9 @@ int64_t als_calc_portion(double lambda, int k, const int32_t *alsRows, const int
   if (!alsRows || !alsIndx || !alsVals || !fixedFactors || !solvedFactors)
     return fail(YCNR_ERR_INVALID, "AlsCalcPortion: null argument");
   if (k < 1) return fail(YCNR_ERR_INVALID, "AlsCalcPortion: k < 1");
-  if (k > kMaxFactors) return fail(YCNR_ERR_UNSUPPORTED, "factorsCount %d > %d is not supported by this build", k, kMaxFactors);
+  if (k > kMaxFactors)
+    return fail(YCNR_ERR_UNSUPPORTED, "factorsCount %d > %d: use the resident trainer (ycnr_als_*) for large factor counts", k,
+                kMaxFactors);
   if (!(lambda >= 0)) return fail(YCNR_ERR_INVALID, "AlsCalcPortion: negative lambda");
   const int nRows = alsRows[0];
   if (nRows < 0) return fail(YCNR_ERR_INVALID, "AlsCalcPortion: alsRows[0] < 0");
