@@ -119,6 +119,9 @@ typedef struct ycnr_als_options {
 #define YCNR_FLAG_NO_DUAL 2
 /* options.flags: sort split chunks by the first column id they touch instead of by length */
 #define YCNR_FLAG_LOCALITY_SORT 4
+/* options.flags: keep the last 4 Gramian columns of k = 16 m + 4 on the matrix cores (padded
+ * tile column) instead of accumulating them on the VALU */
+#define YCNR_FLAG_NO_VALU_EDGE 8
 
 /* Timing / accounting of the last ycnr_als_step, measured with HIP events on the
  * handle's stream around each kernel (DESIGN.md "Measurement"). */

@@ -67,7 +67,7 @@ def test_golden_portion(als, oracle, name):
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
-@pytest.mark.parametrize("k", [1, 7, 16, 20, 33, 64, 100, 128])
+@pytest.mark.parametrize("k", [1, 7, 16, 20, 33, 36, 64, 100, 116, 128])
 def test_half_steps_all_k(als, oracle, k, dt):
     """Resident trainer, byUser then byItem, every MFMA tile count (k -> NB = ceil(k/16))."""
     users, items = 70, 50
@@ -154,7 +154,8 @@ def test_every_row_length_class(als, k):
     V = (rng.standard_normal((items, k)) / np.sqrt(k)).astype(np.float32)
     want, conds = numpy_step(0.05, k, bu, V, U)
     got = {}
-    variants = (("dual", 0), ("primal", _lib.FLAG_NO_DUAL), ("lds", _lib.FLAG_LDS_SOLVER))
+    variants = (("dual", 0), ("primal", _lib.FLAG_NO_DUAL), ("lds", _lib.FLAG_LDS_SOLVER),
+                ("noedge", _lib.FLAG_NO_DUAL | _lib.FLAG_NO_VALU_EDGE))
     if k > 128:  # 4-wave kernels: with and without the dual form for short rows; no LDS-solver variant
         variants = (("dual", 0), ("primal", _lib.FLAG_NO_DUAL))
     for name, flags in variants:
@@ -173,7 +174,7 @@ def test_every_row_length_class(als, k):
         check_rows(got[name], want, conds, np.float32)
         assert np.array_equal(got[name][130], U[130])  # the empty row
         dev.destroy()
-    for a, b in (("dual", "primal"), ("primal", "lds")):
+    for a, b in (("dual", "primal"), ("primal", "lds"), ("primal", "noedge")):
         if b not in got:
             continue
         err = row_rel_err(got[a], got[b])

@@ -232,6 +232,309 @@ struct Gram {
   }
 };
 
+// Uniform interface over the two Gramian forms, used by the kernels below:
+//   State, init, accumulate, accumulate_deep<PF>, slab_count, store_slab, add_slab, to_tiles.
+template <typename T, int NB>
+struct GramPlain {
+  using G = Gram<T, NB>;
+  using acc_t = typename G::acc_t;
+  static constexpr int NT = G::NT;
+  struct State {
+    acc_t acc[NT];
+    T bacc[NB];
+  };
+  static __host__ __device__ constexpr int slab_regs() { return NT * 4 + NB; }
+  static __device__ __forceinline__ void init(State &s) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) s.acc[t] = acc_t{T(0), T(0), T(0), T(0)};
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) s.bacc[cb] = T(0);
+  }
+  static __device__ __forceinline__ void accumulate(State &s, const int32_t *indx, const T *vals, const T *fixed,
+                                                    const T *zeros, int k, int64_t beg, int64_t end, int lane) {
+    G::accumulate(s.acc, s.bacc, indx, vals, fixed, zeros, k, beg, end, lane);
+  }
+  template <int PF>
+  static __device__ __forceinline__ void accumulate_deep(State &s, const int32_t *indx, const T *vals, const T *fixed,
+                                                         const T *zeros, int k, int64_t beg, int64_t end, int lane) {
+    G::template accumulate_deep<PF>(s.acc, s.bacc, indx, vals, fixed, zeros, k, beg, end, lane);
+  }
+  static __device__ __forceinline__ void store_slab(const State &st, T *s) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[(t * 4 + r) * 64] = st.acc[t][r];
+    }
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) s[(NT * 4 + cb) * 64] = st.bacc[cb];
+  }
+  static __device__ __forceinline__ void add_slab(State &st, const T *s) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) st.acc[t][r] += s[(t * 4 + r) * 64];
+    }
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) st.bacc[cb] += s[(NT * 4 + cb) * 64];
+  }
+  static __device__ __forceinline__ void to_tiles(State &st, acc_t (&full)[NT], T (&bfull)[NB], T *, int) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) full[t] = st.acc[t];
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) bfull[cb] = st.bacc[cb];
+  }
+};
+
+// Gramian for k = 16 (NB-1) + 4 (k = 20, 36, ..., 100, 116), float32: the last 4 columns would
+// cost a whole tile column on the matrix cores (7 of 28 tiles at k = 100 for 4 of 100 columns),
+// so they are accumulated on the VALU instead, in the shadow of the MFMAs:
+//   edge[cb][j]  += y[16 cb + c] * e[j]     e[j] = the rating's factors 16 (NB-1) + j, one
+//   corner[j]    += e[c] * e[j]   (c < 4)   float4 load per lane group
+//   be[j]        += e[j] * r
+// 21 MFMAs + 34 v_fma per 4 ratings instead of 28 + 7.  to_tiles rebuilds the NB-block tile set
+// the solvers expect through a 1.6 KB LDS image.
+template <int NB>
+struct GramEdge {
+  using Tr = MfmaTraits<float>;
+  using acc_t = typename Tr::acc_t;
+  static constexpr int NBM = NB - 1;
+  static constexpr int NTM = tile_count(NBM);
+  static constexpr int NT = tile_count(NB);
+  struct State {
+    acc_t acc[NTM];
+    float bacc[NBM];
+    float edge[NBM][4];
+    float corner[4];
+    float be[4];
+  };
+  struct Ops {
+    float y[NBM];
+    float4 e;
+  };
+  static __host__ __device__ constexpr int slab_regs() { return NTM * 4 + NBM + NBM * 4 + 8; }
+  static __device__ __forceinline__ void init(State &s) {
+#pragma unroll
+    for (int t = 0; t < NTM; ++t) s.acc[t] = acc_t{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int cb = 0; cb < NBM; ++cb) {
+      s.bacc[cb] = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s.edge[cb][j] = 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s.corner[j] = s.be[j] = 0.0f;
+  }
+  static __device__ __forceinline__ void load(Ops &o, const float *__restrict__ row, int c) {
+#pragma unroll
+    for (int cb = 0; cb < NBM; ++cb) o.y[cb] = row[cb * 16 + c];
+    o.e = *reinterpret_cast<const float4 *>(row + 16 * NBM);
+  }
+  static __device__ __forceinline__ void step(State &s, const Ops &o, float r, int c) {
+    const float e[4] = {o.e.x, o.e.y, o.e.z, o.e.w};
+    const float ec = c == 0 ? e[0] : (c == 1 ? e[1] : (c == 2 ? e[2] : e[3]));
+#pragma unroll
+    for (int cb = 0; cb < NBM; ++cb) {
+      s.bacc[cb] = fmaf(o.y[cb], r, s.bacc[cb]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s.edge[cb][j] = fmaf(o.y[cb], e[j], s.edge[cb][j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      s.be[j] = fmaf(e[j], r, s.be[j]);
+      s.corner[j] = fmaf(ec, e[j], s.corner[j]);
+    }
+#pragma unroll
+    for (int bi = 0; bi < NBM; ++bi) {
+#pragma unroll
+      for (int bj = bi; bj < NBM; ++bj)
+        s.acc[tile_index(bi, bj, NBM)] = Tr::mma(o.y[bi], o.y[bj], s.acc[tile_index(bi, bj, NBM)]);
+    }
+  }
+  static __device__ __forceinline__ void accumulate(State &st, const int32_t *__restrict__ indx,
+                                                    const float *__restrict__ vals, const float *__restrict__ fixed,
+                                                    const float *__restrict__ zeros, int k, int64_t beg, int64_t end,
+                                                    int lane) {
+    const int g = lane >> 4, c = lane & 15;
+    const int64_t nsteps = (end - beg + 3) >> 2;
+    const int64_t last = end - 1;
+    int64_t n = beg + g;
+    int64_t nc = n < end ? n : last;
+    const float *row0 = n < end ? fixed + (int64_t)indx[nc] * k : zeros;
+    float rv = vals[nc];
+    float r0 = n < end ? rv : 0.0f;
+    n += 4;
+    nc = n < end ? n : last;
+    int32_t id1 = indx[nc];
+    rv = vals[nc];
+    float r1 = n < end ? rv : 0.0f;
+    bool v1 = n < end;
+    Ops A, B;
+    load(A, row0, c);
+    for (int64_t i = 0; i < nsteps; ++i) {
+      const float *row1 = v1 ? fixed + (int64_t)id1 * k : zeros;
+      load(B, row1, c);
+      const float ra = r0;
+      r0 = r1;
+      n += 4;
+      nc = n < end ? n : last;
+      v1 = n < end;
+      id1 = indx[nc];
+      rv = vals[nc];
+      r1 = v1 ? rv : 0.0f;
+      step(st, A, ra, c);
+      A = B;
+    }
+  }
+  template <int PF>
+  static __device__ __forceinline__ void accumulate_deep(State &st, const int32_t *__restrict__ indx,
+                                                         const float *__restrict__ vals,
+                                                         const float *__restrict__ fixed,
+                                                         const float *__restrict__ zeros, int k, int64_t beg,
+                                                         int64_t end, int lane) {
+    static_assert(16 % (PF + 1) == 0, "ring size must divide the 16 steps of a 64-rating block");
+    const int g = lane >> 4, c = lane & 15;
+    const int64_t n = end - beg;
+    const int64_t nblk = (n + 63) >> 6;
+    auto fetch_blk = [&](int64_t b, int32_t &id, float &r) {
+      const int64_t q = b * 64 + lane;
+      const bool v = q < n;
+      const int64_t qc = beg + (v ? q : n - 1);
+      const int32_t i = indx[qc];
+      const float t = vals[qc];
+      id = v ? i : -1;
+      r = v ? t : 0.0f;
+    };
+    auto row_of = [&](int32_t id) { return id >= 0 ? fixed + (int64_t)id * k : zeros; };
+    int32_t idc, idn;
+    float rc, rn;
+    fetch_blk(0, idc, rc);
+    fetch_blk(1, idn, rn);
+    Ops y[PF + 1];
+#pragma unroll
+    for (int t = 0; t < PF; ++t) load(y[t], row_of(__shfl(idc, 4 * t + g, 64)), c);
+    const int64_t ngrp = nblk * (16 / (PF + 1));
+#pragma unroll 1
+    for (int64_t grp = 0; grp < ngrp; ++grp) {
+      const int sbase = (int)(grp % (16 / (PF + 1))) * (PF + 1);
+      if (sbase == 0 && grp != 0) {
+        idc = idn;
+        rc = rn;
+        fetch_blk(grp / (16 / (PF + 1)) + 1, idn, rn);
+      }
+#pragma unroll
+      for (int u = 0; u <= PF; ++u) {
+        const int t = sbase + u + PF;
+        const int32_t src = t < 16 ? idc : idn;
+        const int32_t id = __shfl(src, (4 * t + g) & 63, 64);
+        load(y[(u + PF) % (PF + 1)], row_of(id), c);
+        const float r = __shfl(rc, 4 * (sbase + u) + g, 64);
+        step(st, y[u % (PF + 1)], r, c);
+      }
+    }
+  }
+  // slab order: MFMA tiles, bacc, edge, corner, be -- one register per 64-lane row
+  static __device__ __forceinline__ void store_slab(const State &st, float *s) {
+#pragma unroll
+    for (int t = 0; t < NTM; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[(t * 4 + r) * 64] = st.acc[t][r];
+    }
+    float *p = s + NTM * 4 * 64;
+#pragma unroll
+    for (int cb = 0; cb < NBM; ++cb) p[cb * 64] = st.bacc[cb];
+    p += NBM * 64;
+#pragma unroll
+    for (int cb = 0; cb < NBM; ++cb) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) p[(cb * 4 + j) * 64] = st.edge[cb][j];
+    }
+    p += NBM * 4 * 64;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      p[j * 64] = st.corner[j];
+      p[(4 + j) * 64] = st.be[j];
+    }
+  }
+  static __device__ __forceinline__ void add_slab(State &st, const float *s) {
+#pragma unroll
+    for (int t = 0; t < NTM; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) st.acc[t][r] += s[(t * 4 + r) * 64];
+    }
+    const float *p = s + NTM * 4 * 64;
+#pragma unroll
+    for (int cb = 0; cb < NBM; ++cb) st.bacc[cb] += p[cb * 64];
+    p += NBM * 64;
+#pragma unroll
+    for (int cb = 0; cb < NBM; ++cb) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) st.edge[cb][j] += p[(cb * 4 + j) * 64];
+    }
+    p += NBM * 4 * 64;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      st.corner[j] += p[j * 64];
+      st.be[j] += p[(4 + j) * 64];
+    }
+  }
+  // Rebuild the NB-block upper tile set (C/D layout) and the rhs partials from the state.
+  // S: at least (16 NBM + 4) * 16 bytes of LDS, free for reuse after the call.
+  static __device__ __forceinline__ void to_tiles(State &st, acc_t (&full)[NT], float (&bfull)[NB], float *S, int lane) {
+    const int g = lane >> 4, c = lane & 15;
+    float *E = S, *Cm = S + 16 * NBM * 4;
+    auto gsum = [](float v) {
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      return v;
+    };
+#pragma unroll
+    for (int cb = 0; cb < NBM; ++cb) {
+      const float4 v = float4{gsum(st.edge[cb][0]), gsum(st.edge[cb][1]), gsum(st.edge[cb][2]), gsum(st.edge[cb][3])};
+      if (g == 0) *reinterpret_cast<float4 *>(E + (16 * cb + c) * 4) = v;
+    }
+    {
+      const float4 v = float4{gsum(st.corner[0]), gsum(st.corner[1]), gsum(st.corner[2]), gsum(st.corner[3])};
+      if (g == 0 && c < 4) *reinterpret_cast<float4 *>(Cm + c * 4) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int bi = 0; bi < NBM; ++bi) {
+#pragma unroll
+      for (int bj = bi; bj < NBM; ++bj) full[tile_index(bi, bj, NB)] = st.acc[tile_index(bi, bj, NBM)];
+      acc_t v;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float x = E[(16 * bi + 4 * g + t) * 4 + (c & 3)];
+        v[t] = c < 4 ? x : 0.0f;
+      }
+      full[tile_index(bi, NBM, NB)] = v;
+    }
+    {
+      acc_t v;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float x = Cm[t * 4 + (c & 3)];
+        v[t] = (g == 0 && c < 4) ? x : 0.0f;
+      }
+      full[tile_index(NBM, NBM, NB)] = v;
+    }
+#pragma unroll
+    for (int cb = 0; cb < NBM; ++cb) bfull[cb] = st.bacc[cb];
+    // be is uniform over c inside a lane group and still partial over groups: the solver sums groups
+    bfull[NBM] = c == 0 ? st.be[0] : (c == 1 ? st.be[1] : (c == 2 ? st.be[2] : (c == 3 ? st.be[3] : 0.0f)));
+    __syncthreads();
+  }
+};
+
+template <typename T, int NB, bool EDGE>
+struct GramSel {
+  using type = GramPlain<T, NB>;
+};
+template <int NB>
+struct GramSel<float, NB, true> {
+  using type = GramEdge<NB>;
+};
+
 // ---------------------------------------------------------------------------------------
 // Solve (A + lam I) x = b for one row, A given as upper MFMA tiles in registers.
 // Version 1: dump to LDS, right-looking Cholesky A = U^T U by one wave with b carried as
@@ -566,50 +869,37 @@ struct StepArgs {
 
 // Kernel 1a: one wave per SPLIT unit -- gather + Gramian + rhs of a chunk of a heavy row,
 // written as a partial slab.  Kept apart from the fused kernel so that its register
-// allocation (accumulators + two operand sets) is not inflated by the solve.
-template <typename T, int NB>
+// allocation (accumulators + operand ring) is not inflated by the solve.
+template <typename T, int NB, bool EDGE>
 __global__ __launch_bounds__(64, YCNR_SLAB_WAVES_PER_SIMD) void als_gram_slab_kernel(StepArgs<T> a) {
-  using G = Gram<T, NB>;
-  using acc_t = typename G::acc_t;
+  using G = typename GramSel<T, NB, EDGE>::type;
   const int lane = threadIdx.x;
   const Unit u = a.units[blockIdx.x];
-  acc_t acc[G::NT];
-  T bacc[NB];
-#pragma unroll
-  for (int t = 0; t < G::NT; ++t) acc[t] = acc_t{T(0), T(0), T(0), T(0)};
-#pragma unroll
-  for (int cb = 0; cb < NB; ++cb) bacc[cb] = T(0);
+  typename G::State st;
+  G::init(st);
 #if YCNR_SLAB_PREFETCH > 0
-  G::template accumulate_deep<YCNR_SLAB_PREFETCH>(acc, bacc, a.indx, a.vals, a.fixed, a.zeros, a.k, u.beg, u.end, lane);
+  G::template accumulate_deep<YCNR_SLAB_PREFETCH>(st, a.indx, a.vals, a.fixed, a.zeros, a.k, u.beg, u.end, lane);
 #else
-  G::accumulate(acc, bacc, a.indx, a.vals, a.fixed, a.zeros, a.k, u.beg, u.end, lane);
+  G::accumulate(st, a.indx, a.vals, a.fixed, a.zeros, a.k, u.beg, u.end, lane);
 #endif
-  T *s = a.slabs + (int64_t)u.slab * slab_elems(NB) + lane;
-#pragma unroll
-  for (int t = 0; t < G::NT; ++t) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) s[(t * 4 + r) * 64] = acc[t][r];
-  }
-#pragma unroll
-  for (int cb = 0; cb < NB; ++cb) s[(G::NT * 4 + cb) * 64] = bacc[cb];
+  G::store_slab(st, a.slabs + (int64_t)u.slab * (G::slab_regs() * 64) + lane);
 }
 
 // Kernel 1b (dominant on the user side): one wave per row that fits one unit -- gather +
 // Gramian + rhs, then the row's solve, all in registers.
-template <typename T, int NB, bool LDS_SOLVER>
+template <typename T, int NB, bool LDS_SOLVER, bool EDGE>
 __global__ __launch_bounds__(64, YCNR_FUSED_WAVES_PER_SIMD) void als_gram_solve_kernel(StepArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  using G = Gram<T, NB>;
+  using G = typename GramSel<T, NB, EDGE>::type;
   using acc_t = typename G::acc_t;
   const int lane = threadIdx.x;
   const Unit u = a.units[a.firstFused + blockIdx.x];
+  typename G::State st;
+  G::init(st);
+  G::accumulate(st, a.indx, a.vals, a.fixed, a.zeros, a.k, u.beg, u.end, lane);
   acc_t acc[G::NT];
   T bacc[NB];
-#pragma unroll
-  for (int t = 0; t < G::NT; ++t) acc[t] = acc_t{T(0), T(0), T(0), T(0)};
-#pragma unroll
-  for (int cb = 0; cb < NB; ++cb) bacc[cb] = T(0);
-  G::accumulate(acc, bacc, a.indx, a.vals, a.fixed, a.zeros, a.k, u.beg, u.end, lane);
+  G::to_tiles(st, acc, bacc, reinterpret_cast<T *>(smem), lane);
   // lambda.diagonal(_lambda * _n): the product is formed in double and rounded to T once
   const T lam = (T)(a.lambda * (double)(u.end - u.beg));
   SolverFor<T, NB, LDS_SOLVER>::type::run(acc, bacc, reinterpret_cast<T *>(smem), a.k, lam,
@@ -712,29 +1002,19 @@ __global__ __launch_bounds__(64) void als_dual_solve_kernel(StepArgs<float> a) {
 }
 
 // Kernel 2: one wave per split row -- sum its slabs in slab order, then solve.
-template <typename T, int NB, bool LDS_SOLVER>
+template <typename T, int NB, bool LDS_SOLVER, bool EDGE>
 __global__ __launch_bounds__(64) void als_reduce_solve_kernel(StepArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  using G = Gram<T, NB>;
+  using G = typename GramSel<T, NB, EDGE>::type;
   using acc_t = typename G::acc_t;
   const int lane = threadIdx.x;
   const SplitRow sr = a.split[blockIdx.x];
+  typename G::State st;
+  G::init(st);
+  for (int sl = 0; sl < sr.nslabs; ++sl) G::add_slab(st, a.slabs + (int64_t)(sr.slab0 + sl) * (G::slab_regs() * 64) + lane);
   acc_t acc[G::NT];
   T bacc[NB];
-#pragma unroll
-  for (int t = 0; t < G::NT; ++t) acc[t] = acc_t{T(0), T(0), T(0), T(0)};
-#pragma unroll
-  for (int cb = 0; cb < NB; ++cb) bacc[cb] = T(0);
-  for (int sl = 0; sl < sr.nslabs; ++sl) {
-    const T *s = a.slabs + (int64_t)(sr.slab0 + sl) * slab_elems(NB) + lane;
-#pragma unroll
-    for (int t = 0; t < G::NT; ++t) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[t][r] += s[(t * 4 + r) * 64];
-    }
-#pragma unroll
-    for (int cb = 0; cb < NB; ++cb) bacc[cb] += s[(G::NT * 4 + cb) * 64];
-  }
+  G::to_tiles(st, acc, bacc, reinterpret_cast<T *>(smem), lane);
   const T lam = (T)(a.lambda * (double)sr.n);
   SolverFor<T, NB, LDS_SOLVER>::type::run(acc, bacc, reinterpret_cast<T *>(smem), a.k, lam,
                                           a.solved + (int64_t)sr.row * a.k, sr.row, a.err, lane);

@@ -15,6 +15,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 using namespace ycnr;
@@ -170,13 +171,13 @@ int launch_duals<float>(const StepArgs<float> &args, const DualPlan &dp, hipStre
   return rc;
 }
 
-template <typename T, int NB, bool LDS_SOLVER>
-int launch_nb(StepArgs<T> args, int64_t nUnits, int64_t nSplitUnits, int64_t nSplit, hipStream_t stream,
-              hipEvent_t *ev /* 5 events or null */, const DualPlan &dp) {
+template <typename T, int NB, bool LDS_SOLVER, bool EDGE>
+int launch_nbe(StepArgs<T> args, int64_t nUnits, int64_t nSplitUnits, int64_t nSplit, hipStream_t stream,
+               hipEvent_t *ev /* 5 events or null */, const DualPlan &dp) {
   const size_t lds = SolverFor<T, NB, LDS_SOLVER>::type::lds_bytes();
-  auto k0 = als_gram_slab_kernel<T, NB>;
-  auto k1 = als_gram_solve_kernel<T, NB, LDS_SOLVER>;
-  auto k2 = als_reduce_solve_kernel<T, NB, LDS_SOLVER>;
+  auto k0 = als_gram_slab_kernel<T, NB, EDGE>;
+  auto k1 = als_gram_solve_kernel<T, NB, LDS_SOLVER, EDGE>;
+  auto k2 = als_reduce_solve_kernel<T, NB, LDS_SOLVER, EDGE>;
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k1),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k2),
@@ -205,6 +206,16 @@ int launch_nb(StepArgs<T> args, int64_t nUnits, int64_t nSplitUnits, int64_t nSp
   }
   if (ev) HIP_TRY(hipEventRecord(ev[4], stream));
   return YCNR_OK;
+}
+
+// the VALU-edge Gramian exists for float32 and k = 16 (NB-1) + 4 only
+template <typename T, int NB, bool LDS_SOLVER>
+int launch_nb(const StepArgs<T> &args, int64_t nUnits, int64_t nSplitUnits, int64_t nSplit, hipStream_t stream, hipEvent_t *ev,
+              const DualPlan &dp, bool edge) {
+  if constexpr (std::is_same<T, float>::value && NB >= 2) {
+    if (edge) return launch_nbe<T, NB, LDS_SOLVER, true>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp);
+  }
+  return launch_nbe<T, NB, LDS_SOLVER, false>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp);
 }
 
 template <int NB>
@@ -256,27 +267,27 @@ int launch_step_big(const StepArgs<float> &args, const std::vector<Schedule::Bat
 
 template <typename T>
 int launch_step(const StepArgs<T> &args, int64_t nUnits, int64_t nSplitUnits, int64_t nSplit, hipStream_t stream,
-                hipEvent_t *ev, bool ldsSolver = false, const DualPlan &dp = DualPlan()) {
+                hipEvent_t *ev, bool ldsSolver = false, const DualPlan &dp = DualPlan(), bool edge = false) {
   if (nUnits > 0x7fffffffLL || nSplit > 0x7fffffffLL)
     return fail(YCNR_ERR_UNSUPPORTED, "too many work units for one launch (%lld)", (long long)nUnits);
   const int nb = (args.k + 15) / 16;
   switch (nb) {
-    case 1: return ldsSolver ? launch_nb<T, 1, true>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp)
-                             : launch_nb<T, 1, false>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp);
-    case 2: return ldsSolver ? launch_nb<T, 2, true>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp)
-                             : launch_nb<T, 2, false>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp);
-    case 3: return ldsSolver ? launch_nb<T, 3, true>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp)
-                             : launch_nb<T, 3, false>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp);
-    case 4: return ldsSolver ? launch_nb<T, 4, true>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp)
-                             : launch_nb<T, 4, false>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp);
-    case 5: return ldsSolver ? launch_nb<T, 5, true>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp)
-                             : launch_nb<T, 5, false>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp);
-    case 6: return ldsSolver ? launch_nb<T, 6, true>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp)
-                             : launch_nb<T, 6, false>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp);
-    case 7: return ldsSolver ? launch_nb<T, 7, true>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp)
-                             : launch_nb<T, 7, false>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp);
-    case 8: return ldsSolver ? launch_nb<T, 8, true>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp)
-                             : launch_nb<T, 8, false>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp);
+    case 1: return ldsSolver ? launch_nb<T, 1, true>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp, edge)
+                             : launch_nb<T, 1, false>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp, edge);
+    case 2: return ldsSolver ? launch_nb<T, 2, true>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp, edge)
+                             : launch_nb<T, 2, false>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp, edge);
+    case 3: return ldsSolver ? launch_nb<T, 3, true>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp, edge)
+                             : launch_nb<T, 3, false>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp, edge);
+    case 4: return ldsSolver ? launch_nb<T, 4, true>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp, edge)
+                             : launch_nb<T, 4, false>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp, edge);
+    case 5: return ldsSolver ? launch_nb<T, 5, true>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp, edge)
+                             : launch_nb<T, 5, false>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp, edge);
+    case 6: return ldsSolver ? launch_nb<T, 6, true>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp, edge)
+                             : launch_nb<T, 6, false>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp, edge);
+    case 7: return ldsSolver ? launch_nb<T, 7, true>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp, edge)
+                             : launch_nb<T, 7, false>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp, edge);
+    case 8: return ldsSolver ? launch_nb<T, 8, true>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp, edge)
+                             : launch_nb<T, 8, false>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp, edge);
     default:
       return fail(YCNR_ERR_UNSUPPORTED, "factorsCount %d > %d is not supported by this build", args.k,
                   kMaxFactors);
@@ -284,6 +295,22 @@ int launch_step(const StepArgs<T> &args, int64_t nUnits, int64_t nSplitUnits, in
 }
 
 int slab_nb(int k) { return (k + 15) / 16; }
+
+// float32, k = 16 m + 4 (m >= 1), k <= 128: the last 4 columns of the Gramian go to the VALU
+bool use_valu_edge(const ycnr_als_options &o) {
+  return o.dtype == YCNR_F32 && !(o.flags & YCNR_FLAG_NO_VALU_EDGE) && o.factorsCount >= 20 && o.factorsCount <= kMaxFactors &&
+         o.factorsCount % 16 == 4;
+}
+
+// registers (x 64 lanes x sizeof(T)) one split unit writes
+int64_t slab_regs(const ycnr_als_options &o) {
+  const int nb = slab_nb(o.factorsCount);
+  if (use_valu_edge(o)) {
+    const int nbm = nb - 1;
+    return tile_count(nbm) * 4 + nbm + nbm * 4 + 8;
+  }
+  return tile_count(nb) * 4 + nb;
+}
 
 // Longest row solved in dual form (0 = never): float32 MFMA solver only, rows of 16-byte
 // multiples, and strictly fewer 16-blocks than the primal form would use.
@@ -593,7 +620,7 @@ int ycnr_als_set_ratings(ycnr_als *h, int side, const int64_t *rowPtr, const int
   if (S.nSplit) {
     HIP_TRY(hipMalloc(&S.dSplit, sizeof(SplitRow) * split.size()));
     HIP_TRY(hipMemcpy(S.dSplit, split.data(), sizeof(SplitRow) * split.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipMalloc(&S.dSlabs, (size_t)arenaSlabs * slab_elems(slab_nb(h->opt.factorsCount)) * h->ts()));
+    HIP_TRY(hipMalloc(&S.dSlabs, (size_t)arenaSlabs * slab_regs(h->opt) * 64 * h->ts()));
   }
   return YCNR_OK;
 }
@@ -684,7 +711,8 @@ int ycnr_als_step_async(ycnr_als *h, int side) {
     if (h->opt.factorsCount > kMaxFactors)
       rc = launch_step_big(a, S.batches, h->stream, h->ev, dp);
     else
-      rc = launch_step<float>(a, S.nUnits, S.nSlabs, S.nSplit, h->stream, h->ev, (h->opt.flags & YCNR_FLAG_LDS_SOLVER) != 0, dp);
+      rc = launch_step<float>(a, S.nUnits, S.nSlabs, S.nSplit, h->stream, h->ev, (h->opt.flags & YCNR_FLAG_LDS_SOLVER) != 0, dp,
+                              use_valu_edge(h->opt));
   } else {
     StepArgs<double> a{S.dUnits, S.dSplit, R.dIndx, (const double *)R.dVals, (const double *)h->factors[1 - side],
                        (const double *)h->dZeros, (double *)h->factors[side], (double *)S.dSlabs, h->dErr, lambda, h->opt.factorsCount, 0, 0};
