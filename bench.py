@@ -64,6 +64,8 @@ def main():
     ap.add_argument("--double", action="store_true", help="useDoublePrecision")
     ap.add_argument("--chunk", type=int, default=0, help="ratings per split work unit (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--debug-mod-idx", type=int, default=0,
+                    help="timing experiment only: fold all column ids into [0, N) so every gather hits L1/L2")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the baseline sample")
     args = ap.parse_args()
 
@@ -92,6 +94,9 @@ def main():
     by_user, by_item = synth_ratings(users, items, nnz_target, max_rating=max_rating, seed=20260004, device=dev,
                                      dtype=tdt, degree_sigma=sigma, zipf_a=zipf_a)
     nnz = by_user.nnz
+    if args.debug_mod_idx > 0:
+        by_user.indx %= args.debug_mod_idx
+        by_item.indx %= args.debug_mod_idx
     torch.cuda.synchronize()
     t_gen = time.time() - t0
     # in-sample RMSE set: every 10th rating of each... keep it simple: a 10 % Bernoulli sample

@@ -122,6 +122,9 @@ typedef struct ycnr_als_options {
 /* options.flags: keep the last 4 Gramian columns of k = 16 m + 4 on the matrix cores (padded
  * tile column) instead of accumulating them on the VALU */
 #define YCNR_FLAG_NO_VALU_EDGE 8
+/* options.flags: keep the chunk Gramian on v_mfma_f32_16x16x4_f32 instead of the exact
+ * 3-way bf16 split on the bf16 matrix pipe */
+#define YCNR_FLAG_NO_BF16X6 16
 
 /* Timing / accounting of the last ycnr_als_step, measured with HIP events on the
  * handle's stream around each kernel (DESIGN.md "Measurement"). */

@@ -30,6 +30,10 @@
 #ifndef YCNR_FUSED_WAVES_PER_SIMD
 #define YCNR_FUSED_WAVES_PER_SIMD 2
 #endif
+// Gather prefetch depth (4-rating steps) of the fused kernel's Gramian loop; 1 = shallow loop.
+#ifndef YCNR_FUSED_PREFETCH
+#define YCNR_FUSED_PREFETCH 2
+#endif
 
 // How many 4-rating steps ahead the Gramian-only kernel requests its gathered operands.
 // 0 selects the shallow (one step ahead) loop.
@@ -202,7 +206,10 @@ struct Gram {
       id = v ? i : -1;  // -1: past the end of the unit -> the zero row
       r = v ? t : T(0);
     };
-    auto row_of = [&](int32_t id) { return id >= 0 ? fixed + (int64_t)id * k : zeros; };
+    auto row_of = [&](int32_t id) {  // select, not branch: the product is formed for the clamped id
+      const T *base = fixed + (int64_t)(id < 0 ? 0 : id) * k;
+      return id >= 0 ? base : zeros;
+    };
     int32_t idc, idn;
     T rc, rn;
     fetch_blk(0, idc, rc);
@@ -258,6 +265,11 @@ struct GramPlain {
   static __device__ __forceinline__ void accumulate_deep(State &s, const int32_t *indx, const T *vals, const T *fixed,
                                                          const T *zeros, int k, int64_t beg, int64_t end, int lane) {
     G::template accumulate_deep<PF>(s.acc, s.bacc, indx, vals, fixed, zeros, k, beg, end, lane);
+  }
+  template <int PF>
+  static __device__ __forceinline__ void accumulate_ring(State &s, const int32_t *indx, const T *vals, const T *fixed,
+                                                         const T *zeros, int k, int64_t beg, int64_t end, int lane) {
+    G::accumulate(s.acc, s.bacc, indx, vals, fixed, zeros, k, beg, end, lane);  // plain form: one step ahead
   }
   static __device__ __forceinline__ void store_slab(const State &st, T *s) {
 #pragma unroll
@@ -385,6 +397,53 @@ struct GramEdge {
       A = B;
     }
   }
+  // Like accumulate, with the operands of step s + PF requested while step s runs (ring of
+  // PF + 1 register sets, loop unrolled by PF + 1; at most PF zero steps are added at the end).
+  // Column ids are loaded one step before their operands are requested.
+  template <int PF>
+  static __device__ __forceinline__ void accumulate_ring(State &st, const int32_t *__restrict__ indx,
+                                                         const float *__restrict__ vals,
+                                                         const float *__restrict__ fixed,
+                                                         const float *__restrict__ zeros, int k, int64_t beg,
+                                                         int64_t end, int lane) {
+    const int g = lane >> 4, c = lane & 15;
+    const int64_t nsteps = (end - beg + 3) >> 2;
+    const int64_t last = end - 1;
+    auto fetch = [&](int64_t step, int32_t &id, float &r) {  // id < 0: past the end -> zero row
+      const int64_t n = beg + (step << 2) + g;
+      const bool v = n < end;
+      const int64_t nc = v ? n : last;
+      const int32_t i = indx[nc];
+      const float t = vals[nc];
+      id = v ? i : -1;
+      r = v ? t : 0.0f;
+    };
+    auto row_of = [&](int32_t id) {  // select, not branch: the product is formed for the clamped id
+      const float *base = fixed + (int64_t)(id < 0 ? 0 : id) * k;
+      return id >= 0 ? base : zeros;
+    };
+    Ops y[PF + 1];
+    float rr[PF + 1];
+    int32_t idn;
+    float rn;
+#pragma unroll
+    for (int t = 0; t < PF; ++t) {
+      int32_t id;
+      fetch(t, id, rr[t]);
+      load(y[t], row_of(id), c);
+    }
+    fetch(PF, idn, rn);
+    for (int64_t i = 0; i < nsteps; i += PF + 1) {
+#pragma unroll
+      for (int u = 0; u <= PF; ++u) {
+        const int slot = (u + PF) % (PF + 1);
+        load(y[slot], row_of(idn), c);  // operands of step i + u + PF
+        rr[slot] = rn;
+        fetch(i + u + PF + 1, idn, rn);
+        step(st, y[u], rr[u], c);
+      }
+    }
+  }
   template <int PF>
   static __device__ __forceinline__ void accumulate_deep(State &st, const int32_t *__restrict__ indx,
                                                          const float *__restrict__ vals,
@@ -404,7 +463,10 @@ struct GramEdge {
       id = v ? i : -1;
       r = v ? t : 0.0f;
     };
-    auto row_of = [&](int32_t id) { return id >= 0 ? fixed + (int64_t)id * k : zeros; };
+    auto row_of = [&](int32_t id) {  // select, not branch: the product is formed for the clamped id
+      const float *base = fixed + (int64_t)(id < 0 ? 0 : id) * k;
+      return id >= 0 ? base : zeros;
+    };
     int32_t idc, idn;
     float rc, rn;
     fetch_blk(0, idc, rc);
@@ -865,6 +927,7 @@ struct StepArgs {
   int32_t k;
   int32_t firstFused;  // units[0 .. firstFused) are split chunks, the rest whole rows
   int32_t firstDual;   // first unit of the dual-form launch in flight
+  uint32_t fixedBytes; // size of the fixed matrix when it is below 4 GB (buffer loads), else 0
 };
 
 // Kernel 1a: one wave per SPLIT unit -- gather + Gramian + rhs of a chunk of a heavy row,
@@ -885,6 +948,147 @@ __global__ __launch_bounds__(64, YCNR_SLAB_WAVES_PER_SIMD) void als_gram_slab_ke
   G::store_slab(st, a.slabs + (int64_t)u.slab * (G::slab_regs() * 64) + lane);
 }
 
+// Kernel 1a': the chunk Gramian on the bf16 matrix cores with float32-equivalent products.
+//
+// Measured on MI355X: v_mfma_f32_16x16x4_f32 does not overlap with VALU work of the same
+// SIMD (step time fits 35 cycles per MFMA + 4.1 per other instruction, additively), i.e.
+// the float32 "matrix" rate is the vector ALU's.  The bf16 matrix pipe is separate and 16x
+// faster, so each gathered float is split EXACTLY into three bf16 terms by truncation,
+//     y = b1 + b2 + b3,   b1 = top 8 mantissa bits, b2 = next 8, b3 = last 8,
+// and y_i * y_j is accumulated as the six products b1b1 + b1b2 + b2b1 + b1b3 + b3b1 + b2b2
+// (each exact in the float32 accumulator; the dropped b2b3 + b3b2 + b3b3 are <= 2^-23 of the
+// product).  The split costs ~6.5 VALU ops per value and runs beside the MFMAs.
+// v_mfma_f32_16x16x32_bf16 contracts over 32 ratings: lane (g, c) holds, for column
+// 16 cb + c, the values of ratings 8g .. 8g+7 -- again the same registers are the A operand of
+// tile row cb and the B operand of tile column cb, and the C/D layout equals the float32
+// MFMA's, so the slab format and everything downstream are unchanged.  Gathered rows are read
+// with buffer loads: out-of-range offsets (ratings past the unit's end, padded columns)
+// return 0 in hardware, no zero row and no selects.  Needs the fixed matrix < 2 GB.
+template <int NB>
+__global__ __launch_bounds__(64, 1) void als_gram_slab_x6_kernel(StepArgs<float> a) {
+  using Tr = MfmaTraits<float>;
+  using acc_t = typename Tr::acc_t;
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  constexpr int NT = tile_count(NB);
+  constexpr unsigned OOB = 0x80000000u;  // >= num_records (matrix < 2 GB) and cannot wrap when the block offset is added
+  const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+  const Unit u = a.units[blockIdx.x];
+  const int k = a.k;
+  const unsigned rowBytes = (unsigned)k * 4u;
+  const bool lastok = (NB - 1) * 16 + c < k;
+  __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc((void *)a.fixed, 0, (int)a.fixedBytes, 0x00020000);
+  acc_t acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = acc_t{0.0f, 0.0f, 0.0f, 0.0f};
+  float bacc[NB];
+#pragma unroll
+  for (int cb = 0; cb < NB; ++cb) bacc[cb] = 0.0f;
+  const int64_t n = u.end - u.beg;
+  const int64_t nsteps = (n + 31) >> 5;
+  // per step this lane owns ratings 32 s + 8 g + j, j = 0..7
+  // Two 16-byte loads each for the 8 column ids and the 8 ratings (the arrays carry 64 bytes of
+  // slack, so the vector loads of the last lanes stay inside the allocation).  Keeping the
+  // count of loads in flight below the 6-bit vmcnt range matters: with 16 scalar loads here
+  // (72 in flight together with the 56 gathers) the right-hand side came out wrong now and then.
+  auto fetch = [&](int64_t s, unsigned (&off)[8], float (&r)[8]) {
+    const int64_t q0 = (s << 5) + 8 * g;
+    const int64_t qb = q0 < n ? q0 : 0;  // lanes wholly past the end read the first ratings, masked below
+    const int4 i0 = *reinterpret_cast<const int4 *>(a.indx + u.beg + qb);
+    const int4 i1 = *reinterpret_cast<const int4 *>(a.indx + u.beg + qb + 4);
+    const float4 v0 = *reinterpret_cast<const float4 *>(a.vals + u.beg + qb);
+    const float4 v1 = *reinterpret_cast<const float4 *>(a.vals + u.beg + qb + 4);
+    const int32_t ids[8] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
+    const float vs[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bool v = q0 + j < n;
+      off[j] = v ? (unsigned)ids[j] * rowBytes + (unsigned)c * 4u : OOB;
+      r[j] = v ? vs[j] : 0.0f;
+    }
+  };
+  auto gather = [&](float (&raw)[NB][8], const unsigned (&off)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+      for (int cb = 0; cb < NB - 1; ++cb) raw[cb][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd, off[j], cb * 64, 0));
+      raw[NB - 1][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd, lastok ? off[j] : OOB, (NB - 1) * 64, 0));
+    }
+  };
+  unsigned offA[8], offB[8];
+  float rA[8], rB[8];
+  float rawA[NB][8], rawB[NB][8];
+  fetch(0, offA, rA);
+  gather(rawA, offA);
+  fetch(1, offB, rB);
+  for (int64_t s = 0; s < nsteps; ++s) {
+    gather(rawB, offB);  // operands of step s + 1 (all out of range past the end)
+    float rC[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) rC[j] = rB[j];
+    fetch(s + 2, offB, rB);
+    // b += y * r on the VALU, from the unsplit values
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bacc[cb] = fmaf(rawA[cb][j], rA[j], bacc[cb]);
+    }
+    // exact 3-way bf16 split of every value, packed in k order (pairs j, j+1 per register)
+    u32x4 p1[NB], p2[NB], p3[NB];
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) {
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const float x0 = rawA[cb][2 * jj], x1 = rawA[cb][2 * jj + 1];
+        const unsigned u0 = __builtin_bit_cast(unsigned, x0), u1 = __builtin_bit_cast(unsigned, x1);
+        p1[cb][jj] = __builtin_amdgcn_perm(u1, u0, 0x07060302);
+        const float s0 = x0 - __builtin_bit_cast(float, u0 & 0xFFFF0000u);
+        const float s1 = x1 - __builtin_bit_cast(float, u1 & 0xFFFF0000u);
+        const unsigned v0 = __builtin_bit_cast(unsigned, s0), v1 = __builtin_bit_cast(unsigned, s1);
+        p2[cb][jj] = __builtin_amdgcn_perm(v1, v0, 0x07060302);
+        const float t0 = s0 - __builtin_bit_cast(float, v0 & 0xFFFF0000u);
+        const float t1 = s1 - __builtin_bit_cast(float, v1 & 0xFFFF0000u);
+        p3[cb][jj] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, t1), __builtin_bit_cast(unsigned, t0), 0x07060302);
+      }
+    }
+#pragma unroll
+    for (int bi = 0; bi < NB; ++bi) {
+      const bf16x8 a1 = __builtin_bit_cast(bf16x8, p1[bi]), a2 = __builtin_bit_cast(bf16x8, p2[bi]),
+                   a3 = __builtin_bit_cast(bf16x8, p3[bi]);
+#pragma unroll
+      for (int bj = bi; bj < NB; ++bj) {
+        const bf16x8 b1 = __builtin_bit_cast(bf16x8, p1[bj]), b2 = __builtin_bit_cast(bf16x8, p2[bj]),
+                     b3 = __builtin_bit_cast(bf16x8, p3[bj]);
+        acc_t t = acc[tile_index(bi, bj, NB)];
+        // smallest terms first
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b2, t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b3, t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, b1, t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b2, t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b1, t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, t, 0, 0, 0);
+        acc[tile_index(bi, bj, NB)] = t;
+      }
+    }
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) rawA[cb][j] = rawB[cb][j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) rA[j] = rC[j];
+  }
+  // same slab layout as GramPlain: [tile][reg][lane], then NB rhs partials
+  float *sl = a.slabs + (int64_t)u.slab * slab_elems(NB) + lane;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sl[(t * 4 + r) * 64] = acc[t][r];
+  }
+#pragma unroll
+  for (int cb = 0; cb < NB; ++cb) sl[(NT * 4 + cb) * 64] = bacc[cb];
+}
+
 // Kernel 1b (dominant on the user side): one wave per row that fits one unit -- gather +
 // Gramian + rhs, then the row's solve, all in registers.
 template <typename T, int NB, bool LDS_SOLVER, bool EDGE>
@@ -896,14 +1100,29 @@ __global__ __launch_bounds__(64, YCNR_FUSED_WAVES_PER_SIMD) void als_gram_solve_
   const Unit u = a.units[a.firstFused + blockIdx.x];
   typename G::State st;
   G::init(st);
+#ifdef YCNR_ABLATE_GRAM  // timing experiments only: skip the Gramian (results are wrong)
+  st.acc[0][0] = (T)u.beg;
+#elif YCNR_FUSED_PREFETCH > 1
+  G::template accumulate_ring<YCNR_FUSED_PREFETCH>(st, a.indx, a.vals, a.fixed, a.zeros, a.k, u.beg, u.end, lane);
+#else
   G::accumulate(st, a.indx, a.vals, a.fixed, a.zeros, a.k, u.beg, u.end, lane);
+#endif
   acc_t acc[G::NT];
   T bacc[NB];
   G::to_tiles(st, acc, bacc, reinterpret_cast<T *>(smem), lane);
   // lambda.diagonal(_lambda * _n): the product is formed in double and rounded to T once
   const T lam = (T)(a.lambda * (double)(u.end - u.beg));
+#ifdef YCNR_ABLATE_SOLVE  // timing experiments only: skip the solve, keep the Gramian live
+  {
+    T sum = lam;
+    for (int t = 0; t < G::NT; ++t) sum += acc[t][0] + acc[t][1] + acc[t][2] + acc[t][3];
+    for (int cb = 0; cb < NB; ++cb) sum += bacc[cb];
+    if (lane < a.k) a.solved[(int64_t)u.row * a.k + lane] = sum;
+  }
+#else
   SolverFor<T, NB, LDS_SOLVER>::type::run(acc, bacc, reinterpret_cast<T *>(smem), a.k, lam,
                                           a.solved + (int64_t)u.row * a.k, u.row, a.err, lane);
+#endif
 }
 
 // Kernel 1c: the same row solve in its DUAL form, for rows with fewer ratings than factors.

@@ -171,13 +171,23 @@ int launch_duals<float>(const StepArgs<float> &args, const DualPlan &dp, hipStre
   return rc;
 }
 
-template <typename T, int NB, bool LDS_SOLVER, bool EDGE>
+template <typename T, int NB>
+void (*slab_x6_kernel())(StepArgs<T>) { return nullptr; }
+#define YCNR_X6(NBV) \
+  template <>        \
+  void (*slab_x6_kernel<float, NBV>())(StepArgs<float>) { return als_gram_slab_x6_kernel<NBV>; }
+YCNR_X6(1) YCNR_X6(2) YCNR_X6(3) YCNR_X6(4) YCNR_X6(5) YCNR_X6(6) YCNR_X6(7) YCNR_X6(8)
+#undef YCNR_X6
+
+// SLABX6: split chunks go through the bf16x6 Gramian kernel (plain slab layout), so the reduce
+// kernel reads plain slabs whatever form the fused kernel uses.
+template <typename T, int NB, bool LDS_SOLVER, bool EDGE, bool SLABX6>
 int launch_nbe(StepArgs<T> args, int64_t nUnits, int64_t nSplitUnits, int64_t nSplit, hipStream_t stream,
                hipEvent_t *ev /* 5 events or null */, const DualPlan &dp) {
   const size_t lds = SolverFor<T, NB, LDS_SOLVER>::type::lds_bytes();
-  auto k0 = als_gram_slab_kernel<T, NB, EDGE>;
+  void (*k0)(StepArgs<T>) = SLABX6 ? slab_x6_kernel<T, NB>() : als_gram_slab_kernel<T, NB, EDGE && !SLABX6>;
   auto k1 = als_gram_solve_kernel<T, NB, LDS_SOLVER, EDGE>;
-  auto k2 = als_reduce_solve_kernel<T, NB, LDS_SOLVER, EDGE>;
+  auto k2 = als_reduce_solve_kernel<T, NB, LDS_SOLVER, EDGE && !SLABX6>;
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k1),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k2),
@@ -211,11 +221,15 @@ int launch_nbe(StepArgs<T> args, int64_t nUnits, int64_t nSplitUnits, int64_t nS
 // the VALU-edge Gramian exists for float32 and k = 16 (NB-1) + 4 only
 template <typename T, int NB, bool LDS_SOLVER>
 int launch_nb(const StepArgs<T> &args, int64_t nUnits, int64_t nSplitUnits, int64_t nSplit, hipStream_t stream, hipEvent_t *ev,
-              const DualPlan &dp, bool edge) {
-  if constexpr (std::is_same<T, float>::value && NB >= 2) {
-    if (edge) return launch_nbe<T, NB, LDS_SOLVER, true>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp);
+              const DualPlan &dp, bool edge, bool x6) {
+  if constexpr (std::is_same<T, float>::value) {
+    if constexpr (NB >= 2) {
+      if (edge && x6) return launch_nbe<T, NB, LDS_SOLVER, true, true>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp);
+      if (edge) return launch_nbe<T, NB, LDS_SOLVER, true, false>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp);
+    }
+    if (x6) return launch_nbe<T, NB, LDS_SOLVER, false, true>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp);
   }
-  return launch_nbe<T, NB, LDS_SOLVER, false>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp);
+  return launch_nbe<T, NB, LDS_SOLVER, false, false>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp);
 }
 
 template <int NB>
@@ -267,27 +281,27 @@ int launch_step_big(const StepArgs<float> &args, const std::vector<Schedule::Bat
 
 template <typename T>
 int launch_step(const StepArgs<T> &args, int64_t nUnits, int64_t nSplitUnits, int64_t nSplit, hipStream_t stream,
-                hipEvent_t *ev, bool ldsSolver = false, const DualPlan &dp = DualPlan(), bool edge = false) {
+                hipEvent_t *ev, bool ldsSolver = false, const DualPlan &dp = DualPlan(), bool edge = false, bool x6 = false) {
   if (nUnits > 0x7fffffffLL || nSplit > 0x7fffffffLL)
     return fail(YCNR_ERR_UNSUPPORTED, "too many work units for one launch (%lld)", (long long)nUnits);
   const int nb = (args.k + 15) / 16;
   switch (nb) {
-    case 1: return ldsSolver ? launch_nb<T, 1, true>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp, edge)
-                             : launch_nb<T, 1, false>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp, edge);
-    case 2: return ldsSolver ? launch_nb<T, 2, true>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp, edge)
-                             : launch_nb<T, 2, false>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp, edge);
-    case 3: return ldsSolver ? launch_nb<T, 3, true>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp, edge)
-                             : launch_nb<T, 3, false>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp, edge);
-    case 4: return ldsSolver ? launch_nb<T, 4, true>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp, edge)
-                             : launch_nb<T, 4, false>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp, edge);
-    case 5: return ldsSolver ? launch_nb<T, 5, true>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp, edge)
-                             : launch_nb<T, 5, false>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp, edge);
-    case 6: return ldsSolver ? launch_nb<T, 6, true>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp, edge)
-                             : launch_nb<T, 6, false>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp, edge);
-    case 7: return ldsSolver ? launch_nb<T, 7, true>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp, edge)
-                             : launch_nb<T, 7, false>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp, edge);
-    case 8: return ldsSolver ? launch_nb<T, 8, true>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp, edge)
-                             : launch_nb<T, 8, false>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp, edge);
+    case 1: return ldsSolver ? launch_nb<T, 1, true>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp, edge, x6)
+                             : launch_nb<T, 1, false>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp, edge, x6);
+    case 2: return ldsSolver ? launch_nb<T, 2, true>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp, edge, x6)
+                             : launch_nb<T, 2, false>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp, edge, x6);
+    case 3: return ldsSolver ? launch_nb<T, 3, true>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp, edge, x6)
+                             : launch_nb<T, 3, false>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp, edge, x6);
+    case 4: return ldsSolver ? launch_nb<T, 4, true>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp, edge, x6)
+                             : launch_nb<T, 4, false>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp, edge, x6);
+    case 5: return ldsSolver ? launch_nb<T, 5, true>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp, edge, x6)
+                             : launch_nb<T, 5, false>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp, edge, x6);
+    case 6: return ldsSolver ? launch_nb<T, 6, true>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp, edge, x6)
+                             : launch_nb<T, 6, false>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp, edge, x6);
+    case 7: return ldsSolver ? launch_nb<T, 7, true>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp, edge, x6)
+                             : launch_nb<T, 7, false>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp, edge, x6);
+    case 8: return ldsSolver ? launch_nb<T, 8, true>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp, edge, x6)
+                             : launch_nb<T, 8, false>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp, edge, x6);
     default:
       return fail(YCNR_ERR_UNSUPPORTED, "factorsCount %d > %d is not supported by this build", args.k,
                   kMaxFactors);
@@ -302,10 +316,18 @@ bool use_valu_edge(const ycnr_als_options &o) {
          o.factorsCount % 16 == 4;
 }
 
+// split chunks on the bf16 matrix pipe (exact 3-way split, six products): float32, one-wave
+// kernels, fixed matrix addressable by a 32-bit buffer offset
+bool use_slab_x6(const ycnr_als_options &o, int side) {
+  const int64_t fixedRows = side == YCNR_BY_USER ? o.totalItemsCount : o.totalUsersCount;
+  return o.dtype == YCNR_F32 && !(o.flags & YCNR_FLAG_NO_BF16X6) && o.factorsCount <= kMaxFactors &&
+         fixedRows * o.factorsCount * 4 < ((int64_t)1 << 31);
+}
+
 // registers (x 64 lanes x sizeof(T)) one split unit writes
-int64_t slab_regs(const ycnr_als_options &o) {
+int64_t slab_regs(const ycnr_als_options &o, int side) {
   const int nb = slab_nb(o.factorsCount);
-  if (use_valu_edge(o)) {
+  if (use_valu_edge(o) && !use_slab_x6(o, side)) {
     const int nbm = nb - 1;
     return tile_count(nbm) * 4 + nbm + nbm * 4 + 8;
   }
@@ -515,8 +537,9 @@ static int upload_ratings(ycnr_als *h, Ratings &R, int64_t totalRows, int64_t op
   R.rowEnd = rowEnd;
   R.nnz = nnz;
   const size_t ts = h->ts();
-  HIP_TRY(hipMalloc(&R.dIndx, std::max<size_t>(4, (size_t)nnz * 4)));
-  HIP_TRY(hipMalloc(&R.dVals, std::max<size_t>(8, (size_t)nnz * ts)));
+  // 64 bytes of slack: the bf16x6 kernel reads ids and ratings with 16-byte vector loads
+  HIP_TRY(hipMalloc(&R.dIndx, (size_t)nnz * 4 + 64));
+  HIP_TRY(hipMalloc(&R.dVals, (size_t)nnz * ts + 64));
   int rc = copy_in(R.dIndx, indx + base, (size_t)nnz * 4, memKind, h->stream);
   if (rc) return rc;
   rc = copy_in(R.dVals, (const char *)vals + (size_t)base * ts, (size_t)nnz * ts, memKind, h->stream);
@@ -620,7 +643,7 @@ int ycnr_als_set_ratings(ycnr_als *h, int side, const int64_t *rowPtr, const int
   if (S.nSplit) {
     HIP_TRY(hipMalloc(&S.dSplit, sizeof(SplitRow) * split.size()));
     HIP_TRY(hipMemcpy(S.dSplit, split.data(), sizeof(SplitRow) * split.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipMalloc(&S.dSlabs, (size_t)arenaSlabs * slab_regs(h->opt) * 64 * h->ts()));
+    HIP_TRY(hipMalloc(&S.dSlabs, (size_t)arenaSlabs * slab_regs(h->opt, side) * 64 * h->ts()));
   }
   return YCNR_OK;
 }
@@ -701,7 +724,8 @@ int ycnr_als_step_async(ycnr_als *h, int side) {
   int rc;
   if (h->opt.dtype == YCNR_F32) {
     StepArgs<float> a{S.dUnits, S.dSplit, R.dIndx, (const float *)R.dVals, (const float *)h->factors[1 - side],
-                      (const float *)h->dZeros, (float *)h->factors[side], (float *)S.dSlabs, h->dErr, lambda, h->opt.factorsCount, 0, 0};
+                      (const float *)h->dZeros, (float *)h->factors[side], (float *)S.dSlabs, h->dErr, lambda, h->opt.factorsCount, 0, 0,
+                      use_slab_x6(h->opt, side) ? (uint32_t)(h->rows(1 - side) * h->opt.factorsCount * 4) : 0u};
     DualPlan dp;
     if (dual_max_ratings(h->opt) > 0) {
       dp.nPrimal = S.nPrimal;
@@ -712,10 +736,10 @@ int ycnr_als_step_async(ycnr_als *h, int side) {
       rc = launch_step_big(a, S.batches, h->stream, h->ev, dp);
     else
       rc = launch_step<float>(a, S.nUnits, S.nSlabs, S.nSplit, h->stream, h->ev, (h->opt.flags & YCNR_FLAG_LDS_SOLVER) != 0, dp,
-                              use_valu_edge(h->opt));
+                              use_valu_edge(h->opt), use_slab_x6(h->opt, side));
   } else {
     StepArgs<double> a{S.dUnits, S.dSplit, R.dIndx, (const double *)R.dVals, (const double *)h->factors[1 - side],
-                       (const double *)h->dZeros, (double *)h->factors[side], (double *)S.dSlabs, h->dErr, lambda, h->opt.factorsCount, 0, 0};
+                       (const double *)h->dZeros, (double *)h->factors[side], (double *)S.dSlabs, h->dErr, lambda, h->opt.factorsCount, 0, 0, 0u};
     rc = launch_step<double>(a, S.nUnits, S.nSlabs, S.nSplit, h->stream, h->ev, true);
   }
   if (rc) return rc;
@@ -925,7 +949,7 @@ int64_t als_calc_portion(double lambda, int k, const int32_t *alsRows, const int
   L1_TRY(hipMemcpyAsync(dFixed, cfix.data(), sizeof(T) * cfix.size(), hipMemcpyHostToDevice, stream));
   {
     // rows are numbered 0..nRows-1 on the device and scattered to rowId on the host
-    StepArgs<T> a{dUnits, dSplit, dIndx, dVals, dFixed, dZeros, dSolved, dSlabs, dErr, lambda, k, 0, 0};
+    StepArgs<T> a{dUnits, dSplit, dIndx, dVals, dFixed, dZeros, dSolved, dSlabs, dErr, lambda, k, 0, 0, 0u};
     rc = launch_step<T>(a, (int64_t)units.size(), nSlabs, (int64_t)split.size(), stream, nullptr);
     if (rc) {
       cleanup();
