@@ -1015,31 +1015,16 @@ __global__ __launch_bounds__(64, 1) void als_gram_slab_x6_kernel(StepArgs<float>
       raw[NB - 1][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd, lastok ? off[j] : OOB, (NB - 1) * 64, 0));
     }
   };
-  unsigned offA[8], offB[8];
-  float rA[8], rB[8];
-  float rawA[NB][8], rawB[NB][8];
-  fetch(0, offA, rA);
-  gather(rawA, offA);
-  fetch(1, offB, rB);
-  for (int64_t s = 0; s < nsteps; ++s) {
-    gather(rawB, offB);  // operands of step s + 1 (all out of range past the end)
-    float rC[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) rC[j] = rB[j];
-    fetch(s + 2, offB, rB);
-    // b += y * r on the VALU, from the unsplit values
+  // exact 3-way bf16 split of every value, packed in k order (pairs j, j+1 per register), and
+  // b += y * r on the VALU from the unsplit values
+  auto split = [&](const float (&raw)[NB][8], const float (&r)[8], u32x4 (&p1)[NB], u32x4 (&p2)[NB], u32x4 (&p3)[NB]) {
 #pragma unroll
     for (int cb = 0; cb < NB; ++cb) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) bacc[cb] = fmaf(rawA[cb][j], rA[j], bacc[cb]);
-    }
-    // exact 3-way bf16 split of every value, packed in k order (pairs j, j+1 per register)
-    u32x4 p1[NB], p2[NB], p3[NB];
-#pragma unroll
-    for (int cb = 0; cb < NB; ++cb) {
+      for (int j = 0; j < 8; ++j) bacc[cb] = fmaf(raw[cb][j], r[j], bacc[cb]);
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
-        const float x0 = rawA[cb][2 * jj], x1 = rawA[cb][2 * jj + 1];
+        const float x0 = raw[cb][2 * jj], x1 = raw[cb][2 * jj + 1];
         const unsigned u0 = __builtin_bit_cast(unsigned, x0), u1 = __builtin_bit_cast(unsigned, x1);
         p1[cb][jj] = __builtin_amdgcn_perm(u1, u0, 0x07060302);
         const float s0 = x0 - __builtin_bit_cast(float, u0 & 0xFFFF0000u);
@@ -1051,6 +1036,8 @@ __global__ __launch_bounds__(64, 1) void als_gram_slab_x6_kernel(StepArgs<float>
         p3[cb][jj] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, t1), __builtin_bit_cast(unsigned, t0), 0x07060302);
       }
     }
+  };
+  auto mma6 = [&](const u32x4 (&p1)[NB], const u32x4 (&p2)[NB], const u32x4 (&p3)[NB]) {
 #pragma unroll
     for (int bi = 0; bi < NB; ++bi) {
       const bf16x8 a1 = __builtin_bit_cast(bf16x8, p1[bi]), a2 = __builtin_bit_cast(bf16x8, p2[bi]),
@@ -1070,13 +1057,40 @@ __global__ __launch_bounds__(64, 1) void als_gram_slab_x6_kernel(StepArgs<float>
         acc[tile_index(bi, bj, NB)] = t;
       }
     }
+  };
+  // Software pipeline, two steps per trip so that no register set is copied:
+  //   matrix pipe: products of step s        (from p / q, split during step s - 1)
+  //   VALU:        split + rhs of step s + 1 (from the gather issued during step s - 1)
+  //   memory:      gather of step s + 2, column ids and ratings of step s + 3
+  // A gather is issued only after the previous one has been consumed, so at most 56 + 4 loads
+  // are in flight (see fetch).
+  unsigned offG[8];
+  float rG[8], rX[8], rY[8];
+  float rawX[NB][8], rawY[NB][8];
+  u32x4 p1[NB], p2[NB], p3[NB], q1[NB], q2[NB], q3[NB];
+  auto keep = [](float (&dst)[8], const float (&src)[8]) {
 #pragma unroll
-    for (int cb = 0; cb < NB; ++cb) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) rawA[cb][j] = rawB[cb][j];
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) rA[j] = rC[j];
+    for (int j = 0; j < 8; ++j) dst[j] = src[j];
+  };
+  fetch(0, offG, rG);
+  gather(rawX, offG);
+  keep(rX, rG);
+  fetch(1, offG, rG);
+  split(rawX, rX, p1, p2, p3);  // step 0 (waits for its gather)
+  gather(rawY, offG);           // step 1
+  keep(rY, rG);
+  fetch(2, offG, rG);
+  for (int64_t s = 0; s < nsteps; s += 2) {
+    split(rawY, rY, q1, q2, q3);  // step s + 1
+    gather(rawX, offG);           // step s + 2
+    keep(rX, rG);
+    fetch(s + 3, offG, rG);
+    mma6(p1, p2, p3);             // step s
+    split(rawX, rX, p1, p2, p3);  // step s + 2
+    gather(rawY, offG);           // step s + 3
+    keep(rY, rG);
+    fetch(s + 4, offG, rG);
+    mma6(q1, q2, q3);             // step s + 1 (all zero when s + 1 == nsteps)
   }
   // same slab layout as GramPlain: [tile][reg][lane], then NB rhs partials
   float *sl = a.slabs + (int64_t)u.slab * slab_elems(NB) + lane;
