@@ -799,9 +799,12 @@ struct SolveMfmaF32 {
       }
 #pragma unroll
       for (int p = 0; p < 16; ++p) {
+        // padded pivots (index >= k) are rows of the identity: their scale is 1 and their
+        // multipliers are 0, so skipping them is exact (a wave-uniform branch)
+        if (J * 16 + p >= k) break;
         float d = readlane(R[p], p);  // D[p][p] after the updates of pivots < p (lane p, group 0)
         if (!(d > 0.0f)) {
-          bad = bad || (J * 16 + p < k);
+          bad = true;
           d = 1.0f;
         }
         float rs = __builtin_amdgcn_rsqf(d);
