@@ -64,6 +64,11 @@ def main():
     ap.add_argument("--double", action="store_true", help="useDoublePrecision")
     ap.add_argument("--chunk", type=int, default=0, help="ratings per split work unit (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for functional tests)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="functional test only: every rank uses cuda:0 (several ranks on one GPU, gloo)")
+    ap.add_argument("--dump-factors", default="", help="write the final factor matrices of rank 0 to this .npz")
     ap.add_argument("--debug-mod-idx", type=int, default=0,
                     help="timing experiment only: fold all column ids into [0, N) so every gather hits L1/L2")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the baseline sample")
@@ -78,12 +83,17 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device (no CPU fallback)")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     from ycnr_als.data import synth_ratings
     from ycnr_als.emf import Dataset, EmfLord
@@ -196,6 +206,8 @@ def main():
     }
 
     rmse = lord.calcRmse("rmseValidate", False)
+    if args.dump_factors and rank == 0:
+        np.savez(args.dump_factors, U=lord.backend.get_factors(0), V=lord.backend.get_factors(1), rmse=rmse)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

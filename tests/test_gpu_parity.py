@@ -320,3 +320,22 @@ def test_full_iterations_ml100k_shape(als, oracle):
             assert abs(a[key] - b[key]) <= 1e-6, (key, a[key], b[key])
     assert abs(c1["globalAvgShift"] - c2["globalAvgShift"]) <= 1e-6
     assert h1[-1]["rmseValidate"] < h1[0]["rmseValidate"]  # it learns
+
+
+def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path):
+    """The sharded HIP path end to end: two gloo ranks sharing cuda:0 (functional stand-in for
+    two GPUs over RCCL) must reproduce the single-process factors bit for bit -- shard
+    ranges, per-shard CSR upload, the padded all-gather and the RMSE all-reduce included."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--workload", "ml100k", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    one = str(tmp_path / "one.npz")
+    two = str(tmp_path / "two.npz")
+    subprocess.check_call([sys.executable, os.path.join(root, "bench.py")] + common + ["--dump-factors", one], timeout=600)
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                           "--master-addr", "127.0.0.1", "--master-port", "29541", os.path.join(root, "bench.py"),
+                           "--gpus", "2", "--backend", "gloo", "--same-device", "--dump-factors", two] + common, timeout=900)
+    a, b = np.load(one), np.load(two)
+    assert np.array_equal(a["U"], b["U"]) and np.array_equal(a["V"], b["V"])
+    assert abs(float(a["rmse"]) - float(b["rmse"])) < 1e-12
