@@ -1029,6 +1029,10 @@ __global__ __launch_bounds__(64, 1) void als_gram_slab_x6_kernel(StepArgs<float>
       for (int jj = 0; jj < 4; ++jj) {
         const float x0 = raw[cb][2 * jj], x1 = raw[cb][2 * jj + 1];
         const unsigned u0 = __builtin_bit_cast(unsigned, x0), u1 = __builtin_bit_cast(unsigned, x1);
+#ifdef YCNR_ABLATE_X6_SPLIT  // timing experiments only: no split, raw bits as operands
+        p1[cb][jj] = u0; p2[cb][jj] = u1; p3[cb][jj] = u0 ^ u1;
+        continue;
+#endif
         p1[cb][jj] = __builtin_amdgcn_perm(u1, u0, 0x07060302);
         const float s0 = x0 - __builtin_bit_cast(float, u0 & 0xFFFF0000u);
         const float s1 = x1 - __builtin_bit_cast(float, u1 & 0xFFFF0000u);
@@ -1041,23 +1045,24 @@ __global__ __launch_bounds__(64, 1) void als_gram_slab_x6_kernel(StepArgs<float>
     }
   };
   auto mma6 = [&](const u32x4 (&p1)[NB], const u32x4 (&p2)[NB], const u32x4 (&p3)[NB]) {
+#ifdef YCNR_ABLATE_X6_MMA  // timing experiments only: keep the split results alive, skip the products
 #pragma unroll
-    for (int bi = 0; bi < NB; ++bi) {
-      const bf16x8 a1 = __builtin_bit_cast(bf16x8, p1[bi]), a2 = __builtin_bit_cast(bf16x8, p2[bi]),
-                   a3 = __builtin_bit_cast(bf16x8, p3[bi]);
+    for (int cb = 0; cb < NB; ++cb) asm volatile("" ::"v"(p1[cb]), "v"(p2[cb]), "v"(p3[cb]));
+    return;
+#endif
+    // product type outermost: consecutive MFMAs update different tiles, so no MFMA waits for
+    // the previous one's accumulator (smallest terms still first per tile)
 #pragma unroll
-      for (int bj = bi; bj < NB; ++bj) {
-        const bf16x8 b1 = __builtin_bit_cast(bf16x8, p1[bj]), b2 = __builtin_bit_cast(bf16x8, p2[bj]),
-                     b3 = __builtin_bit_cast(bf16x8, p3[bj]);
-        acc_t t = acc[tile_index(bi, bj, NB)];
-        // smallest terms first
-        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b2, t, 0, 0, 0);
-        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b3, t, 0, 0, 0);
-        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, b1, t, 0, 0, 0);
-        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b2, t, 0, 0, 0);
-        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b1, t, 0, 0, 0);
-        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, t, 0, 0, 0);
-        acc[tile_index(bi, bj, NB)] = t;
+    for (int term = 0; term < 6; ++term) {
+#pragma unroll
+      for (int bi = 0; bi < NB; ++bi) {
+#pragma unroll
+        for (int bj = bi; bj < NB; ++bj) {
+          const u32x4 &pa = term == 0 ? p2[bi] : (term == 1 || term == 3 || term == 5) ? p1[bi] : (term == 2 ? p3[bi] : p2[bi]);
+          const u32x4 &pb = term == 0 ? p2[bj] : term == 1 ? p3[bj] : term == 2 ? p1[bj] : term == 3 ? p2[bj] : p1[bj];
+          acc[tile_index(bi, bj, NB)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+              __builtin_bit_cast(bf16x8, pa), __builtin_bit_cast(bf16x8, pb), acc[tile_index(bi, bj, NB)], 0, 0, 0);
+        }
       }
     }
   };

@@ -781,7 +781,7 @@ int ycnr_als_sync(ycnr_als *h) {
     ErrInfo ei{};
     HIP_TRY(hipMemcpy(&ei, h->dErr, sizeof ei, hipMemcpyDeviceToHost));
     h->info.numericErrors = ei.count;
-    if (ei.count > 0)
+    if (ei.count > 0 && !getenv("YCNR_IGNORE_NUMERIC"))  // the env var exists for timing experiments with ablated kernels
       return fail(YCNR_ERR_NUMERIC, "%d row(s) had a normal matrix that is not positive definite (e.g. row %d)",
                   ei.count, ei.firstRow);
   }
