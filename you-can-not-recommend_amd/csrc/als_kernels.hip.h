@@ -1288,12 +1288,39 @@ __global__ __launch_bounds__(256) void als_rmse_kernel(RmseArgs<T> a) {
   const int64_t r0 = p == 0 ? 0 : a.portionRowEnd[p - 1];
   const int64_t r1 = a.portionRowEnd[p];
   double sd2 = 0, sp = 0, cnt = 0;
+  // 16-byte loads when rows are 16-byte multiples: lane l16 owns the vec4 chunks l16, l16 + 16, ...
+  // of both factor rows; the user's chunks stay in registers for all of its ratings
+  typedef T vec4 __attribute__((ext_vector_type(4)));
+  const bool vec = (a.k * sizeof(T)) % 16 == 0 && a.k <= 512;
+  const int nchunk = a.k >> 2;
   for (int64_t r = r0 + grp; r < r1; r += 16) {
     const T *uF = a.userFactors + (a.rowBegin + r) * a.k;
+    vec4 u[8];
+    if (vec) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int ch = l16 + 16 * i;
+        u[i] = ch < nchunk ? *reinterpret_cast<const vec4 *>(uF + 4 * ch) : vec4{T(0), T(0), T(0), T(0)};
+      }
+    }
     for (int64_t q = a.rowPtr[r]; q < a.rowPtr[r + 1]; ++q) {
       const T *iF = a.itemFactors + (int64_t)a.indx[q] * a.k;
       T dot = T(0);
-      for (int f = l16; f < a.k; f += 16) dot = fma(uF[f], iF[f], dot);
+      if (vec) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int ch = l16 + 16 * i;
+          if (16 * i < nchunk) {  // uniform
+            const vec4 v = ch < nchunk ? *reinterpret_cast<const vec4 *>(iF + 4 * ch) : vec4{T(0), T(0), T(0), T(0)};
+            dot = fma(u[i][0], v[0], dot);
+            dot = fma(u[i][1], v[1], dot);
+            dot = fma(u[i][2], v[2], dot);
+            dot = fma(u[i][3], v[3], dot);
+          }
+        }
+      } else {
+        for (int f = l16; f < a.k; f += 16) dot = fma(uF[f], iF[f], dot);
+      }
       dot += wave_shfl_xor<T>(dot, 8);
       dot += wave_shfl_xor<T>(dot, 4);
       dot += wave_shfl_xor<T>(dot, 2);
