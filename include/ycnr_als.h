@@ -151,8 +151,10 @@ int ycnr_als_create(const ycnr_als_options *opts, ycnr_als **out);
 /* Frees all device memory of the handle (cf. detachSharedFactors, EmfBase.js:351-376). */
 int ycnr_als_destroy(ycnr_als *h);
 
-/* Use an existing hipStream_t (e.g. torch's current stream) for all work of the handle;
- * NULL restores the handle's own stream. */
+/* Use an existing hipStream_t (e.g. torch's current stream) for all work of the handle, so
+ * that the caller's copies and collectives are ordered against it.  NULL is the device's
+ * default (null) stream; YCNR_OWN_STREAM restores the handle's own non-blocking stream. */
+#define YCNR_OWN_STREAM ((void *)(intptr_t)-1)
 int ycnr_als_set_stream(ycnr_als *h, void *hipStream);
 
 /* Ratings of one side in CSR form, replacing the per-portion SQL fetch + packer

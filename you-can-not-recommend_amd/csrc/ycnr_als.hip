@@ -506,7 +506,7 @@ int ycnr_als_set_stream(ycnr_als *h, void *s) {
   if (!h) return fail(YCNR_ERR_INVALID, "null handle");
   HIP_TRY(hipSetDevice(h->opt.device));
   HIP_TRY(hipStreamSynchronize(h->stream));
-  h->stream = s ? (hipStream_t)s : h->ownStream;
+  h->stream = s == YCNR_OWN_STREAM ? h->ownStream : (hipStream_t)s;  // NULL = the null (default) stream
   return YCNR_OK;
 }
 

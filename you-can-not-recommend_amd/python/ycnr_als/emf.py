@@ -40,6 +40,9 @@ def default_options():
         "dataDir": "data",
         # ratings per wave-level work unit on the GPU (0 = library default)
         "chunkRatings": 0,
+        # multi-GPU only: the user shard is solved in this many chunks so that the all-gather of
+        # one chunk overlaps with the solve of the next (1 = solve, then exchange)
+        "exchangeChunks": 4,
     }
 
 
@@ -132,7 +135,13 @@ class Dataset:
 
 class HipBackend:
     """The product compute backend: libycnr_als.so on cuda:<device>.  Factor matrices are
-    torch CUDA tensors bound into the handle so collectives run on them in place."""
+    torch CUDA tensors bound into the handle(s) so collectives run on them in place.
+
+    With several ranks the local shard of a side can be cut into `chunks` row ranges, each
+    with its own native handle (same bound matrices): chunk c's solved rows are exchanged
+    while chunk c + 1 is being solved.  All work is enqueued on torch's current stream, so a
+    collective issued after step_chunk_async(c) is ordered behind that chunk's kernels and
+    overlaps with the next chunk's."""
 
     def __init__(self, opts, users, items, device=0):
         import torch
@@ -142,13 +151,20 @@ class HipBackend:
         self.device = torch.device("cuda", device)
         self.dtype_np = np.float64 if opts["useDoublePrecision"] else np.float32
         tdt = torch.float64 if opts["useDoublePrecision"] else torch.float32
+        self.opts, self.users, self.items, self.devno = opts, users, items, device
         k = opts["factorsCount"]
-        self.dev = AlsDevice(k, users, items, opts["useDoublePrecision"], opts["als"]["userFactReg"],
-                             opts["als"]["itemFactReg"], device=device, chunkRatings=opts.get("chunkRatings", 0))
         self.fac = [torch.zeros(users, k, dtype=tdt, device=self.device),
                     torch.zeros(items, k, dtype=tdt, device=self.device)]
-        self.dev.bind_factors(0, self.fac[0])
-        self.dev.bind_factors(1, self.fac[1])
+        self.dev = self._new_handle()
+        self.chunk_devs = {0: [], 1: []}  # side -> [(AlsDevice, rowBegin, rowEnd)]
+
+    def _new_handle(self):
+        o = self.opts
+        d = AlsDevice(o["factorsCount"], self.users, self.items, o["useDoublePrecision"], o["als"]["userFactReg"],
+                      o["als"]["itemFactReg"], device=self.devno, chunkRatings=o.get("chunkRatings", 0))
+        d.bind_factors(0, self.fac[0])
+        d.bind_factors(1, self.fac[1])
+        return d
 
     def factors(self, side):
         return self.fac[side]
@@ -163,22 +179,57 @@ class HipBackend:
     def _vals(self, csr):
         return csr.astype(self.dtype_np)
 
-    def set_ratings(self, side, csr, rb, re):
+    def set_ratings(self, side, csr, rb, re, chunk_bounds=None):
+        """chunk_bounds: ascending row ids [rb, ..., re] cutting the shard into pipelined chunks."""
         c = self._vals(csr)
-        self.dev.set_ratings(side, c.rowPtr, c.indx, c.vals, rb, re)
+        for d, _, _ in self.chunk_devs[side]:
+            d.destroy()
+        self.chunk_devs[side] = []
+        if chunk_bounds is not None and len(chunk_bounds) > 2:
+            stream = self.torch.cuda.current_stream(self.device).cuda_stream
+            for lo, hi in zip(chunk_bounds[:-1], chunk_bounds[1:]):
+                d = self._new_handle()
+                d.set_stream(stream)
+                d.set_ratings(side, c.rowPtr, c.indx, c.vals, int(lo), int(hi))
+                self.chunk_devs[side].append((d, int(lo), int(hi)))
+        else:
+            self.dev.set_ratings(side, c.rowPtr, c.indx, c.vals, rb, re)
 
     def set_rmse_ratings(self, which, csr, rb, re):
         c = self._vals(csr)
         self.dev.set_rmse_ratings(which, c.rowPtr, c.indx, c.vals, rb, re)
 
+    def nchunks(self, side):
+        return len(self.chunk_devs[side])
+
     def step(self, side):
         self.torch.cuda.synchronize(self.device)  # collectives on torch's stream are done
         return self.dev.step(side)
+
+    def step_chunk_async(self, side, c):
+        self.chunk_devs[side][c][0].step_async(side)
+
+    def sync_chunks(self, side):
+        """Wait for all chunk kernels; returns one merged StepInfo-like object."""
+        infos = []
+        for d, _, _ in self.chunk_devs[side]:
+            d.sync()
+            infos.append(d.last_step_info())
+        m = infos[0]
+        for i in infos[1:]:
+            for f in ("rows", "ratings", "units", "splitRows", "fusedRows", "fusedRatings", "dualRows", "dualRatings",
+                      "gramSlabMs", "gramSolveMs", "dualSolveMs", "reduceSolveMs", "totalMs", "numericErrors"):
+                setattr(m, f, getattr(m, f) + getattr(i, f))
+        return m
 
     def rmse(self, which, shift, portion_row_end):
         return self.dev.rmse(which, shift, portion_row_end)
 
     def destroy(self):
+        for side in (0, 1):
+            for d, _, _ in self.chunk_devs[side]:
+                d.destroy()
+            self.chunk_devs[side] = []
         self.dev.destroy()
 
 
@@ -245,7 +296,16 @@ class EmfLord:
         self.backend = self._backend_factory(self.options, self.totalUsersCount, self.totalItemsCount, device)
         ub, ue = self.shards[0][self.rank], self.shards[0][self.rank + 1]
         ib, ie = self.shards[1][self.rank], self.shards[1][self.rank + 1]
-        self.backend.set_ratings(0, ds.train_by_user, int(ub), int(ue))
+        # pipelined exchange of the big (user) side: every rank's shard is cut into the same number
+        # of nnz-balanced chunks; chunkBounds[side][r] = row ids [begin, ..., end] of rank r
+        self.chunkBounds = {}
+        nch = int(self.options.get("exchangeChunks", 4)) if self.world > 1 else 1
+        if nch > 1 and hasattr(self.backend, "step_chunk_async"):
+            b = self.shards[0]
+            self.chunkBounds[0] = [b[r] + shard_ranges(cu[b[r]:b[r + 1]], nch) for r in range(self.world)]
+            self.backend.set_ratings(0, ds.train_by_user, int(ub), int(ue), chunk_bounds=self.chunkBounds[0][self.rank])
+        else:
+            self.backend.set_ratings(0, ds.train_by_user, int(ub), int(ue))
         self.backend.set_ratings(1, ds.train_by_item, int(ib), int(ie))
         self.trainRatingsCount = int(cu.sum())
         # portions of the RMSE passes (EmfLord.js:523-598); kept as exclusive 0-based row ends
@@ -314,11 +374,47 @@ class EmfLord:
         has been re-solved everywhere, i.e. after the local step AND the exchange."""
         side = self.STEP_SIDE[stepType]
         t0 = time.perf_counter()
-        info = self.backend.step(side)
-        self._exchange(side)
+        if side in self.chunkBounds:
+            info = self._step_pipelined(side)
+        else:
+            info = self.backend.step(side)
+            self._exchange(side)
         self.stepTimes.append({"stepType": stepType, "iter": self.trainIter, "info": info,
                                "wall": time.perf_counter() - t0})
         return info
+
+    def _step_pipelined(self, side):
+        """Solve the local shard chunk by chunk; the all-gather of chunk c runs (on the
+        collective's own stream) while chunk c + 1 is being solved.  Same results as
+        step + _exchange: rows are independent within a half-step."""
+        dist, torch = self._dist, _torch()
+        bounds = self.chunkBounds[side]  # per rank: row ids [b0, b1, ..., bn]
+        nch = len(bounds[0]) - 1
+        fac = self.backend.factors(side)
+        k = fac.shape[1]
+        if not hasattr(self, "_cbuf"):
+            self._cbuf = {}
+        works = []
+        torch.cuda.synchronize()
+        for c in range(nch):
+            self.backend.step_chunk_async(side, c)
+            sizes = [int(bounds[r][c + 1] - bounds[r][c]) for r in range(self.world)]
+            mx = max(max(sizes), 1)
+            key = (side, c)
+            if key not in self._cbuf or self._cbuf[key].shape[1] != mx:
+                self._cbuf[key] = torch.zeros(self.world, mx, k, dtype=fac.dtype, device=fac.device)
+            buf = self._cbuf[key]
+            lo = int(bounds[self.rank][c])
+            buf[self.rank, : sizes[self.rank]].copy_(fac[lo:lo + sizes[self.rank]])
+            works.append((dist.all_gather_into_tensor(buf.view(-1), buf[self.rank].reshape(-1), async_op=True), buf, sizes, c))
+        for w, buf, sizes, c in works:
+            w.wait()
+            for r in range(self.world):
+                if r != self.rank and sizes[r] > 0:
+                    lo = int(bounds[r][c])
+                    fac[lo:lo + sizes[r]].copy_(buf[r, : sizes[r]])
+        torch.cuda.synchronize()
+        return self.backend.sync_chunks(side)
 
     def _exchange(self, side):
         """All-gather of the freshly solved shard into every rank's replica of the matrix."""

@@ -120,7 +120,8 @@ class AlsDevice:
 
     # -- data -----------------------------------------------------------------------
     def set_stream(self, hip_stream):
-        check(self._L.ycnr_als_set_stream(self._h, C.c_void_p(hip_stream or 0)))
+        """hip_stream: a hipStream_t value (0 = the default stream), or None for the handle's own stream."""
+        check(self._L.ycnr_als_set_stream(self._h, C.c_void_p(-1 if hip_stream is None else int(hip_stream))))
 
     def _upload(self, fn, key, rowPtr, indx, vals, rowBegin, rowEnd):
         n = (len(rowPtr) if not _is_torch(rowPtr) else rowPtr.numel()) - 1
