@@ -112,8 +112,8 @@ typedef struct ycnr_als_options {
   int32_t flags;           /* YCNR_FLAG_* bits, normally 0 */
 } ycnr_als_options;
 
-/* options.flags: use the plain LDS Cholesky for float32 too (float64 always uses it); the
- * default float32 solve is the register-resident MFMA block Cholesky. For A/B tests. */
+/* options.flags: use the plain LDS Cholesky (the first solver) instead of the
+ * register-resident MFMA block Cholesky. For A/B tests. */
 #define YCNR_FLAG_LDS_SOLVER 1
 /* options.flags: never use the dual (n x n) form for rows with fewer ratings than factors */
 #define YCNR_FLAG_NO_DUAL 2

@@ -181,6 +181,38 @@ def test_every_row_length_class(als, k):
         assert (err <= np.maximum(16 * conds * EPS32, 2e-6)).all()
 
 
+@pytest.mark.parametrize("k", [20, 100, 128])
+def test_float64_solvers_agree(als, k):
+    """useDoublePrecision: the register-resident f64 MFMA Cholesky (default) and the plain LDS
+    Cholesky (YCNR_FLAG_LDS_SOLVER) against float64 numpy and each other, rows of every length
+    class including split rows."""
+    from ycnr_als import _lib
+    items = 500
+    lens = [1, 2, 5, 15, 16, 17, 33, 64, 99, 100, 101, 130, 300, 0, 450]
+    rng = np.random.default_rng(k + 1)
+    rowPtr = np.zeros(len(lens) + 1, np.int64)
+    rowPtr[1:] = np.cumsum(lens)
+    indx = np.concatenate([np.sort(rng.choice(items, n, replace=False)) for n in lens]).astype(np.int32)
+    vals = rng.integers(1, 11, rowPtr[-1]).astype(np.float64)
+    bu = Csr(len(lens), items, rowPtr, indx, vals)
+    U = rng.standard_normal((len(lens), k)) / k
+    V = rng.standard_normal((items, k)) / np.sqrt(k)
+    want, conds = numpy_step(0.05, k, bu, V, U)
+    got = {}
+    for name, flags in (("mfma", 0), ("lds", _lib.FLAG_LDS_SOLVER)):
+        dev = als.AlsDevice(k, len(lens), items, useDoublePrecision=True, flags=flags, chunkRatings=128)
+        dev.set_ratings("byUser", bu.rowPtr, bu.indx, bu.vals)
+        dev.set_factors("byUser", U)
+        dev.set_factors("byItem", V)
+        info = dev.step("byUser")
+        assert info.splitRows == 3 and info.numericErrors == 0
+        got[name] = dev.get_factors("byUser")
+        assert row_rel_err(got[name], want).max() < 1e-9
+        assert np.array_equal(got[name][13], U[13])
+        dev.destroy()
+    assert row_rel_err(got["mfma"], got["lds"]).max() < 1e-9
+
+
 def test_big_k_split_rows_and_batches(als):
     """k = 256 through the 4-wave kernels: rows of many chunks, a row longer than 64 chunks, and
     both half-steps; checked against float64."""

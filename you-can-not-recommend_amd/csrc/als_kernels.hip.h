@@ -906,6 +906,168 @@ struct SolveMfmaF32 {
   }
 };
 
+// The same register-resident block Cholesky for float64 (v_mfma_f64_16x16x4_f64).  The f64
+// C/D layout puts row g + 4t in register t of lane group g, so the register with index q of a
+// tile already IS the MFMA operand of contraction step q (rows 4q + g): the panel and the
+// trailing update need no lane transposes at all.  Everything else mirrors SolveMfmaF32
+// (two 32-bit readlanes per broadcast, 1/sqrt in double, shuffles instead of DPP).
+template <int NB>
+struct SolveMfmaF64 {
+  using Tr = MfmaTraits<double>;
+  using acc_t = typename Tr::acc_t;
+  static constexpr int NT = tile_count(NB);
+  static constexpr int LDW = 18;  // doubles per LDS image row (144 B: 16-byte aligned rows)
+  static constexpr size_t lds_bytes() { return 2 * 16 * LDW * sizeof(double); }
+
+  static __device__ __forceinline__ double row_sum(double v) {
+    v += __shfl_xor(v, 8, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 1, 64);
+    return v;
+  }
+  static __device__ __forceinline__ double group_sum(double v) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+  }
+  static __device__ __forceinline__ double readlane(double v, int lane) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)lo);
+  }
+
+  static __device__ __forceinline__ bool solve(acc_t (&acc)[NT], const double (&bacc)[NB], double *S, int k, double lam,
+                                               double (&xcol)[NB], int lane) {
+    const int g = lane >> 4, c = lane & 15;
+    double *Dt = S, *Wt = S + 16 * LDW;
+    double bcol[NB];
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) bcol[cb] = group_sum(bacc[cb]);
+    {
+      // element (row, col) = (g + 4t, c) is on the diagonal when c % 4 == g, in register c / 4
+      const bool mine = (c & 3) == g;
+      const int t0 = c >> 2;
+#pragma unroll
+      for (int bi = 0; bi < NB; ++bi) {
+        const double add = (bi * 16 + c < k) ? lam : 1.0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[tile_index(bi, bi, NB)][t] += (mine && t == t0) ? add : 0.0;
+      }
+    }
+    bool bad = false;
+    double zrow[NB][4];  // z in row form: zrow[J][t] = z[16 J + g + 4 t]
+#pragma unroll
+    for (int J = 0; J < NB; ++J) {
+      {
+        const acc_t d = acc[tile_index(J, J, NB)];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) Dt[(g + 4 * t) * LDW + c] = d[t];
+      }
+      __syncthreads();
+      double R[16];
+      {
+        const bool xlane = (g & 1) != 0;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+          const double v = Dt[c * LDW + m];
+          R[m] = xlane ? (c == m ? 1.0 : 0.0) : v;
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < 16; ++p) {
+        if (J * 16 + p >= k) break;
+        double d = readlane(R[p], p);
+        if (!(d > 0.0)) {
+          bad = true;
+          d = 1.0;
+        }
+        const double rs = 1.0 / sqrt(d);
+        R[p] *= rs;
+#pragma unroll
+        for (int j = p + 1; j < 16; ++j) {
+          const double s = readlane(R[p], j);
+          R[j] = fma(-R[p], s, R[j]);
+        }
+      }
+      if (g == 1) {
+#pragma unroll
+        for (int m = 0; m < 16; ++m) Wt[c * LDW + m] = R[m];
+      }
+      __syncthreads();
+      acc_t W;  // W[g + 4t][c]
+#pragma unroll
+      for (int t = 0; t < 4; ++t) W[t] = Wt[c * LDW + g + 4 * t];
+      double Aop[4];  // A operand of MFMA q: W[i = c][kk = 4q + g]
+#pragma unroll
+      for (int q = 0; q < 4; ++q) Aop[q] = Wt[(4 * q + g) * LDW + c];
+      acc[tile_index(J, J, NB)] = W;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) zrow[J][t] = row_sum(W[t] * bcol[J]);
+      acc_t Pt[NB > 1 ? NB - 1 : 1];  // panel tiles; register q is the operand of step q
+#pragma unroll
+      for (int bj = J + 1; bj < NB; ++bj) {
+        const acc_t T = acc[tile_index(J, bj, NB)];
+        acc_t P = acc_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) P = Tr::mma(Aop[q], T[q], P);
+        acc[tile_index(J, bj, NB)] = P;
+        Pt[bj - J - 1] = P;
+        double s = P[0] * zrow[J][0];
+        s = fma(P[1], zrow[J][1], s);
+        s = fma(P[2], zrow[J][2], s);
+        s = fma(P[3], zrow[J][3], s);
+        bcol[bj] -= group_sum(s);
+      }
+#pragma unroll
+      for (int bi = J + 1; bi < NB; ++bi) {
+#pragma unroll
+        for (int bj = bi; bj < NB; ++bj) {
+          acc_t t = acc[tile_index(bi, bj, NB)];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) t = Tr::mma(-Pt[bi - J - 1][q], Pt[bj - J - 1][q], t);
+          acc[tile_index(bi, bj, NB)] = t;
+        }
+      }
+    }
+#pragma unroll
+    for (int J = NB - 1; J >= 0; --J) {
+      double part[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int bj = J + 1; bj < NB; ++bj) {
+        const acc_t u = acc[tile_index(J, bj, NB)];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) part[t] = fma(u[t], xcol[bj], part[t]);
+      }
+      const acc_t W = acc[tile_index(J, J, NB)];
+      double s = 0.0;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const double y = (J + 1 < NB) ? zrow[J][t] - row_sum(part[t]) : zrow[J][t];
+        s = fma(W[t], y, s);
+      }
+      xcol[J] = group_sum(s);
+    }
+    return bad;
+  }
+
+  static __device__ __forceinline__ void run(acc_t (&acc)[NT], const double (&bacc)[NB], double *S, int k, double lam,
+                                             double *__restrict__ out_row, int row, ErrInfo *err, int lane) {
+    const int g = lane >> 4, c = lane & 15;
+    double xcol[NB];
+    const bool bad = solve(acc, bacc, S, k, lam, xcol, lane);
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) {
+      if ((cb & 3) == g && cb * 16 + c < k) out_row[cb * 16 + c] = xcol[cb];
+    }
+    if (bad && lane == 0) {
+      atomicAdd(&err->count, 1);
+      err->firstRow = row;
+    }
+  }
+};
+
 template <typename T, int NB, bool LDS_SOLVER>
 struct SolverFor {
   using type = SolveLds<T, NB>;
@@ -913,6 +1075,10 @@ struct SolverFor {
 template <int NB>
 struct SolverFor<float, NB, false> {
   using type = SolveMfmaF32<NB>;
+};
+template <int NB>
+struct SolverFor<double, NB, false> {
+  using type = SolveMfmaF64<NB>;
 };
 
 template <typename T>
@@ -937,7 +1103,7 @@ struct StepArgs {
 // written as a partial slab.  Kept apart from the fused kernel so that its register
 // allocation (accumulators + operand ring) is not inflated by the solve.
 template <typename T, int NB, bool EDGE>
-__global__ __launch_bounds__(64, YCNR_SLAB_WAVES_PER_SIMD) void als_gram_slab_kernel(StepArgs<T> a) {
+__global__ __launch_bounds__(64, sizeof(T) == 8 ? 1 : YCNR_SLAB_WAVES_PER_SIMD) void als_gram_slab_kernel(StepArgs<T> a) {
   using G = typename GramSel<T, NB, EDGE>::type;
   const int lane = threadIdx.x;
   const Unit u = a.units[blockIdx.x];
@@ -1114,7 +1280,7 @@ __global__ __launch_bounds__(64, 1) void als_gram_slab_x6_kernel(StepArgs<float>
 // Kernel 1b (dominant on the user side): one wave per row that fits one unit -- gather +
 // Gramian + rhs, then the row's solve, all in registers.
 template <typename T, int NB, bool LDS_SOLVER, bool EDGE>
-__global__ __launch_bounds__(64, YCNR_FUSED_WAVES_PER_SIMD) void als_gram_solve_kernel(StepArgs<T> a) {
+__global__ __launch_bounds__(64, sizeof(T) == 8 ? 1 : YCNR_FUSED_WAVES_PER_SIMD) void als_gram_solve_kernel(StepArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using G = typename GramSel<T, NB, EDGE>::type;
   using acc_t = typename G::acc_t;

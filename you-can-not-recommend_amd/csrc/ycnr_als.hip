@@ -740,7 +740,7 @@ int ycnr_als_step_async(ycnr_als *h, int side) {
   } else {
     StepArgs<double> a{S.dUnits, S.dSplit, R.dIndx, (const double *)R.dVals, (const double *)h->factors[1 - side],
                        (const double *)h->dZeros, (double *)h->factors[side], (double *)S.dSlabs, h->dErr, lambda, h->opt.factorsCount, 0, 0, 0u};
-    rc = launch_step<double>(a, S.nUnits, S.nSlabs, S.nSplit, h->stream, h->ev, true);
+    rc = launch_step<double>(a, S.nUnits, S.nSlabs, S.nSplit, h->stream, h->ev, (h->opt.flags & YCNR_FLAG_LDS_SOLVER) != 0);
   }
   if (rc) return rc;
   memset(&h->info, 0, sizeof h->info);
