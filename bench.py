@@ -31,6 +31,7 @@ import torch  # noqa: E402
 WORKLOADS = {
     # name: users, items, nnz, k, max_rating, zipf_a, degree_sigma, description
     "mal": (1_750_000, 12_700, 121_000_000, 100, 10, 0.6, 1.2, "MAL-scale synthetic 1.75Mx12.7K, 121M nnz, k=100"),
+    "mal96": (1_750_000, 12_700, 121_000_000, 96, 10, 0.6, 1.2, "MAL-scale synthetic 1.75Mx12.7K, 121M nnz, k=96 (kernel experiments)"),
     "c3": (200_000, 20_000, 20_000_000, 64, 10, 0.8, 1.0, "synthetic 200Kx20K, 20M nnz, k=64"),
     "c5": (10_000_000, 100_000, 1_000_000_000, 256, 10, 0.7, 1.0, "synthetic 10Mx100K, 1B nnz, k=256"),
     "c5shard": (1_250_000, 100_000, 125_000_000, 256, 10, 0.7, 1.0, "one GPU's eighth of the 10Mx100K, 1B nnz, k=256 config (1.25Mx100K, 125M nnz)"),

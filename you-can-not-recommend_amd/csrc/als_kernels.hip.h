@@ -23,6 +23,7 @@
 //    so results do not depend on how many GPUs or workgroups took part.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 // Register budget of the fused Gramian + solve kernel: 2 waves per SIMD = at most 256
@@ -1267,6 +1268,468 @@ __global__ __launch_bounds__(64, 1) void als_gram_slab_x6_kernel(StepArgs<float>
     mma6(q1, q2, q3);             // step s + 1 (all zero when s + 1 == nsteps)
   }
   // same slab layout as GramPlain: [tile][reg][lane], then NB rhs partials
+  float *sl = a.slabs + (int64_t)u.slab * slab_elems(NB) + lane;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sl[(t * 4 + r) * 64] = acc[t][r];
+  }
+#pragma unroll
+  for (int cb = 0; cb < NB; ++cb) sl[(NT * 4 + cb) * 64] = bacc[cb];
+}
+
+// ds_bpermute the optimizer cannot see through.  hipcc (ROCm 7.2) folds
+//   v = (c & 3) == t ? __builtin_amdgcn_ds_bpermute(a, x[t]) : v,  t = 0..3
+// into a single bpermute of x[0] (the select is moved across the lane exchange), the same class of
+// miscompile as the permlane swaps in transpose_rg.
+// v may be fresh out of an MFMA: hipcc pads no hazard for an asm operand, so the statement opens
+// with the 12 wait states an MFMA result needs before a non-MFMA reader.
+__device__ __forceinline__ float bpermute_opaque(int byteAddr, float v) {
+  float r;
+  asm volatile("s_nop 7\n\ts_nop 3\n\tds_bpermute_b32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r) : "v"(byteAddr), "v"(v));
+  return r;
+}
+
+// The same bf16x6 Gramian arranged to fit TWO waves per SIMD (<= 256 registers per lane).
+//
+// Why two waves: measured with devtest/mfmarate.hip, one wave cannot hide vector work behind
+// v_mfma_f32_16x16x32_bf16 -- an MFMA blocks its own wave's issue for the 16 cycles it occupies
+// the matrix pipe, less one slot (19.6 cycles per MFMA bare, 27.9 with 3 VALU instructions
+// each, 36.9 with 6).  Two waves of a SIMD do overlap: the pair sustains an MFMA every 16
+// cycles with 2 VALU instructions each, every 17 with 3.  The split needs ~2 per MFMA.
+//
+// Registers: the 3 x NB operand registers are single-buffered.  Tiles are visited row by row
+// (bi, bj >= bi), so after row bi nothing reads block bi again and the NEXT step's block bi is
+// split into the same registers while rows bi+1.. still multiply.  Gathered floats wait in a
+// ring of D half-blocks (4 ratings x 16 columns per lane: 4 registers) that is refilled D
+// half-blocks ahead -- half a step for NB >= 5, a whole step below.  Column ids and ratings
+// travel as one register per step (lane L holds rating 32 s + L) and reach the lanes that
+// need them through ds_bpermute.
+//
+// PADRHS (k < 16 NB): the ratings ride in the first unused column of the last block, so
+// b = Y^T r comes out of the MFMAs as column k of the padded Gramian: no VALU multiply-adds and
+// no accumulators for it.  It is moved to the slab's b-partials at the end and the padded
+// entries are zeroed, so the slab is indistinguishable from the other kernels'.
+template <int NB, bool PADRHS>
+__global__ __launch_bounds__(64, 2) void als_gram_slab_x6p_kernel(StepArgs<float> a) {
+  using acc_t = typename MfmaTraits<float>::acc_t;
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  constexpr int NT = tile_count(NB);
+  constexpr int NH = 2 * NB;               // half-blocks per step
+  constexpr int D = NB >= 5 ? NB : 2 * NB; // ring slots = prefetch distance in half-blocks
+  constexpr unsigned OOB = 0x80000000u;
+  const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+  const Unit u = a.units[blockIdx.x];
+  const int k = a.k;
+  const int kr = k - 16 * (NB - 1);  // columns in use in the last block; PADRHS: kr < 16
+  const unsigned rowBytes = (unsigned)k * 4u;
+  const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc((void *)a.fixed, 0, (int)a.fixedBytes, 0x00020000);
+  const int64_t n = u.end - u.beg;
+  const int64_t nsteps = (n + 31) >> 5;
+
+  acc_t acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = acc_t{0.0f, 0.0f, 0.0f, 0.0f};
+  float bacc[PADRHS ? 1 : NB];
+#pragma unroll
+  for (int cb = 0; cb < (PADRHS ? 1 : NB); ++cb) bacc[cb] = 0.0f;
+  u32x4 p1[NB], p2[NB], p3[NB];
+  float raw[D][4];
+  unsigned off[8];
+  float rr[PADRHS ? 1 : 8];
+  unsigned offP;  // byte offset of the gathered row of rating 32 t + (lane & 31), or OOB
+  float rP;       // its rating value, or 0
+
+  // packed per-step inputs of step t (may be past the end: OOB / 0).  Buffer loads bounded to
+  // the unit: past its end they return 0 without a branch (a plain load under "q < n" is turned
+  // into a conditional block with a full vmcnt(0) wait by the compiler).
+  const unsigned unitBytes = (unsigned)(n < 0x3fffffff ? n : 0x3fffffff) * 4u;
+  const __amdgpu_buffer_rsrc_t srdI = __builtin_amdgcn_make_buffer_rsrc((void *)(a.indx + u.beg), 0, (int)unitBytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t srdR = __builtin_amdgcn_make_buffer_rsrc((void *)(a.vals + u.beg), 0, (int)unitBytes, 0x00020000);
+  const unsigned lane4 = (unsigned)(lane & 31) * 4u;
+  auto load_off = [&](int64_t t) {
+    const unsigned qb = ((unsigned)t << 7) + lane4;
+    const unsigned id = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(srdI, qb, 0, 0);
+    // past the end id = 0: OR-ing the marker in keeps the load out of any "if (valid)" block
+    return id * rowBytes | (qb < unitBytes ? 0u : OOB);
+  };
+  auto load_r = [&](int64_t t) {
+    const unsigned qb = ((unsigned)t << 7) + lane4;
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srdR, qb, 0, 0));
+  };
+  const int bpBase = g << 5;  // ds_bpermute byte address of lane 8 g
+  auto unpack_off = [&]() {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      off[j] = (unsigned)__builtin_amdgcn_ds_bpermute(bpBase + 4 * j, (int)offP) + (unsigned)c * 4u;
+  };
+  auto r_of = [&](int j) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bpBase + 4 * j, __builtin_bit_cast(int, rP))); };
+  auto issue = [&](int slot, int hbn) {  // gather half-block hbn (of the step off[] belongs to) into a ring slot
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      raw[slot][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd, off[4 * (hbn & 1) + j], (hbn >> 1) * 64, 0));
+  };
+  auto mma_row = [&](int bi) {
+    // product type outermost: consecutive MFMAs update different tiles of the row (smallest
+    // terms first per tile, as in als_gram_slab_x6_kernel, so the two kernels agree bitwise)
+#pragma unroll
+    for (int term = 0; term < 6; ++term) {
+#pragma unroll
+      for (int bj = bi; bj < NB; ++bj) {
+        const u32x4 &pa = term == 0 ? p2[bi] : (term == 1 || term == 3 || term == 5) ? p1[bi] : (term == 2 ? p3[bi] : p2[bi]);
+        const u32x4 &pb = term == 0 ? p2[bj] : term == 1 ? p3[bj] : term == 2 ? p1[bj] : term == 3 ? p2[bj] : p1[bj];
+        acc[tile_index(bi, bj, NB)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+            __builtin_bit_cast(bf16x8, pa), __builtin_bit_cast(bf16x8, pb), acc[tile_index(bi, bj, NB)], 0, 0, 0);
+      }
+    }
+  };
+  const float padOne = (PADRHS && c == kr) ? 1.0f : 0.0f;
+  const bool lastLive = (NB - 1) * 16 + c < k;
+  // One phase: products of step s (MMA) beside split of step s + 1 and the gathers D
+  // half-blocks ahead of the split.  s may be -1 (prologue, MMA = false).
+  auto phase = [&](int64_t s, auto MMA_, auto SPLIT_) {
+    constexpr bool MMA = decltype(MMA_)::value, SPLIT = decltype(SPLIT_)::value;
+    if constexpr (SPLIT && !PADRHS) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) rr[j] = r_of(j);  // ratings of step s + 1
+      rP = load_r(s + 2);
+    }
+#pragma unroll
+    for (int bi = 0; bi < NB; ++bi) {
+      if constexpr (MMA) mma_row(bi);
+      if constexpr (SPLIT) {
+        float x[8];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const int hb = 2 * bi + half, slot = hb % D, hbn = (hb + D) % NH;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) x[4 * half + j] = raw[slot][j];
+          if (hbn == 0) {  // the gathers from here on belong to step s + 2
+            unpack_off();
+            offP = load_off(s + 3);
+          }
+          issue(slot, hbn);
+        }
+        if (bi == NB - 1) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            if constexpr (PADRHS) {
+              const float rj = r_of(j) * padOne;  // unconditional: a bpermute cannot sit under a lane mask
+              x[j] = lastLive ? x[j] : rj;
+            } else {
+              x[j] = lastLive ? x[j] : 0.0f;
+            }
+          }
+          if constexpr (PADRHS) rP = load_r(s + 2);
+        }
+        if constexpr (!PADRHS) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) bacc[bi] = fmaf(x[j], rr[j], bacc[bi]);
+        }
+        // whole registers at once: element-wise updates of the operand tuples end up in fresh
+        // registers plus copies
+        unsigned h[4], m[4], l[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const float x0 = x[2 * jj], x1 = x[2 * jj + 1];
+          const unsigned u0 = __builtin_bit_cast(unsigned, x0), u1 = __builtin_bit_cast(unsigned, x1);
+          h[jj] = __builtin_amdgcn_perm(u1, u0, 0x07060302);
+          const float s0 = x0 - __builtin_bit_cast(float, u0 & 0xFFFF0000u);
+          const float s1 = x1 - __builtin_bit_cast(float, u1 & 0xFFFF0000u);
+          const unsigned v0 = __builtin_bit_cast(unsigned, s0), v1 = __builtin_bit_cast(unsigned, s1);
+          m[jj] = __builtin_amdgcn_perm(v1, v0, 0x07060302);
+          const float t0 = s0 - __builtin_bit_cast(float, v0 & 0xFFFF0000u);
+          const float t1 = s1 - __builtin_bit_cast(float, v1 & 0xFFFF0000u);
+          l[jj] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, t1), __builtin_bit_cast(unsigned, t0), 0x07060302);
+        }
+        p1[bi] = u32x4{h[0], h[1], h[2], h[3]};
+        p2[bi] = u32x4{m[0], m[1], m[2], m[3]};
+        p3[bi] = u32x4{l[0], l[1], l[2], l[3]};
+#ifdef YCNR_X6P_SCHED_BARRIER
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+      }
+    }
+  };
+  using yes = std::integral_constant<bool, true>;
+  using no = std::integral_constant<bool, false>;
+  // before the prologue: offsets of step 0 live, ring = first D half-blocks of step 0
+  // (all of step 0 when D = NH), packed inputs one step further
+  offP = load_off(0);
+  rP = load_r(0);
+  unpack_off();
+  offP = load_off(1);
+#pragma unroll
+  for (int hb = 0; hb < D; ++hb) issue(hb, hb % NH);
+  if constexpr (D == NH) {  // the ring holds a whole step: the phase's own gathers are one step on
+    // nothing to do: phase(-1) switches to step 1 at its first half-block
+  }
+  // phase(s) switches off[] to step s + 2 and prefetches the packed offsets of step s + 3, so
+  // entering phase(-1) offP must hold step 1 -- it does.
+  phase(-1, no{}, yes{});
+  for (int64_t s = 0; s + 1 < nsteps; ++s) phase(s, yes{}, yes{});
+  phase(nsteps - 1, yes{}, no{});
+
+  float *sl = a.slabs + (int64_t)u.slab * slab_elems(NB) + lane;
+  if constexpr (PADRHS) {
+    // column kr of the padded Gramian is b: tile (bi, NB-1), lane (g, c = kr), register t holds
+    // b[16 bi + 4 g + t].  Slab format: lane (0, c') carries b[16 cb + c'], the other groups 0.
+    const int src = ((c >> 2) << 4) + kr;
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) {
+      acc_t &tl = acc[tile_index(cb, NB - 1, NB)];
+      float v = 0.0f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float w = bpermute_opaque(src << 2, tl[t]);
+        v = (c & 3) == t ? w : v;
+      }
+      if (g != 0 || (cb == NB - 1 && c >= kr)) v = 0.0f;
+      sl[(NT * 4 + cb) * 64] = v;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (c == kr) tl[t] = 0.0f;
+        if (cb == NB - 1 && 4 * g + t == kr) tl[t] = 0.0f;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) sl[(NT * 4 + cb) * 64] = bacc[cb];
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sl[(t * 4 + r) * 64] = acc[t][r];
+  }
+}
+
+// The bf16x6 Gramian with the gather staged through LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`),
+// two waves per SIMD.
+//
+// als_gram_slab_x6p_kernel's limit is registers: at NB = 7 the accumulators (112), the operands
+// (84) and a ring of gathered floats (28) leave nothing for addresses and temporaries and it
+// spills.  Here the ring lives in LDS instead: a whole step (32 ratings x 16 NB columns, NB KiB
+// per wave) is in flight while the previous one is multiplied, and no register waits for memory.
+//
+//   * One DMA instruction fills one 1-KiB slot (b, h): 16 ratings x the 16 columns of block b.
+//     Lane l fetches 16 bytes: columns 16 b + 4 (l & 3) .. +3 of rating
+//     16 h + 8 ((l >> 2) & 1) + (l >> 3).  With this order the MFMA operand lane (g, c) finds
+//     rating 8 g + j of its column at dword (2 j + (g & 1)) 16 + c of slot (b, g >> 1):
+//     four conflict-free ds_read2_b32 with one address register per block.  14 DMA + 28 LDS reads
+//     per step replace 56 dword loads with 8 address registers.
+//   * Lanes whose rating is past the unit's end, or whose column quad is past the matrix, carry
+//     an out-of-range offset: the DMA writes zeros for them (devtest/dmaprobe.hip).
+//   * Column ids and ratings of a step arrive by DMA too (64 + 64 dwords per step: all lanes
+//     load, the upper half repeats the next step's; a ring of 4 steps), so the loop contains
+//     no load the compiler counts: it would wait vmcnt(0) for such a load and drain the ring.
+//     All LDS reads are inline asm for the same reason; the waits are counted by hand.  Every
+//     phase issues 2 + 2 NB vector-memory operations in a fixed order, so "the two slots of
+//     block b have landed" is vmcnt(2 NB) at every b.  (These two DMAs must not sit under a
+//     lane mask: with `if (lane < 32)` around them one instantiation read stale ratings in
+//     about half of its launches.)
+//   * A slot is refilled only after its reads have returned (lgkmcnt(0)), and the wave drains
+//     its DMA before it ends: LDS is handed to the next workgroup when the wave retires.
+// Needs k % 4 == 0 (16-byte aligned rows) and the fixed matrix < 2 GB.  Results are bitwise
+// those of als_gram_slab_x6_kernel for the tiles; with PADRHS b comes out of the MFMAs.
+typedef __attribute__((address_space(3))) void *lds_void_ptr;
+
+template <int NB, bool PADRHS>
+struct GramX6D {
+  using acc_t = typename MfmaTraits<float>::acc_t;
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  static constexpr int NT = tile_count(NB);
+  static constexpr int NH = 2 * NB;
+  static constexpr int META = NH * 256;           // dword index of the ids / ratings ring
+  static constexpr int LDS_DWORDS = META + 4 * 128;  // per step 64 ids + 64 ratings (the upper halves repeat the next step's)
+  static constexpr unsigned OOB = 0x80000000u;
+
+  // acc += Y^T Y over ratings [beg, beg + n) of indx / vals; PADRHS: column k of the padded
+  // Gramian accumulates b, else bacc does (per lane-group partials, as Gram<>).  `lds` is this
+  // wave's LDS_DWORDS dwords.
+  static __device__ __forceinline__ void accumulate(acc_t (&acc)[NT], float (&bacc)[NB], unsigned *lds,
+                                                    const int32_t *indx, const float *vals, const float *fixed,
+                                                    uint32_t fixedBytes, int k, int64_t beg, int64_t n, int lane) {
+    const int g = lane >> 4, c = lane & 15;
+    const int kr = k - 16 * (NB - 1);
+    const unsigned rowBytes = (unsigned)k * 4u;
+    const unsigned n32 = (unsigned)(n < 0x3fffffff ? n : 0x3fffffff);
+    const int64_t nsteps = (n + 31) >> 5;
+    const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc((void *)fixed, 0, (int)fixedBytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srdI = __builtin_amdgcn_make_buffer_rsrc((void *)(indx + beg), 0, (int)(n32 * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t srdR = __builtin_amdgcn_make_buffer_rsrc((void *)(vals + beg), 0, (int)(n32 * 4u), 0x00020000);
+    const unsigned ldsBase = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned *)lds;
+    // DMA side: this lane's rating inside a half (16 ratings) and its column quad
+    const unsigned rhoL = 8u * ((lane >> 2) & 1) + (lane >> 3);
+    const unsigned quadBytes = (unsigned)(lane & 3) * 16u;
+    // operand side: byte address of (rating 8 g, column c) in slot (0, g >> 1)
+    const unsigned rdBase = ldsBase + (unsigned)(g >> 1) * 1024u + (unsigned)((g & 1) * 16 + c) * 4u;
+
+    u32x4 p1[NB], p2[NB], p3[NB];
+    unsigned offH[2];
+    float rr[8];
+
+    auto meta_dma = [&](int64_t t) {  // ids and ratings of step t (and of t + 1 behind them) -> ring slot t & 3
+      unsigned *slot = lds + META + ((int)t & 3) * 128;
+      const unsigned qb = ((unsigned)t << 7) + (unsigned)lane * 4u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srdI, (lds_void_ptr)slot, 4, qb, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srdR, (lds_void_ptr)(slot + 64), 4, qb, 0, 0, 0);
+    };
+    auto read_offsets = [&](int64_t t) {  // gather offsets of step t for this lane's two DMA ratings
+      const unsigned ma = ldsBase + (unsigned)(META + ((int)t & 3) * 128) * 4u + rhoL * 4u;
+      unsigned id0, id1;
+      asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:64\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(id0), "=&v"(id1) : "v"(ma) : "memory");
+      const unsigned q0 = ((unsigned)t << 5) + rhoL;
+      offH[0] = q0 < n32 ? id0 * rowBytes + quadBytes : OOB;
+      offH[1] = q0 + 16u < n32 ? id1 * rowBytes + quadBytes : OOB;
+    };
+    auto read_r = [&](int64_t t, float (&r)[8]) {  // ratings 8 g .. 8 g + 7 of step t
+      const unsigned ra = ldsBase + (unsigned)(META + ((int)t & 3) * 128 + 64) * 4u + (unsigned)g * 32u;
+      f32x4 r0, r1;
+      asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(r0), "=&v"(r1) : "v"(ra) : "memory");
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { r[j] = r0[j]; r[4 + j] = r1[j]; }
+    };
+    auto gather_block = [&](int b) {  // both halves of block b of the step offH[] belongs to
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_void_ptr)(lds + (2 * b) * 256), 16, offH[0], b * 64, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_void_ptr)(lds + (2 * b + 1) * 256), 16, offH[1], b * 64, 0, 0);
+    };
+    auto mma_row = [&](int bi) {
+#pragma unroll
+      for (int term = 0; term < 6; ++term) {
+#pragma unroll
+        for (int bj = bi; bj < NB; ++bj) {
+          const u32x4 &pa = term == 0 ? p2[bi] : (term == 1 || term == 3 || term == 5) ? p1[bi] : (term == 2 ? p3[bi] : p2[bi]);
+          const u32x4 &pb = term == 0 ? p2[bj] : term == 1 ? p3[bj] : term == 2 ? p1[bj] : term == 3 ? p2[bj] : p1[bj];
+          acc[tile_index(bi, bj, NB)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+              __builtin_bit_cast(bf16x8, pa), __builtin_bit_cast(bf16x8, pb), acc[tile_index(bi, bj, NB)], 0, 0, 0);
+        }
+      }
+    };
+    const float padOne = (PADRHS && c == kr) ? 1.0f : 0.0f;
+    const bool lastLive = (NB - 1) * 16 + c < k;
+    // One phase: products of step s beside the split of step s + 1 and the DMA of step s + 2.
+    auto phase = [&](int64_t s, auto MMA_, auto SPLIT_) {
+      constexpr bool MMA = decltype(MMA_)::value, SPLIT = decltype(SPLIT_)::value;
+      if constexpr (SPLIT) {
+        meta_dma(s + 4);       // into the slot of step s, whose last reader was phase s - 1
+        read_offsets(s + 2);   // issued two phases ago: behind every vmcnt wait of phase s - 1
+        if constexpr (!PADRHS) read_r(s + 1, rr);
+      }
+#pragma unroll
+      for (int bi = 0; bi < NB; ++bi) {
+        f32x2 x01, x23, x45, x67;
+        if constexpr (SPLIT) {
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NH) : "memory");  // block bi of step s + 1 has landed
+          const unsigned ra = rdBase + (unsigned)bi * 2048u;
+          asm volatile("ds_read2_b32 %0, %4 offset1:32\n\tds_read2_b32 %1, %4 offset0:64 offset1:96\n\t"
+                       "ds_read2_b32 %2, %4 offset0:128 offset1:160\n\tds_read2_b32 %3, %4 offset0:192 offset1:224"
+                       : "=&v"(x01), "=&v"(x23), "=&v"(x45), "=&v"(x67) : "v"(ra) : "memory");
+        }
+        if constexpr (MMA) mma_row(bi);
+        if constexpr (SPLIT) {
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x01), "+v"(x23), "+v"(x45), "+v"(x67)::"memory");
+          gather_block(bi);  // step s + 2 into the slots just read
+          float x[8] = {x01[0], x01[1], x23[0], x23[1], x45[0], x45[1], x67[0], x67[1]};
+          if (bi == NB - 1) {
+            if constexpr (PADRHS) {
+              float rv[8];
+              read_r(s + 1, rv);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) x[j] = lastLive ? x[j] : rv[j] * padOne;
+            } else {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) x[j] = lastLive ? x[j] : 0.0f;
+            }
+          }
+          if constexpr (!PADRHS) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bacc[bi] = fmaf(x[j], rr[j], bacc[bi]);
+          }
+          unsigned h[4], m[4], l[4];
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const float x0 = x[2 * jj], x1 = x[2 * jj + 1];
+            const unsigned u0 = __builtin_bit_cast(unsigned, x0), u1 = __builtin_bit_cast(unsigned, x1);
+            h[jj] = __builtin_amdgcn_perm(u1, u0, 0x07060302);
+            const float s0 = x0 - __builtin_bit_cast(float, u0 & 0xFFFF0000u);
+            const float s1 = x1 - __builtin_bit_cast(float, u1 & 0xFFFF0000u);
+            const unsigned v0 = __builtin_bit_cast(unsigned, s0), v1 = __builtin_bit_cast(unsigned, s1);
+            m[jj] = __builtin_amdgcn_perm(v1, v0, 0x07060302);
+            const float t0 = s0 - __builtin_bit_cast(float, v0 & 0xFFFF0000u);
+            const float t1 = s1 - __builtin_bit_cast(float, v1 & 0xFFFF0000u);
+            l[jj] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, t1), __builtin_bit_cast(unsigned, t0), 0x07060302);
+          }
+          p1[bi] = u32x4{h[0], h[1], h[2], h[3]};
+          p2[bi] = u32x4{m[0], m[1], m[2], m[3]};
+          p3[bi] = u32x4{l[0], l[1], l[2], l[3]};
+        }
+      }
+    };
+    using yes = std::integral_constant<bool, true>;
+    using no = std::integral_constant<bool, false>;
+    // ids / ratings of steps 0..2, then the whole of step 0 into the ring (same issue order as
+    // a phase: 2 NB gathers last, so phase(-1) can use the same counted waits)
+    meta_dma(0);
+    meta_dma(1);
+    meta_dma(2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    read_offsets(0);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) gather_block(b);
+    phase(-1, no{}, yes{});
+    for (int64_t s = 0; s + 1 < nsteps; ++s) phase(s, yes{}, yes{});
+    phase(nsteps - 1, yes{}, no{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing of this wave may land in LDS after it ends
+  }
+
+  // PADRHS: move b out of column kr of the padded Gramian into the slab's b-partials (lane
+  // (0, c') carries b[16 cb + c'], the other lane groups 0) and zero the padded entries.
+  static __device__ __forceinline__ void extract_rhs(acc_t (&acc)[NT], float (&bacc)[NB], int k, int lane) {
+    const int g = lane >> 4, c = lane & 15;
+    const int kr = k - 16 * (NB - 1);
+    const int src = ((c >> 2) << 4) + kr;
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) {
+      acc_t &tl = acc[tile_index(cb, NB - 1, NB)];
+      float v = 0.0f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float w = bpermute_opaque(src << 2, tl[t]);
+        v = (c & 3) == t ? w : v;
+      }
+      if (g != 0 || (cb == NB - 1 && c >= kr)) v = 0.0f;
+      bacc[cb] = v;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (c == kr) tl[t] = 0.0f;
+        if (cb == NB - 1 && 4 * g + t == kr) tl[t] = 0.0f;
+      }
+    }
+  }
+};
+
+template <int NB, bool PADRHS>
+__global__ __launch_bounds__(64, 2) void als_gram_slab_x6d_kernel(StepArgs<float> a) {
+  using G = GramX6D<NB, PADRHS>;
+  using acc_t = typename G::acc_t;
+  constexpr int NT = G::NT;
+  __shared__ __attribute__((aligned(16))) unsigned lds[G::LDS_DWORDS];
+  const int lane = threadIdx.x;
+  const Unit u = a.units[blockIdx.x];
+  acc_t acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = acc_t{0.0f, 0.0f, 0.0f, 0.0f};
+  float bacc[NB];
+#pragma unroll
+  for (int cb = 0; cb < NB; ++cb) bacc[cb] = 0.0f;
+  G::accumulate(acc, bacc, lds, a.indx, a.vals, a.fixed, a.fixedBytes, a.k, u.beg, u.end - u.beg, lane);
+  if constexpr (PADRHS) G::extract_rhs(acc, bacc, a.k, lane);
   float *sl = a.slabs + (int64_t)u.slab * slab_elems(NB) + lane;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {

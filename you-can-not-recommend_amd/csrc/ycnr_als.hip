@@ -179,6 +179,24 @@ void (*slab_x6_kernel())(StepArgs<T>) { return nullptr; }
 YCNR_X6(1) YCNR_X6(2) YCNR_X6(3) YCNR_X6(4) YCNR_X6(5) YCNR_X6(6) YCNR_X6(7) YCNR_X6(8)
 #undef YCNR_X6
 
+// the two-waves-per-SIMD arrangement of the same kernel, where its registers fit
+template <typename T, int NB>
+void (*slab_x6p_kernel(int))(StepArgs<T>) { return nullptr; }
+#define YCNR_X6P(NBV) \
+  template <>         \
+  void (*slab_x6p_kernel<float, NBV>(int k))(StepArgs<float>) { return k < 16 * NBV ? als_gram_slab_x6p_kernel<NBV, true> : als_gram_slab_x6p_kernel<NBV, false>; }
+YCNR_X6P(1) YCNR_X6P(2) YCNR_X6P(3) YCNR_X6P(4) YCNR_X6P(5) YCNR_X6P(6)
+#undef YCNR_X6P
+
+// ... and with the gather staged through LDS by LDS-DMA: fits two waves per SIMD up to k = 112
+template <typename T, int NB>
+void (*slab_x6d_kernel(int))(StepArgs<T>) { return nullptr; }
+#define YCNR_X6D(NBV) \
+  template <>         \
+  void (*slab_x6d_kernel<float, NBV>(int k))(StepArgs<float>) { return k % 4 ? nullptr : k < 16 * NBV ? als_gram_slab_x6d_kernel<NBV, true> : als_gram_slab_x6d_kernel<NBV, false>; }
+YCNR_X6D(1) YCNR_X6D(2) YCNR_X6D(3) YCNR_X6D(4) YCNR_X6D(5) YCNR_X6D(6) YCNR_X6D(7)
+#undef YCNR_X6D
+
 // SLABX6: split chunks go through the bf16x6 Gramian kernel (plain slab layout), so the reduce
 // kernel reads plain slabs whatever form the fused kernel uses.
 template <typename T, int NB, bool LDS_SOLVER, bool EDGE, bool SLABX6>
@@ -186,6 +204,8 @@ int launch_nbe(StepArgs<T> args, int64_t nUnits, int64_t nSplitUnits, int64_t nS
                hipEvent_t *ev /* 5 events or null */, const DualPlan &dp) {
   const size_t lds = SolverFor<T, NB, LDS_SOLVER>::type::lds_bytes();
   void (*k0)(StepArgs<T>) = SLABX6 ? slab_x6_kernel<T, NB>() : als_gram_slab_kernel<T, NB, EDGE && !SLABX6>;
+  if (SLABX6 && slab_x6p_kernel<T, NB>(args.k) && getenv("YCNR_X6P")) k0 = slab_x6p_kernel<T, NB>(args.k);
+  if (SLABX6 && slab_x6d_kernel<T, NB>(args.k) && !getenv("YCNR_NO_X6D") && !getenv("YCNR_X6P")) k0 = slab_x6d_kernel<T, NB>(args.k);
   auto k1 = als_gram_solve_kernel<T, NB, LDS_SOLVER, EDGE>;
   auto k2 = als_reduce_solve_kernel<T, NB, LDS_SOLVER, EDGE && !SLABX6>;
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k1),
