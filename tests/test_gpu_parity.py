@@ -181,6 +181,38 @@ def test_every_row_length_class(als, k):
         assert (err <= np.maximum(16 * conds * EPS32, 2e-6)).all()
 
 
+@pytest.mark.parametrize("k", [64, 100])
+def test_many_rows_at_full_occupancy(als, k):
+    """Tens of thousands of rows in one launch, so that every CU holds its full set of workgroups
+    while rows start and finish: the LDS-DMA staged Gramian (k % 16 == 0: right-hand side on the
+    VALU; otherwise out of the padded Gramian) showed errors only under that load during
+    development, none with a handful of workgroups.  Every row against float64."""
+    users, items = 30000, 20000
+    rng = np.random.default_rng(100 + k)
+    lens = np.clip(rng.lognormal(np.log(110), 0.8, users).astype(np.int64), 1, 3000)
+    rowPtr = np.zeros(users + 1, np.int64)
+    np.cumsum(lens, out=rowPtr[1:])
+    # distinct columns per row: a random start and stride walk of the item range
+    start = rng.integers(0, items, users)
+    indx = np.empty(rowPtr[-1], np.int32)
+    for u in range(users):
+        indx[rowPtr[u]:rowPtr[u + 1]] = np.sort((start[u] + 7 * np.arange(lens[u])) % items)
+    vals = rng.integers(1, 11, rowPtr[-1]).astype(np.float32)
+    bu = Csr(users, items, rowPtr, indx, vals)
+    U = np.zeros((users, k), np.float32)
+    V = (rng.standard_normal((items, k)) / np.sqrt(k)).astype(np.float32)
+    dev = als.AlsDevice(k, users, items)
+    dev.set_ratings("byUser", bu.rowPtr, bu.indx, bu.vals)
+    dev.set_factors("byUser", U)
+    dev.set_factors("byItem", V)
+    info = dev.step("byUser")
+    got = dev.get_factors("byUser")
+    dev.destroy()
+    assert info.fusedRows > 10000 and info.dualRows > 2000
+    want, conds = numpy_step(0.05, k, bu, V, U)
+    check_rows(got, want, conds, np.float32)
+
+
 @pytest.mark.parametrize("k", [20, 100, 128])
 def test_float64_solvers_agree(als, k):
     """useDoublePrecision: the register-resident f64 MFMA Cholesky (default) and the plain LDS

@@ -1290,7 +1290,8 @@ __device__ __forceinline__ float bpermute_opaque(int byteAddr, float v) {
   return r;
 }
 
-// The same bf16x6 Gramian arranged to fit TWO waves per SIMD (<= 256 registers per lane).
+// The bf16x6 Gramian with the gather staged through LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`),
+// two waves per SIMD.
 //
 // Why two waves: measured with devtest/mfmarate.hip, one wave cannot hide vector work behind
 // v_mfma_f32_16x16x32_bf16 -- an MFMA blocks its own wave's issue for the 16 cycles it occupies
@@ -1298,219 +1299,17 @@ __device__ __forceinline__ float bpermute_opaque(int byteAddr, float v) {
 // each, 36.9 with 6).  Two waves of a SIMD do overlap: the pair sustains an MFMA every 16
 // cycles with 2 VALU instructions each, every 17 with 3.  The split needs ~2 per MFMA.
 //
-// Registers: the 3 x NB operand registers are single-buffered.  Tiles are visited row by row
-// (bi, bj >= bi), so after row bi nothing reads block bi again and the NEXT step's block bi is
-// split into the same registers while rows bi+1.. still multiply.  Gathered floats wait in a
-// ring of D half-blocks (4 ratings x 16 columns per lane: 4 registers) that is refilled D
-// half-blocks ahead -- half a step for NB >= 5, a whole step below.  Column ids and ratings
-// travel as one register per step (lane L holds rating 32 s + L) and reach the lanes that
-// need them through ds_bpermute.
+// Registers (<= 256 per lane for two waves): the 3 x NB operand registers are single-buffered.
+// Tiles are visited row by row (bi, bj >= bi), so after row bi nothing reads block bi again and
+// the NEXT step's block bi is split into the same registers while rows bi+1.. still multiply.
+// The gathered floats wait in LDS, not in registers (at NB = 7 accumulators 112 + operands 84
+// leave no room for a register ring): a whole step (32 ratings x 16 NB columns, NB KiB per
+// wave) is in flight while the previous one is multiplied.
 //
 // PADRHS (k < 16 NB): the ratings ride in the first unused column of the last block, so
 // b = Y^T r comes out of the MFMAs as column k of the padded Gramian: no VALU multiply-adds and
 // no accumulators for it.  It is moved to the slab's b-partials at the end and the padded
 // entries are zeroed, so the slab is indistinguishable from the other kernels'.
-template <int NB, bool PADRHS>
-__global__ __launch_bounds__(64, 2) void als_gram_slab_x6p_kernel(StepArgs<float> a) {
-  using acc_t = typename MfmaTraits<float>::acc_t;
-  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  constexpr int NT = tile_count(NB);
-  constexpr int NH = 2 * NB;               // half-blocks per step
-  constexpr int D = NB >= 5 ? NB : 2 * NB; // ring slots = prefetch distance in half-blocks
-  constexpr unsigned OOB = 0x80000000u;
-  const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
-  const Unit u = a.units[blockIdx.x];
-  const int k = a.k;
-  const int kr = k - 16 * (NB - 1);  // columns in use in the last block; PADRHS: kr < 16
-  const unsigned rowBytes = (unsigned)k * 4u;
-  const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc((void *)a.fixed, 0, (int)a.fixedBytes, 0x00020000);
-  const int64_t n = u.end - u.beg;
-  const int64_t nsteps = (n + 31) >> 5;
-
-  acc_t acc[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) acc[t] = acc_t{0.0f, 0.0f, 0.0f, 0.0f};
-  float bacc[PADRHS ? 1 : NB];
-#pragma unroll
-  for (int cb = 0; cb < (PADRHS ? 1 : NB); ++cb) bacc[cb] = 0.0f;
-  u32x4 p1[NB], p2[NB], p3[NB];
-  float raw[D][4];
-  unsigned off[8];
-  float rr[PADRHS ? 1 : 8];
-  unsigned offP;  // byte offset of the gathered row of rating 32 t + (lane & 31), or OOB
-  float rP;       // its rating value, or 0
-
-  // packed per-step inputs of step t (may be past the end: OOB / 0).  Buffer loads bounded to
-  // the unit: past its end they return 0 without a branch (a plain load under "q < n" is turned
-  // into a conditional block with a full vmcnt(0) wait by the compiler).
-  const unsigned unitBytes = (unsigned)(n < 0x3fffffff ? n : 0x3fffffff) * 4u;
-  const __amdgpu_buffer_rsrc_t srdI = __builtin_amdgcn_make_buffer_rsrc((void *)(a.indx + u.beg), 0, (int)unitBytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t srdR = __builtin_amdgcn_make_buffer_rsrc((void *)(a.vals + u.beg), 0, (int)unitBytes, 0x00020000);
-  const unsigned lane4 = (unsigned)(lane & 31) * 4u;
-  auto load_off = [&](int64_t t) {
-    const unsigned qb = ((unsigned)t << 7) + lane4;
-    const unsigned id = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(srdI, qb, 0, 0);
-    // past the end id = 0: OR-ing the marker in keeps the load out of any "if (valid)" block
-    return id * rowBytes | (qb < unitBytes ? 0u : OOB);
-  };
-  auto load_r = [&](int64_t t) {
-    const unsigned qb = ((unsigned)t << 7) + lane4;
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srdR, qb, 0, 0));
-  };
-  const int bpBase = g << 5;  // ds_bpermute byte address of lane 8 g
-  auto unpack_off = [&]() {
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-      off[j] = (unsigned)__builtin_amdgcn_ds_bpermute(bpBase + 4 * j, (int)offP) + (unsigned)c * 4u;
-  };
-  auto r_of = [&](int j) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bpBase + 4 * j, __builtin_bit_cast(int, rP))); };
-  auto issue = [&](int slot, int hbn) {  // gather half-block hbn (of the step off[] belongs to) into a ring slot
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      raw[slot][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd, off[4 * (hbn & 1) + j], (hbn >> 1) * 64, 0));
-  };
-  auto mma_row = [&](int bi) {
-    // product type outermost: consecutive MFMAs update different tiles of the row (smallest
-    // terms first per tile, as in als_gram_slab_x6_kernel, so the two kernels agree bitwise)
-#pragma unroll
-    for (int term = 0; term < 6; ++term) {
-#pragma unroll
-      for (int bj = bi; bj < NB; ++bj) {
-        const u32x4 &pa = term == 0 ? p2[bi] : (term == 1 || term == 3 || term == 5) ? p1[bi] : (term == 2 ? p3[bi] : p2[bi]);
-        const u32x4 &pb = term == 0 ? p2[bj] : term == 1 ? p3[bj] : term == 2 ? p1[bj] : term == 3 ? p2[bj] : p1[bj];
-        acc[tile_index(bi, bj, NB)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-            __builtin_bit_cast(bf16x8, pa), __builtin_bit_cast(bf16x8, pb), acc[tile_index(bi, bj, NB)], 0, 0, 0);
-      }
-    }
-  };
-  const float padOne = (PADRHS && c == kr) ? 1.0f : 0.0f;
-  const bool lastLive = (NB - 1) * 16 + c < k;
-  // One phase: products of step s (MMA) beside split of step s + 1 and the gathers D
-  // half-blocks ahead of the split.  s may be -1 (prologue, MMA = false).
-  auto phase = [&](int64_t s, auto MMA_, auto SPLIT_) {
-    constexpr bool MMA = decltype(MMA_)::value, SPLIT = decltype(SPLIT_)::value;
-    if constexpr (SPLIT && !PADRHS) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) rr[j] = r_of(j);  // ratings of step s + 1
-      rP = load_r(s + 2);
-    }
-#pragma unroll
-    for (int bi = 0; bi < NB; ++bi) {
-      if constexpr (MMA) mma_row(bi);
-      if constexpr (SPLIT) {
-        float x[8];
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          const int hb = 2 * bi + half, slot = hb % D, hbn = (hb + D) % NH;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) x[4 * half + j] = raw[slot][j];
-          if (hbn == 0) {  // the gathers from here on belong to step s + 2
-            unpack_off();
-            offP = load_off(s + 3);
-          }
-          issue(slot, hbn);
-        }
-        if (bi == NB - 1) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            if constexpr (PADRHS) {
-              const float rj = r_of(j) * padOne;  // unconditional: a bpermute cannot sit under a lane mask
-              x[j] = lastLive ? x[j] : rj;
-            } else {
-              x[j] = lastLive ? x[j] : 0.0f;
-            }
-          }
-          if constexpr (PADRHS) rP = load_r(s + 2);
-        }
-        if constexpr (!PADRHS) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) bacc[bi] = fmaf(x[j], rr[j], bacc[bi]);
-        }
-        // whole registers at once: element-wise updates of the operand tuples end up in fresh
-        // registers plus copies
-        unsigned h[4], m[4], l[4];
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          const float x0 = x[2 * jj], x1 = x[2 * jj + 1];
-          const unsigned u0 = __builtin_bit_cast(unsigned, x0), u1 = __builtin_bit_cast(unsigned, x1);
-          h[jj] = __builtin_amdgcn_perm(u1, u0, 0x07060302);
-          const float s0 = x0 - __builtin_bit_cast(float, u0 & 0xFFFF0000u);
-          const float s1 = x1 - __builtin_bit_cast(float, u1 & 0xFFFF0000u);
-          const unsigned v0 = __builtin_bit_cast(unsigned, s0), v1 = __builtin_bit_cast(unsigned, s1);
-          m[jj] = __builtin_amdgcn_perm(v1, v0, 0x07060302);
-          const float t0 = s0 - __builtin_bit_cast(float, v0 & 0xFFFF0000u);
-          const float t1 = s1 - __builtin_bit_cast(float, v1 & 0xFFFF0000u);
-          l[jj] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, t1), __builtin_bit_cast(unsigned, t0), 0x07060302);
-        }
-        p1[bi] = u32x4{h[0], h[1], h[2], h[3]};
-        p2[bi] = u32x4{m[0], m[1], m[2], m[3]};
-        p3[bi] = u32x4{l[0], l[1], l[2], l[3]};
-#ifdef YCNR_X6P_SCHED_BARRIER
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-      }
-    }
-  };
-  using yes = std::integral_constant<bool, true>;
-  using no = std::integral_constant<bool, false>;
-  // before the prologue: offsets of step 0 live, ring = first D half-blocks of step 0
-  // (all of step 0 when D = NH), packed inputs one step further
-  offP = load_off(0);
-  rP = load_r(0);
-  unpack_off();
-  offP = load_off(1);
-#pragma unroll
-  for (int hb = 0; hb < D; ++hb) issue(hb, hb % NH);
-  if constexpr (D == NH) {  // the ring holds a whole step: the phase's own gathers are one step on
-    // nothing to do: phase(-1) switches to step 1 at its first half-block
-  }
-  // phase(s) switches off[] to step s + 2 and prefetches the packed offsets of step s + 3, so
-  // entering phase(-1) offP must hold step 1 -- it does.
-  phase(-1, no{}, yes{});
-  for (int64_t s = 0; s + 1 < nsteps; ++s) phase(s, yes{}, yes{});
-  phase(nsteps - 1, yes{}, no{});
-
-  float *sl = a.slabs + (int64_t)u.slab * slab_elems(NB) + lane;
-  if constexpr (PADRHS) {
-    // column kr of the padded Gramian is b: tile (bi, NB-1), lane (g, c = kr), register t holds
-    // b[16 bi + 4 g + t].  Slab format: lane (0, c') carries b[16 cb + c'], the other groups 0.
-    const int src = ((c >> 2) << 4) + kr;
-#pragma unroll
-    for (int cb = 0; cb < NB; ++cb) {
-      acc_t &tl = acc[tile_index(cb, NB - 1, NB)];
-      float v = 0.0f;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const float w = bpermute_opaque(src << 2, tl[t]);
-        v = (c & 3) == t ? w : v;
-      }
-      if (g != 0 || (cb == NB - 1 && c >= kr)) v = 0.0f;
-      sl[(NT * 4 + cb) * 64] = v;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        if (c == kr) tl[t] = 0.0f;
-        if (cb == NB - 1 && 4 * g + t == kr) tl[t] = 0.0f;
-      }
-    }
-  } else {
-#pragma unroll
-    for (int cb = 0; cb < NB; ++cb) sl[(NT * 4 + cb) * 64] = bacc[cb];
-  }
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) sl[(t * 4 + r) * 64] = acc[t][r];
-  }
-}
-
-// The bf16x6 Gramian with the gather staged through LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`),
-// two waves per SIMD.
-//
-// als_gram_slab_x6p_kernel's limit is registers: at NB = 7 the accumulators (112), the operands
-// (84) and a ring of gathered floats (28) leave nothing for addresses and temporaries and it
-// spills.  Here the ring lives in LDS instead: a whole step (32 ratings x 16 NB columns, NB KiB
-// per wave) is in flight while the previous one is multiplied, and no register waits for memory.
 //
 //   * One DMA instruction fills one 1-KiB slot (b, h): 16 ratings x the 16 columns of block b.
 //     Lane l fetches 16 bytes: columns 16 b + 4 (l & 3) .. +3 of rating
@@ -1650,6 +1449,15 @@ struct GramX6D {
           if constexpr (!PADRHS) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) bacc[bi] = fmaf(x[j], rr[j], bacc[bi]);
+            // Keeps the compiler from pairing the multiply-adds of two blocks into v_pk_fma_f32
+            // (packed float32 beside MFMAs is slower anyway).  With that pairing, and only with many
+            // workgroups per CU, the copies it took of x right after the wait above held OLD values
+            // in lanes 48..63 of block 0 (tiles right, b wrong in ~7 % of rows; devtest/x6many.hip
+            // built with -DYCNR_X6D_ALLOW_PK reproduces it).  A sentinel word read behind the eight
+            // values never arrived late in 2.5 M reads, so the wait itself holds; the cause is open.
+#ifndef YCNR_X6D_ALLOW_PK
+            asm volatile("" : "+v"(bacc[bi]));
+#endif
           }
           unsigned h[4], m[4], l[4];
 #pragma unroll
@@ -1774,6 +1582,29 @@ __global__ __launch_bounds__(64, sizeof(T) == 8 ? 1 : YCNR_FUSED_WAVES_PER_SIMD)
   SolverFor<T, NB, LDS_SOLVER>::type::run(acc, bacc, reinterpret_cast<T *>(smem), a.k, lam,
                                           a.solved + (int64_t)u.row * a.k, u.row, a.err, lane);
 #endif
+}
+
+// Kernel 1b': the fused row kernel with the bf16x6 / LDS-DMA Gramian (GramX6D) in place of the
+// float32-MFMA one; the solve is unchanged.  float32, k % 4 == 0, k <= 112, fixed matrix < 2 GB.
+template <int NB, bool PADRHS, bool LDS_SOLVER>
+__global__ __launch_bounds__(64, 2) void als_gram_solve_x6d_kernel(StepArgs<float> a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using G = GramX6D<NB, PADRHS>;
+  using acc_t = typename G::acc_t;
+  __shared__ __attribute__((aligned(16))) unsigned ring[G::LDS_DWORDS];
+  const int lane = threadIdx.x;
+  const Unit u = a.units[a.firstFused + blockIdx.x];
+  acc_t acc[G::NT];
+#pragma unroll
+  for (int t = 0; t < G::NT; ++t) acc[t] = acc_t{0.0f, 0.0f, 0.0f, 0.0f};
+  float bacc[NB];
+#pragma unroll
+  for (int cb = 0; cb < NB; ++cb) bacc[cb] = 0.0f;
+  G::accumulate(acc, bacc, ring, a.indx, a.vals, a.fixed, a.fixedBytes, a.k, u.beg, u.end - u.beg, lane);
+  if constexpr (PADRHS) G::extract_rhs(acc, bacc, a.k, lane);
+  const float lam = (float)(a.lambda * (double)(u.end - u.beg));
+  SolverFor<float, NB, LDS_SOLVER>::type::run(acc, bacc, reinterpret_cast<float *>(smem), a.k, lam,
+                                              a.solved + (int64_t)u.row * a.k, u.row, a.err, lane);
 }
 
 // Kernel 1c: the same row solve in its DUAL form, for rows with fewer ratings than factors.

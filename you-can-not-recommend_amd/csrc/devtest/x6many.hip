@@ -1,0 +1,99 @@
+// Many short units at once (8 blocks per CU): als_gram_slab_x6d_kernel against the float32-MFMA
+// slab kernel, unit by unit.  x6many <nb:4|7> <k> <n> <units> [ldspad]
+#include "../als_kernels.hip.h"
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <vector>
+#include <random>
+using namespace ycnr;
+template <int NB, bool PAD>
+int run(int k, int n, int units, int items) {
+  std::mt19937 rng(7);
+  std::normal_distribution<float> nd(0.f, 1.f / std::sqrt((float)k));
+  std::vector<float> V((size_t)items * k), vals((size_t)units * n);
+  std::vector<int32_t> indx((size_t)units * n);
+  for (auto &v : V) v = nd(rng);
+  for (size_t i = 0; i < indx.size(); ++i) { indx[i] = rng() % items; vals[i] = 1 + (rng() % 10); }
+  std::vector<Unit> us(units);
+  for (int u = 0; u < units; ++u) us[u] = Unit{(int64_t)u * n, (int64_t)(u + 1) * n, u, u};
+  float *dV, *dvals, *dA, *dB, *dz; int32_t *dindx; Unit *du;
+  const size_t se = slab_elems(NB);
+  hipMalloc(&dV, V.size() * 4); hipMalloc(&dvals, vals.size() * 4 + 64); hipMalloc(&dindx, indx.size() * 4 + 64); hipMalloc(&du, sizeof(Unit) * units);
+  hipMalloc(&dA, se * 4 * units); hipMalloc(&dB, se * 4 * units); hipMalloc(&dz, 2048); hipMemset(dz, 0, 2048);
+  hipMemcpy(dV, V.data(), V.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dvals, vals.data(), vals.size() * 4, hipMemcpyHostToDevice);
+  hipMemcpy(dindx, indx.data(), indx.size() * 4, hipMemcpyHostToDevice); hipMemcpy(du, us.data(), sizeof(Unit) * units, hipMemcpyHostToDevice);
+  StepArgs<float> a{du, nullptr, dindx, dvals, dV, dz, nullptr, dA, nullptr, 0.05, k, 0, 0, (uint32_t)(V.size() * 4)};
+  hipLaunchKernelGGL((als_gram_slab_kernel<float, NB, false>), dim3(units), dim3(64), 0, 0, a);
+  a.slabs = dB;
+#ifdef YCNR_X6D_DEBUG_RR
+  float *dbg; const size_t dbgN = (size_t)units * 64 * 64 * 8;
+  hipMalloc(&dbg, dbgN * 4); hipMemset(dbg, 0, dbgN * 4);
+  hipMemcpyToSymbol(HIP_SYMBOL(g_debug_rr), &dbg, sizeof dbg);
+#endif
+  hipLaunchKernelGGL((als_gram_slab_x6d_kernel<NB, PAD>), dim3(units), dim3(64), 0, 0, a);
+  hipError_t e = hipDeviceSynchronize();
+#if defined(YCNR_X6D_SENTINEL)
+  { unsigned h[8]; hipMemcpyFromSymbol(h, HIP_SYMBOL(g_probe_late), sizeof h);
+    printf("sentinel: %u block reads had to spin, %u gave up; %u phases\n", h[0], h[1], h[7]); }
+#endif
+  std::vector<float> A(se * units), B(se * units);
+  hipMemcpy(A.data(), dA, A.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(B.data(), dB, B.size() * 4, hipMemcpyDeviceToHost);
+#ifdef YCNR_X6D_DEBUG_RR
+  {
+    std::vector<float> D(dbgN);
+    hipMemcpy(D.data(), dbg, dbgN * 4, hipMemcpyDeviceToHost);
+    const int steps = (n + 31) / 32; long wrong = 0; int shownD = 0;
+    // slots 0..NB-1 hold the running b partials of the lane after the step (block NB-1 of that step not yet added)
+    for (int u = 0; u < units; ++u) {
+      std::vector<double> part((size_t)64 * NB, 0.0);
+      for (int st = 0; st < steps && st < 64; ++st) {
+        for (int lane = 0; lane < 64; ++lane) for (int cb = 0; cb < NB; ++cb) for (int j = 0; j < 8; ++j) {
+          const int q = st * 32 + 8 * (lane >> 4) + j, col = cb * 16 + (lane & 15);
+          if (q < n && col < k) part[lane * NB + cb] += (double)V[(size_t)indx[(size_t)u * n + q] * k + col] * vals[(size_t)u * n + q];
+        }
+        for (int lane = 0; lane < 64; ++lane) for (int cb = 0; cb < NB; ++cb) {
+          const float got = D[(((size_t)u * 64 + st) * 64 + lane) * 8 + cb];
+          const double want = part[lane * NB + cb];
+          if (std::fabs(got - want) > 1e-3) {
+            ++wrong;
+            if (shownD++ < 24) {
+              // candidates for what was added instead of this step's contribution
+              auto contrib = [&](int sx, int sr) { double c = 0; for (int j = 0; j < 8; ++j) { const int qx = sx * 32 + 8 * (lane >> 4) + j, qr = sr * 32 + 8 * (lane >> 4) + j, col = cb * 16 + (lane & 15);
+                  if (qx >= 0 && qx < n && qr >= 0 && qr < n) c += (double)V[(size_t)indx[(size_t)u * n + qx] * k + col] * vals[(size_t)u * n + qr]; } return c; };
+              printf("  unit %d step %d lane %d (g %d c %d) block %d: added %g instead of %g; x(st)r(st-1) %g  x(st-1)r(st) %g  x(st)r(st+1) %g x(st+1)r(st) %g\n", u, st, lane, lane >> 4, lane & 15, cb,
+                     got - (want - contrib(st, st)), contrib(st, st), contrib(st, st - 1), contrib(st - 1, st), contrib(st, st + 1), contrib(st + 1, st));
+            }
+            part[lane * NB + cb] = got;
+          }
+        }
+      }
+    }
+    printf("rr values wrong: %ld\n", wrong);
+  }
+#endif
+  const size_t ntile = (size_t)tile_count(NB) * 4 * 64;
+  int badUnits = 0, shown = 0;
+  for (int u = 0; u < units; ++u) {
+    const float *pa = &A[se * u], *pb = &B[se * u];
+    double norm = 0, md = 0; int badTiles = 0;
+    for (size_t i = 0; i < ntile; ++i) norm = std::fmax(norm, std::fabs((double)pa[i]));
+    std::vector<int> tb;
+    for (int t = 0; t < tile_count(NB); ++t) { double d = 0; for (int i = 0; i < 256; ++i) d = std::fmax(d, std::fabs((double)pa[t * 256 + i] - pb[t * 256 + i])); if (d > 1e-4 * norm) { ++badTiles; tb.push_back(t); } md = std::fmax(md, d); }
+    double bd = 0, bn = 1e-30;
+    for (int cb = 0; cb < NB; ++cb) for (int c = 0; c < 16; ++c) { double sa = 0, sb = 0; for (int g = 0; g < 4; ++g) { sa += pa[ntile + cb * 64 + g * 16 + c]; sb += pb[ntile + cb * 64 + g * 16 + c]; } bd = std::fmax(bd, std::fabs(sa - sb)); bn = std::fmax(bn, std::fabs(sa)); }
+    if (badTiles || bd > 1e-4 * bn) {
+      ++badUnits;
+      if (shown++ < 6) { printf("unit %d: %d bad tiles (max diff %.3g of %.3g), b diff %.3g of %.3g; tiles:", u, badTiles, md, norm, bd, bn); for (int t : tb) printf(" %d", t); printf("\n"); }
+    }
+  }
+  printf("%s: NB=%d k=%d n=%d units=%d: %d bad units\n", hipGetErrorString(e), NB, k, n, units, badUnits);
+  return badUnits;
+}
+int main(int argc, char **argv) {
+  const int nb = atoi(argv[1]), k = atoi(argv[2]), n = atoi(argv[3]), units = atoi(argv[4]);
+  int bad = 0;
+  if (nb == 4) bad = k < 64 ? run<4, true>(k, n, units, 20000) : run<4, false>(k, n, units, 20000);
+  if (nb == 7) bad = k < 112 ? run<7, true>(k, n, units, 20000) : run<7, false>(k, n, units, 20000);
+  return bad != 0;
+}

@@ -179,22 +179,22 @@ void (*slab_x6_kernel())(StepArgs<T>) { return nullptr; }
 YCNR_X6(1) YCNR_X6(2) YCNR_X6(3) YCNR_X6(4) YCNR_X6(5) YCNR_X6(6) YCNR_X6(7) YCNR_X6(8)
 #undef YCNR_X6
 
-// the two-waves-per-SIMD arrangement of the same kernel, where its registers fit
-template <typename T, int NB>
-void (*slab_x6p_kernel(int))(StepArgs<T>) { return nullptr; }
-#define YCNR_X6P(NBV) \
-  template <>         \
-  void (*slab_x6p_kernel<float, NBV>(int k))(StepArgs<float>) { return k < 16 * NBV ? als_gram_slab_x6p_kernel<NBV, true> : als_gram_slab_x6p_kernel<NBV, false>; }
-YCNR_X6P(1) YCNR_X6P(2) YCNR_X6P(3) YCNR_X6P(4) YCNR_X6P(5) YCNR_X6P(6)
-#undef YCNR_X6P
-
-// ... and with the gather staged through LDS by LDS-DMA: fits two waves per SIMD up to k = 112
+// the same Gramian with the gather staged through LDS by LDS-DMA: fits two waves per SIMD up to k = 112
 template <typename T, int NB>
 void (*slab_x6d_kernel(int))(StepArgs<T>) { return nullptr; }
 #define YCNR_X6D(NBV) \
   template <>         \
   void (*slab_x6d_kernel<float, NBV>(int k))(StepArgs<float>) { return k % 4 ? nullptr : k < 16 * NBV ? als_gram_slab_x6d_kernel<NBV, true> : als_gram_slab_x6d_kernel<NBV, false>; }
 YCNR_X6D(1) YCNR_X6D(2) YCNR_X6D(3) YCNR_X6D(4) YCNR_X6D(5) YCNR_X6D(6) YCNR_X6D(7)
+#undef YCNR_X6D
+
+template <typename T, int NB, bool LDS_SOLVER>
+void (*fused_x6d_kernel(int))(StepArgs<T>) { return nullptr; }
+#define YCNR_X6D(NBV, LDSV) \
+  template <>               \
+  void (*fused_x6d_kernel<float, NBV, LDSV>(int k))(StepArgs<float>) { return k % 4 ? nullptr : k < 16 * NBV ? als_gram_solve_x6d_kernel<NBV, true, LDSV> : als_gram_solve_x6d_kernel<NBV, false, LDSV>; }
+YCNR_X6D(1, false) YCNR_X6D(2, false) YCNR_X6D(3, false) YCNR_X6D(4, false) YCNR_X6D(5, false) YCNR_X6D(6, false) YCNR_X6D(7, false)
+YCNR_X6D(1, true) YCNR_X6D(2, true) YCNR_X6D(3, true) YCNR_X6D(4, true) YCNR_X6D(5, true) YCNR_X6D(6, true) YCNR_X6D(7, true)
 #undef YCNR_X6D
 
 // SLABX6: split chunks go through the bf16x6 Gramian kernel (plain slab layout), so the reduce
@@ -204,9 +204,10 @@ int launch_nbe(StepArgs<T> args, int64_t nUnits, int64_t nSplitUnits, int64_t nS
                hipEvent_t *ev /* 5 events or null */, const DualPlan &dp) {
   const size_t lds = SolverFor<T, NB, LDS_SOLVER>::type::lds_bytes();
   void (*k0)(StepArgs<T>) = SLABX6 ? slab_x6_kernel<T, NB>() : als_gram_slab_kernel<T, NB, EDGE && !SLABX6>;
-  if (SLABX6 && slab_x6p_kernel<T, NB>(args.k) && getenv("YCNR_X6P")) k0 = slab_x6p_kernel<T, NB>(args.k);
-  if (SLABX6 && slab_x6d_kernel<T, NB>(args.k) && !getenv("YCNR_NO_X6D") && !getenv("YCNR_X6P")) k0 = slab_x6d_kernel<T, NB>(args.k);
-  auto k1 = als_gram_solve_kernel<T, NB, LDS_SOLVER, EDGE>;
+  if (SLABX6 && slab_x6d_kernel<T, NB>(args.k) && !getenv("YCNR_NO_X6D")) k0 = slab_x6d_kernel<T, NB>(args.k);
+  void (*k1)(StepArgs<T>) = als_gram_solve_kernel<T, NB, LDS_SOLVER, EDGE>;
+  if (SLABX6 && fused_x6d_kernel<T, NB, LDS_SOLVER>(args.k) && !getenv("YCNR_NO_X6D") && !getenv("YCNR_NO_FUSED_X6D"))
+    k1 = fused_x6d_kernel<T, NB, LDS_SOLVER>(args.k);
   auto k2 = als_reduce_solve_kernel<T, NB, LDS_SOLVER, EDGE && !SLABX6>;
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k1),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -221,7 +222,9 @@ int launch_nbe(StepArgs<T> args, int64_t nUnits, int64_t nSplitUnits, int64_t nS
   if (ev) HIP_TRY(hipEventRecord(ev[1], stream));
   const int64_t nPrimal = dp.nPrimal >= 0 ? dp.nPrimal : nUnits - nSplitUnits;
   if (nPrimal > 0) {
-    hipLaunchKernelGGL(k1, dim3((unsigned)nPrimal), dim3(64), lds, stream, args);
+    const size_t pad = getenv("YCNR_K1_LDSPAD") ? (size_t)atoi(getenv("YCNR_K1_LDSPAD")) : 0;  // experiments: limits blocks per CU
+    if (pad) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + pad)));
+    hipLaunchKernelGGL(k1, dim3((unsigned)nPrimal), dim3(64), lds + pad, stream, args);
     HIP_TRY(hipGetLastError());
   }
   if (ev) HIP_TRY(hipEventRecord(ev[2], stream));
