@@ -117,7 +117,8 @@ typedef struct ycnr_als_options {
 #define YCNR_FLAG_LDS_SOLVER 1
 /* options.flags: never use the dual (n x n) form for rows with fewer ratings than factors */
 #define YCNR_FLAG_NO_DUAL 2
-/* options.flags: sort split chunks by the first column id they touch instead of by length */
+/* options.flags: accepted and ignored (band-major chunks, its successor, are the default;
+ * see YCNR_FLAG_NO_BANDS) */
 #define YCNR_FLAG_LOCALITY_SORT 4
 /* options.flags: keep the last 4 Gramian columns of k = 16 m + 4 on the matrix cores (padded
  * tile column) instead of accumulating them on the VALU */
@@ -125,6 +126,11 @@ typedef struct ycnr_als_options {
 /* options.flags: keep the chunk Gramian on v_mfma_f32_16x16x4_f32 instead of the exact
  * 3-way bf16 split on the bf16 matrix pipe */
 #define YCNR_FLAG_NO_BF16X6 16
+/* options.flags: cut split rows every chunkRatings ratings only.  Default: when the fixed matrix
+ * is much larger than the last-level cache, split rows are cut at common column-id boundaries
+ * (bands of 96 MB of the fixed matrix) and their chunks run band by band, so the waves in flight
+ * gather from one cache-resident band. */
+#define YCNR_FLAG_NO_BANDS 32
 
 /* Timing / accounting of the last ycnr_als_step, measured with HIP events on the
  * handle's stream around each kernel (DESIGN.md "Measurement"). */

@@ -181,6 +181,49 @@ def test_every_row_length_class(als, k):
         assert (err <= np.maximum(16 * conds * EPS32, 2e-6)).all()
 
 
+def test_band_major_chunks(als, monkeypatch):
+    """Split rows cut at common column-id boundaries (bands of the fixed matrix) instead of every
+    chunkRatings ratings: same results as the plain chunks within float32 rounding, both against
+    float64.  Bands of 1 MB so that a small matrix has many; rows that miss whole bands, rows with
+    a few ratings in a band (merged into the next one) and rows heavy enough to hit the
+    64-chunks-per-row limit."""
+    from ycnr_als import _lib
+    k, users, items = 64, 12000, 400     # fixed matrix 12000 x 64 x 4 B = 3 MB = 3 bands
+    monkeypatch.setenv("YCNR_BAND_MB", "1")
+    rng = np.random.default_rng(77)
+    lens = [11000, 9000, 5000, 3000, 2500, 1500, 1100, 1030, 700, 64, 3] + [int(x) for x in rng.integers(1, 2500, items - 11)]
+    rows = []
+    for i, n in enumerate(lens):
+        if i == 3:      # only the last band
+            cols = 9000 + rng.choice(3000, n, replace=False)
+        elif i == 4:    # 5 ratings in the first band, the rest in the second
+            cols = np.concatenate([rng.choice(4000, 5, replace=False), 4200 + rng.choice(3000, n - 5, replace=False)])
+        else:
+            cols = rng.choice(users, n, replace=False)
+        rows.append(np.sort(cols))
+    rowPtr = np.zeros(items + 1, np.int64)
+    rowPtr[1:] = np.cumsum(lens)
+    indx = np.concatenate(rows).astype(np.int32)
+    vals = rng.integers(1, 11, rowPtr[-1]).astype(np.float32)
+    bi = Csr(items, users, rowPtr, indx, vals)
+    U = (rng.standard_normal((users, k)) / np.sqrt(k)).astype(np.float32)
+    V = np.zeros((items, k), np.float32)
+    want, conds = numpy_step(0.05, k, bi, U, V)
+    got = {}
+    for name, flags, chunk in (("bands", 0, 0), ("plain", _lib.FLAG_NO_BANDS, 0), ("bands256", 0, 256)):
+        dev = als.AlsDevice(k, users, items, flags=flags, chunkRatings=chunk)
+        dev.set_ratings("byItem", bi.rowPtr, bi.indx, bi.vals)
+        dev.set_factors("byUser", U)
+        dev.set_factors("byItem", V)
+        info = dev.step("byItem")
+        got[name] = (dev.get_factors("byItem"), info.units)
+        check_rows(got[name][0], want, conds, np.float32)
+        dev.destroy()
+    assert got["bands"][1] != got["plain"][1]   # the schedules differ ...
+    err = row_rel_err(got["bands"][0], got["plain"][0])
+    assert (err <= np.maximum(16 * conds * EPS32, 2e-6)).all()   # ... the results do not
+
+
 @pytest.mark.parametrize("k", [64, 100])
 def test_many_rows_at_full_occupancy(als, k):
     """Tens of thousands of rows in one launch, so that every CU holds its full set of workgroups

@@ -47,6 +47,7 @@ constexpr int kMaxFactorsBig = 256;  // float32 through the 4-wave kernels of al
 constexpr size_t kBigArenaBytes = (size_t)16 << 30;  // slabs of the big path are produced and consumed in batches
 constexpr int kDefaultChunk = 1024;  // ratings per split unit (and the largest fused row)
 constexpr int kMaxSlabsPerRow = 64;  // heavier rows get proportionally longer chunks
+constexpr int64_t kBandBytes = (int64_t)96 << 20;  // slice of the fixed matrix one band of chunks gathers from (cache-sized)
 constexpr size_t kZeroRowBytes = 2048;  // >= kMaxFactors doubles
 constexpr int kMaxDualBlocks = 6;        // dual-form kernels exist for 1..6 blocks of 16 ratings
 
@@ -395,6 +396,44 @@ int gather_i32(const int32_t *dSrc, const std::vector<int64_t> &pos, std::vector
   return YCNR_OK;
 }
 
+// out[q] = first position p in [beg[q], end[q]) with indx[p] >= key[q] (end[q] if none); rows sorted by column id
+__global__ void lower_bound_i32_kernel(const int32_t *indx, const int64_t *beg, const int64_t *end, const int32_t *key,
+                                       int64_t *out, int64_t n) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  int64_t lo = beg[q], hi = end[q];
+  const int32_t kq = key[q];
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (indx[mid] < kq) lo = mid + 1;
+    else hi = mid;
+  }
+  out[q] = lo;
+}
+
+int lower_bound_i32(const int32_t *dIndx, const std::vector<int64_t> &beg, const std::vector<int64_t> &end,
+                    const std::vector<int32_t> &key, std::vector<int64_t> &out, hipStream_t stream) {
+  const size_t n = key.size();
+  out.resize(n);
+  if (n == 0) return YCNR_OK;
+  char *d = nullptr;
+  HIP_TRY(hipMalloc(&d, n * 28));
+  int64_t *dBeg = (int64_t *)d, *dEnd = dBeg + n, *dOut = dEnd + n;
+  int32_t *dKey = (int32_t *)(dOut + n);
+  hipError_t e = hipMemcpyAsync(dBeg, beg.data(), n * 8, hipMemcpyHostToDevice, stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(dEnd, end.data(), n * 8, hipMemcpyHostToDevice, stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(dKey, key.data(), n * 4, hipMemcpyHostToDevice, stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(lower_bound_i32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dIndx, dBeg, dEnd, dKey, dOut, (int64_t)n);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(out.data(), dOut, n * 8, hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  (void)hipFree(d);
+  if (e != hipSuccess) return fail(YCNR_ERR_HIP, "lower_bound_i32: %s", hipGetErrorString(e));
+  return YCNR_OK;
+}
+
 // validate 0 <= indx[i] < limit on the device
 int check_index_range(const int32_t *dIndx, int64_t n, int64_t limit, hipStream_t stream,
                       const char *what) {
@@ -479,6 +518,7 @@ int ycnr_als_create(const ycnr_als_options *o, ycnr_als **out) {
   ycnr_als *h = new (std::nothrow) ycnr_als();
   if (!h) return fail(YCNR_ERR_NOMEM, "out of host memory");
   h->opt = *o;
+  if (const char *e = getenv("YCNR_EXTRA_FLAGS")) h->opt.flags |= (uint32_t)atoi(e);  // experiments from unmodified hosts
   if (h->opt.chunkRatings == 0) h->opt.chunkRatings = kDefaultChunk;
   h->opt.chunkRatings = (h->opt.chunkRatings + 3) & ~3;
   hipError_t e = hipStreamCreateWithFlags(&h->ownStream, hipStreamNonBlocking);
@@ -617,22 +657,83 @@ int ycnr_als_set_ratings(ycnr_als *h, int side, const int64_t *rowPtr, const int
     }
     batches.push_back(cur);
   }
-  // Optional (measured: no gain at MAL scale, 16.4 vs 16.0 ms for the item step, because the
-  // chunk kernel is bound by the matrix pipe, not by the gather): order the split chunks by
-  // the first column id they touch, so the waves in flight at any moment walk the same
-  // window of the fixed matrix.
-  if (nSlabs > 1 && (h->opt.flags & YCNR_FLAG_LOCALITY_SORT)) {
-    std::vector<int64_t> firstPos((size_t)nSlabs);
-    for (int64_t i = 0; i < nSlabs; ++i) firstPos[i] = units[i].beg;
-    std::vector<int32_t> firstId((size_t)nSlabs);
-    int rc2 = gather_i32(h->ratings[side].dIndx, firstPos, firstId, h->stream);
-    if (rc2) return rc2;
-    std::vector<int32_t> order((size_t)nSlabs);
-    for (int64_t i = 0; i < nSlabs; ++i) order[i] = (int32_t)i;
-    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return firstId[a] < firstId[b]; });
-    std::vector<Unit> sorted((size_t)nSlabs);
-    for (int64_t i = 0; i < nSlabs; ++i) sorted[i] = units[order[i]];
-    std::copy(sorted.begin(), sorted.end(), units.begin());
+  // Band-major chunks (unless YCNR_FLAG_NO_BANDS): when the fixed matrix is far larger than the
+  // last-level cache, cut every split row at the same column-id boundaries ("bands" of
+  // kBandBytes of the fixed matrix) instead of every `chunk` ratings, and run the chunks band
+  // by band.  All waves in flight then gather from one band, which stays cache-resident while
+  // each of its rows is used once per rating that refers to it.  Rows are assumed sorted by
+  // column id (they are when they come from a CSR transpose); unsorted rows only lose locality.
+  {
+    const int64_t fixedRows = h->rows(1 - side);
+    const int64_t rowBytes = (int64_t)h->opt.factorsCount * (int64_t)h->ts();
+    int64_t bandBytes = kBandBytes;
+    if (const char *e = getenv("YCNR_BAND_MB")) bandBytes = (int64_t)atoi(e) << 20;
+    if (!big && nSlabs > 1 && !(h->opt.flags & YCNR_FLAG_NO_BANDS) && bandBytes > 0 && fixedRows * rowBytes > 2 * bandBytes) {
+      const int64_t W = std::max<int64_t>(1, bandBytes / rowBytes);
+      const int nBands = (int)((fixedRows + W - 1) / W);
+      const int64_t base = hp[0];
+      std::vector<int64_t> qBeg, qEnd, cuts;
+      std::vector<int32_t> qKey;
+      for (const SplitRow &sr : split) {
+        const int64_t b = hp[sr.row - rowBegin] - base, e = hp[sr.row - rowBegin + 1] - base;
+        for (int j = 1; j < nBands; ++j) {
+          qBeg.push_back(b);
+          qEnd.push_back(e);
+          qKey.push_back((int32_t)(j * W));
+        }
+      }
+      int rc2 = lower_bound_i32(h->ratings[side].dIndx, qBeg, qEnd, qKey, cuts, h->stream);
+      if (rc2) return rc2;
+      struct BandUnit { Unit u; int band; };
+      std::vector<BandUnit> bu;
+      const int64_t chunk = h->opt.chunkRatings, minSeg = std::max<int64_t>(64, chunk / 4);
+      int64_t slabs = 0;
+      for (size_t r = 0; r < split.size(); ++r) {
+        SplitRow &sr = split[r];
+        const int64_t b = hp[sr.row - rowBegin] - base, e = hp[sr.row - rowBegin + 1] - base;
+        // band segments, short ones merged into their successor (the last into its predecessor)
+        std::vector<std::pair<int64_t, int>> seg;  // (start, band); ends at the next start / e
+        int64_t p = b;
+        for (int j = 0; j < nBands; ++j) {
+          const int64_t q = j + 1 < nBands ? std::min(e, std::max(p, cuts[r * (size_t)(nBands - 1) + j])) : e;
+          if (q - p >= minSeg) {
+            seg.push_back({p, j});
+            p = q;
+          }
+        }
+        if (seg.empty()) seg.push_back({b, 0});
+        seg[0].first = b;  // ratings left over before the first kept boundary join the first segment
+        int64_t ch = chunk;
+        const int64_t room = kMaxSlabsPerRow - (int64_t)seg.size();
+        if (room < 1 || (sr.n + ch - 1) / ch > room) ch = std::max(ch, (sr.n + std::max<int64_t>(1, room) - 1) / std::max<int64_t>(1, room));
+        sr.slab0 = (int32_t)slabs;
+        int32_t parts = 0;
+        for (size_t i = 0; i < seg.size(); ++i) {
+          const int64_t sb = seg[i].first, se = i + 1 < seg.size() ? seg[i + 1].first : e, len = se - sb;
+          const int64_t np = (len + ch - 1) / ch;
+          const int64_t pl = (((len + np - 1) / np) + 3) & ~(int64_t)3;
+          for (int64_t q = 0; q < np; ++q) {
+            const int64_t ub = sb + q * pl, ue = std::min(se, ub + pl);
+            if (ue <= ub) break;
+            bu.push_back({Unit{ub, ue, sr.row, (int32_t)(slabs + parts)}, seg[i].second});
+            ++parts;
+          }
+        }
+        if (parts > kMaxSlabsPerRow) return fail(YCNR_ERR_STATE, "band schedule: %d chunks for row %d", parts, sr.row);
+        sr.nslabs = parts;
+        slabs += parts;
+      }
+      std::stable_sort(bu.begin(), bu.end(), [](const BandUnit &x, const BandUnit &y) {
+        return x.band != y.band ? x.band < y.band : (x.u.end - x.u.beg) > (y.u.end - y.u.beg);
+      });
+      std::vector<Unit> all;
+      all.reserve(bu.size() + units.size() - (size_t)nSlabs);
+      for (const BandUnit &x : bu) all.push_back(x.u);
+      all.insert(all.end(), units.begin() + nSlabs, units.end());
+      units.swap(all);
+      nSlabs = slabs;
+      arenaSlabs = slabs;
+    }
   }
   Schedule &S = h->sched[side];
   S.release();

@@ -17,7 +17,7 @@ BY_USER, BY_ITEM = 0, 1
 F32, F64 = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
 RMSE_VALIDATE, RMSE_TEST = 0, 1
-FLAG_LDS_SOLVER, FLAG_NO_DUAL, FLAG_LOCALITY_SORT, FLAG_NO_VALU_EDGE, FLAG_NO_BF16X6 = 1, 2, 4, 8, 16
+FLAG_LDS_SOLVER, FLAG_NO_DUAL, FLAG_LOCALITY_SORT, FLAG_NO_VALU_EDGE, FLAG_NO_BF16X6, FLAG_NO_BANDS = 1, 2, 4, 8, 16, 32
 
 # every symbol include/ycnr_als.h declares (checked by tests/test_abi.py)
 EXPORTS = [
