@@ -10,7 +10,7 @@ user and by item, both factor matrices) are resident in HBM before the timed reg
 N > 1 the total problem is fixed and rows are sharded over the ranks ("strong").
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline      -- the dominant kernel (als_gram_solve) against its binding roof, from HIP-event
+  roofline      -- the dominant kernel (per half-step) against the roof that binds it, from HIP-event
                    durations measured inside libycnr_als.so on the launch stream
   cpu_baseline  -- the CPU oracle (a port of the reference algorithm) timed on a bounded row
                    sample of the same workload on this box's host cores (N = 1 only)
@@ -40,6 +40,7 @@ WORKLOADS = {
 }
 
 PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector = fp32 MFMA peak
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA; a float32 product costs 6 bf16 products (exact 3-way split)
 PEAK_FP64_TFLOPS = 78.6
 PEAK_HBM_GBS = 8000.0     # spec; ~6300 achievable
 
@@ -151,13 +152,15 @@ def main():
     per_rating = k * (k + 1) + 2 * k            # symmetric Gramian + rhs
     per_row = k ** 3 / 3.0 + 2 * k * k          # Cholesky + two triangular solves
     bytes_rating = 4 + s + k * s                # index + value + gathered factor row
-    kern = {n: {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0} for n in
-            ("als_gram_solve_kernel", "als_dual_solve_kernel", "als_gram_slab_kernel", "als_gram_big+als_solve_big",
-             "als_reduce_solve_kernel")}
+    # kernels are accounted per half-step: the same kernel is a different workload on the two sides
+    # (user side: the 5 MB item matrix is cache-resident; item side: 700 MB of user factors are not)
+    kern = {}
     step_ms = {"byUser": 0.0, "byItem": 0.0}
     for st in lord.stepTimes:
         i = st["info"]
-        step_ms[st["stepType"]] += i.totalMs
+        side = st["stepType"]
+        step_ms[side] += i.totalMs
+        chunk_ratings = i.ratings - i.fusedRatings
         for name, ms, fl, by in (
                 ("als_gram_solve_kernel", i.gramSolveMs,
                  (i.fusedRatings - i.dualRatings) * per_rating + (i.fusedRows - i.dualRows) * per_row,
@@ -169,42 +172,75 @@ def main():
                 # k > 128: this interval holds als_gram_big + als_solve_big of every batch, so the
                 # rows' solve work is priced here too
                 ("als_gram_big+als_solve_big" if k > 128 else "als_gram_slab_kernel", i.gramSlabMs,
-                 (i.ratings - i.fusedRatings) * per_rating + (i.splitRows * per_row if k > 128 else 0),
-                 (i.ratings - i.fusedRatings) * bytes_rating),
+                 chunk_ratings * per_rating + (i.splitRows * per_row if k > 128 else 0),
+                 chunk_ratings * bytes_rating),
                 ("als_reduce_solve_kernel", i.reduceSolveMs, 0 if k > 128 else i.splitRows * per_row,
                  i.splitRows * (k * s + 8))):
             if fl > 0:
-                kern[name]["ms"] += ms
-                kern[name]["flops"] += fl
-                kern[name]["bytes"] += by
-                kern[name]["launches"] += 1
+                d = kern.setdefault(f"{name}[{side}]", {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
+                d["ms"] += ms
+                d["flops"] += fl
+                d["bytes"] += by
+                d["launches"] += 1
     dom = max(kern, key=lambda n: kern[n]["ms"])
+
+    def peak_of(n):
+        # Gramian kernels of float32 runs use the bf16 pipe (6 products per float32 product) when the
+        # library's conditions hold: k % 4 == 0, k <= 112, fixed matrix of that half-step < 2 GB
+        side = n[n.index("[") + 1:-1]
+        fixed_rows = items if side == "byUser" else users
+        x6 = (not args.double) and k % 4 == 0 and k <= 112 and fixed_rows * k * 4 < 2 ** 31
+        if x6 and (n.startswith("als_gram_slab_kernel") or n.startswith("als_gram_solve_kernel")):
+            return PEAK_BF16_TFLOPS / 6.0, "bf16 MFMA peak / 6"
+        return peak, "fp64 MFMA peak" if args.double else "fp32 MFMA peak"
 
     def describe(n):
         d = kern[n]
         t = d["ms"] * 1e-3
         tf = d["flops"] / t / 1e12 if t > 0 else 0.0
         gb = d["bytes"] / t / 1e9 if t > 0 else 0.0
+        pk, pk_name = peak_of(n)
         return {"kernel": n, "launches": d["launches"], "avg_launch_ms": round(d["ms"] / max(d["launches"], 1), 4),
-                "achieved_TFLOPs": round(tf, 3), "mfma_frac": round(tf / peak, 4),
+                "achieved_TFLOPs": round(tf, 3), "mfma_peak_TFLOPs": round(pk, 1), "mfma_peak": pk_name,
+                "mfma_frac": round(tf / pk, 4),
                 "algorithmic_GBs": round(gb, 1), "hbm_frac": round(gb / PEAK_HBM_GBS, 4)}
 
     dd = describe(dom)
     tot_ms = sum(d["ms"] for d in kern.values())
     tot_fl = sum(d["flops"] for d in kern.values())
     tot_by = sum(d["bytes"] for d in kern.values())
+    # the roof that binds the dominant kernel: the one it is closer to
+    hbm_bound = dd["hbm_frac"] >= dd["mfma_frac"]
     roofline = {
-        "bound": "mfma", "kernel": dom, "achieved": dd["achieved_TFLOPs"], "peak": peak, "unit": "TFLOP/s",
-        "frac": dd["mfma_frac"], "traffic": None, "launches": dd["launches"], "avg_launch_ms": dd["avg_launch_ms"],
-        "flops_model": "k(k+1)+2k per rating + k^3/3+2k^2 per solved row (symmetric Gramian + Cholesky), fp32 MFMA peak",
+        "bound": "hbm" if hbm_bound else "mfma", "kernel": dom,
+        "achieved": dd["algorithmic_GBs"] if hbm_bound else dd["achieved_TFLOPs"],
+        "peak": PEAK_HBM_GBS if hbm_bound else dd["mfma_peak_TFLOPs"], "unit": "GB/s" if hbm_bound else "TFLOP/s",
+        "frac": dd["hbm_frac"] if hbm_bound else dd["mfma_frac"],
+        "traffic": None, "launches": dd["launches"], "avg_launch_ms": dd["avg_launch_ms"],
+        "bytes_model": "per rating: 4 (column id) + s (rating) + k s (gathered factor row); per solved row: k s + 8; s = sizeof(T)",
+        "flops_model": "k(k+1)+2k per rating + k^3/3+2k^2 per solved row (symmetric Gramian + Cholesky); "
+                       "each kernel against the matrix-core peak of the pipe its Gramian uses (mfma_peak)",
         "kernels": [describe(n) for n in kern if kern[n]["launches"]],
         # all kernels of the iteration together, against both roofs (gather-model bytes for HBM)
         "iteration": {"kernel_ms_per_step": round(tot_ms / args.steps, 3),
-                      "mfma_frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / peak, 4) if tot_ms else 0.0,
+                      "mfma_frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / peak, 4) if tot_ms else 0.0,  # against the fp32 (fp64) MFMA peak
                       "hbm_frac": round(tot_by / (tot_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if tot_ms else 0.0,
                       "byUser_ms": round(step_ms["byUser"] / args.steps, 3),
                       "byItem_ms": round(step_ms["byItem"] / args.steps, 3)},
     }
+    # HBM traffic of the dominant kernel comes from PMC passes of this same command (rocprofv3
+    # cannot run inside the timed bench): profiles/traffic.json, written by profiles/aggregate_pmc.py
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            ent = tj.get("workloads", {}).get(args.workload if not args.double else args.workload + "_f64", {}).get(dom)
+            if ent and world == 1:
+                roofline["traffic"] = ent["hbm_bytes_per_launch"]
+                roofline["traffic_source"] = tj.get("source", "profiles/traffic.json")
+                roofline["traffic_over_algorithmic"] = round(ent["hbm_bytes_per_launch"] / (kern[dom]["bytes"] / kern[dom]["launches"]), 3)
+        except (OSError, ValueError, KeyError):
+            pass
 
     rmse = lord.calcRmse("rmseValidate", False)
     if args.dump_factors and rank == 0:

@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Sum rocprofv3 PMC passes per kernel and write the per-launch HBM traffic bench.py quotes.
+
+    python profiles/aggregate_pmc.py <tag> <workload> <dir with *_counter_collection.csv files...>
+
+Each directory is one `rocprofv3 --pmc <counters> --output-format csv` pass of
+`python3 bench.py --workload <workload> --steps 1 --warmup 1 --no-cpu-baseline` (counters must
+be collected in separate passes from the kernel trace; FETCH_SIZE and WRITE_SIZE do not fit one
+pass).  Output: profiles/<tag>_<workload>_pmc_by_kernel.json (raw sums per kernel and half-step)
+and the <workload> entry of profiles/traffic.json.
+
+HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KB: on gfx950 FETCH_SIZE counts a 128-byte
+request of a 16-byte-per-lane load as 64 bytes (MI355X_MICROARCH.md, HBM); every gather of these
+kernels is 16 bytes per lane.  Infinity-Cache hits are included in FETCH_SIZE, so this is
+memory-side traffic of the L2, an upper bound of the HBM bytes.
+"""
+import csv
+import glob
+import json
+import os
+import sys
+
+BENCH_NAME = (("als_gram_solve", "als_gram_solve_kernel"), ("als_dual_solve", "als_dual_solve_kernel"),
+              ("als_gram_slab", "als_gram_slab_kernel"), ("als_gram_big", "als_gram_big+als_solve_big"),
+              ("als_solve_big", "als_gram_big+als_solve_big"), ("als_reduce_solve", "als_reduce_solve_kernel"))
+
+
+def main():
+    tag, workload, dirs = sys.argv[1], sys.argv[2], sys.argv[3:]
+    rows = {}
+    for d in dirs:
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                rows.setdefault(int(r["Dispatch_Id"]), {"name": r["Kernel_Name"]})[r["Counter_Name"]] = \
+                    rows.get(int(r["Dispatch_Id"]), {}).get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    # half-step of each dispatch: a byUser step launches [slab] fused duals [reduce], then byItem the same;
+    # the fused kernel opens a new half-step, slab kernels belong to the half-step that follows them
+    per = {}
+    side, seen_fused = "byUser", False
+    order = sorted(rows)
+    sides = {}
+    half = 0
+    for i, did in enumerate(order):
+        n = rows[did]["name"]
+        if "als_gram_slab" in n or "als_gram_big" in n:
+            # a slab kernel starts a half-step unless it directly follows another slab kernel
+            prev = rows[order[i - 1]]["name"] if i else ""
+            if not ("als_gram_slab" in prev or "als_gram_big" in prev or "als_solve_big" in prev):
+                half += 1
+        elif "als_gram_solve" in n:
+            prev = rows[order[i - 1]]["name"] if i else ""
+            if not ("als_gram_slab" in prev):
+                half += 1
+        sides[did] = "byUser" if half % 2 == 1 else "byItem"
+    for did in order:
+        r = rows[did]
+        short = r["name"].split("(")[0].replace("void ", "")
+        if "ycnr::als_" not in short or "rmse" in short:
+            continue
+        key = (short, sides[did])
+        d = per.setdefault(key, {"kernel": short, "half_step": sides[did], "dispatches": 0})
+        d["dispatches"] += 1
+        for c, v in r.items():
+            if c != "name":
+                d[c] = d.get(c, 0.0) + v
+    out = sorted(per.values(), key=lambda d: (d["half_step"], d["kernel"]))
+    here = os.path.dirname(os.path.abspath(__file__))
+    json.dump(out, open(os.path.join(here, f"{tag}_{workload}_pmc_by_kernel.json"), "w"), indent=1)
+    # per-launch traffic under bench.py's kernel names (all dual classes of a half-step are one bench entry)
+    traffic = {}
+    for d in out:
+        bn = next((b for a, b in BENCH_NAME if a in d["kernel"]), None)
+        if bn is None or "FETCH_SIZE" not in d:
+            continue
+        t = traffic.setdefault(f"{bn}[{d['half_step']}]", {"kb": 0.0, "launches": 0})
+        t["kb"] += 2.0 * d["FETCH_SIZE"] + d.get("WRITE_SIZE", 0.0)
+        t["launches"] = max(t["launches"], d["dispatches"])
+    tpath = os.path.join(here, "traffic.json")
+    tj = json.load(open(tpath)) if os.path.exists(tpath) else {"workloads": {}}
+    tj["source"] = f"profiles/{tag}_*_pmc_by_kernel.json: (2 x FETCH_SIZE + WRITE_SIZE) KB per launch, rocprofv3 --pmc, own passes"
+    tj["workloads"][workload] = {k: {"hbm_bytes_per_launch": round(v["kb"] * 1024.0 / v["launches"])} for k, v in traffic.items()}
+    json.dump(tj, open(tpath, "w"), indent=1)
+    for k, v in tj["workloads"][workload].items():
+        print(k, v)
+
+
+if __name__ == "__main__":
+    main()
