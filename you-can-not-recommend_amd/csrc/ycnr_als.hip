@@ -97,12 +97,23 @@ struct Schedule {
   }
 };
 
+// Ratings per split unit when the caller leaves it to the library: every chunk costs a 30 KB
+// slab written and read again (k = 100), so chunks should be long -- but a launch wants >= 16
+// units per resident wave (2048 on a 256-CU part at two waves per SIMD) to keep its tail short.
+// MAL item side: 121.5 M ratings on one GPU -> 3072; an eighth of it on each of 8 GPUs -> 1024.
+int auto_chunk(int64_t nnz) {
+  const int64_t c = nnz / (2048 * 16);
+  return (int)((std::min<int64_t>(3072, std::max<int64_t>(kDefaultChunk, c)) + 3) & ~(int64_t)3);
+}
+
 // Split rows into wave-level units (the counterpart of EmfLord.splitToPortions,
 // lib/emf/EmfLord.js:510-612, at wave instead of worker-process granularity).
 // rowPtr: local (length nRows + 1, any base).  Units index ratings relative to rowPtr[0].
 void build_schedule(const int64_t *rowPtr, int64_t rowBegin, int64_t nRows, int chunk,
                     std::vector<Unit> &units, std::vector<SplitRow> &split, int64_t &nSlabs,
-                    int64_t &solvedRows, int64_t splitAbove = -1) {
+                    int64_t &solvedRows, int64_t splitAbove = -1, int fusedMax = 0) {
+  // fusedMax: longest row that stays one unit (default: chunk)
+  if (fusedMax <= 0) fusedMax = chunk;
   // splitAbove >= 0 (big path): every row longer than splitAbove goes through slabs, in row
   // order (no longest-first sort, so that batches are contiguous)
   // on return units = [split chunks (nSlabs of them) | whole rows]
@@ -118,7 +129,7 @@ void build_schedule(const int64_t *rowPtr, int64_t rowBegin, int64_t nRows, int 
     if (n <= 0) continue;  // rows without ratings are never written
     ++solvedRows;
     const int32_t row = (int32_t)(rowBegin + r);
-    if (splitAbove >= 0 ? n <= splitAbove : n <= chunk) {
+    if (splitAbove >= 0 ? n <= splitAbove : n <= fusedMax) {
       fused.push_back(Unit{b, e, row, -1});
       continue;
     }
@@ -467,6 +478,7 @@ struct ycnr_als {
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   void *factors[2] = {nullptr, nullptr};
   bool ownFactors[2] = {false, false};
+  bool autoChunk = false;  // options.chunkRatings was 0: sized per upload (auto_chunk)
   Ratings ratings[2];
   Schedule sched[2];
   Ratings rmse[2];
@@ -519,6 +531,7 @@ int ycnr_als_create(const ycnr_als_options *o, ycnr_als **out) {
   if (!h) return fail(YCNR_ERR_NOMEM, "out of host memory");
   h->opt = *o;
   if (const char *e = getenv("YCNR_EXTRA_FLAGS")) h->opt.flags |= (uint32_t)atoi(e);  // experiments from unmodified hosts
+  h->autoChunk = h->opt.chunkRatings == 0;
   if (h->opt.chunkRatings == 0) h->opt.chunkRatings = kDefaultChunk;
   h->opt.chunkRatings = (h->opt.chunkRatings + 3) & ~3;
   hipError_t e = hipStreamCreateWithFlags(&h->ownStream, hipStreamNonBlocking);
@@ -629,8 +642,9 @@ int ycnr_als_set_ratings(ycnr_als *h, int side, const int64_t *rowPtr, const int
   std::vector<SplitRow> split;
   int64_t nSlabs = 0, solved = 0;
   const bool big = h->opt.factorsCount > kMaxFactors;
-  build_schedule(hp.data(), rowBegin, rowEnd - rowBegin, h->opt.chunkRatings, units, split, nSlabs, solved,
-                 big ? dual_max_ratings(h->opt) : -1);
+  const int chunkRatings = h->autoChunk && !big ? auto_chunk(hp[rowEnd - rowBegin] - hp[0]) : h->opt.chunkRatings;
+  build_schedule(hp.data(), rowBegin, rowEnd - rowBegin, chunkRatings, units, split, nSlabs, solved,
+                 big ? dual_max_ratings(h->opt) : -1, std::min(chunkRatings, h->opt.chunkRatings));
   std::vector<Schedule::Batch> batches;
   int64_t arenaSlabs = nSlabs;
   if (big && nSlabs > 0) {
@@ -686,7 +700,7 @@ int ycnr_als_set_ratings(ycnr_als *h, int side, const int64_t *rowPtr, const int
       if (rc2) return rc2;
       struct BandUnit { Unit u; int band; };
       std::vector<BandUnit> bu;
-      const int64_t chunk = h->opt.chunkRatings, minSeg = std::max<int64_t>(64, chunk / 4);
+      const int64_t chunk = chunkRatings, minSeg = std::max<int64_t>(64, chunk / 4);
       int64_t slabs = 0;
       for (size_t r = 0; r < split.size(); ++r) {
         SplitRow &sr = split[r];
