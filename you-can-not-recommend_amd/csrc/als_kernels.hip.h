@@ -1616,7 +1616,11 @@ __global__ __launch_bounds__(64, 2) void als_gram_solve_x6d_kernel(StepArgs<floa
 // Operands: lane (g, c) of block ba holds the float4 Y[idx[16 ba + c]][16 s + 4 g .. +3];
 // element j feeds MFMA step (s, j), whose 4 contraction indices are {16 s + 4 g + j : g}.
 // Requires k % 4 == 0 (16-byte aligned rows).
-template <int NBN>
+// X6: G = Y Y^T on the bf16 matrix pipe with the exact 3-way split (as GramX6D): the contraction
+// runs over the k factors, which are contiguous in a gathered row, so lane (g, c) loads its eight
+// operand values 32 s + 8 g .. + 7 of row 16 ba + c as two float4 and splits them in place; 6 MFMAs
+// of K = 32 per tile replace 8 float32 MFMAs of K = 4 that cost 35 cycles each.
+template <int NBN, bool X6>
 __global__ __launch_bounds__(64) void als_dual_solve_kernel(StepArgs<float> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using Sv = SolveMfmaF32<NBN>;
@@ -1666,12 +1670,72 @@ __global__ __launch_bounds__(64) void als_dual_solve_kernel(StepArgs<float> a) {
       }
     }
   };
-  load(ya, 0);
-  for (int s = 0; s < ksteps; ++s) {
-    if (s + 1 < ksteps) load(yb, s + 1);
-    mma4(ya);
+  if constexpr (X6) {
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const int ksteps32 = (k + 31) >> 5;
+    float4 za[NBN][2], zb[NBN][2];
+    auto load8 = [&](float4 (&y)[NBN][2], int s) {
+      const int f = 32 * s + 8 * g;
 #pragma unroll
-    for (int ba = 0; ba < NBN; ++ba) ya[ba] = yb[ba];
+      for (int ba = 0; ba < NBN; ++ba) {
+        y[ba][0] = *reinterpret_cast<const float4 *>(f < k ? rowp[ba] + f : a.zeros);
+        y[ba][1] = *reinterpret_cast<const float4 *>(f + 4 < k ? rowp[ba] + f + 4 : a.zeros);
+      }
+    };
+    load8(za, 0);
+    for (int s = 0; s < ksteps32; ++s) {
+      if (s + 1 < ksteps32) load8(zb, s + 1);
+      u32x4 p1[NBN], p2[NBN], p3[NBN];
+#pragma unroll
+      for (int ba = 0; ba < NBN; ++ba) {
+        const float x[8] = {za[ba][0].x, za[ba][0].y, za[ba][0].z, za[ba][0].w, za[ba][1].x, za[ba][1].y, za[ba][1].z, za[ba][1].w};
+        unsigned h[4], m[4], l[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const float x0 = x[2 * jj], x1 = x[2 * jj + 1];
+          const unsigned u0 = __builtin_bit_cast(unsigned, x0), u1 = __builtin_bit_cast(unsigned, x1);
+          h[jj] = __builtin_amdgcn_perm(u1, u0, 0x07060302);
+          const float s0 = x0 - __builtin_bit_cast(float, u0 & 0xFFFF0000u);
+          const float s1 = x1 - __builtin_bit_cast(float, u1 & 0xFFFF0000u);
+          const unsigned v0 = __builtin_bit_cast(unsigned, s0), v1 = __builtin_bit_cast(unsigned, s1);
+          m[jj] = __builtin_amdgcn_perm(v1, v0, 0x07060302);
+          const float t0 = s0 - __builtin_bit_cast(float, v0 & 0xFFFF0000u);
+          const float t1 = s1 - __builtin_bit_cast(float, v1 & 0xFFFF0000u);
+          l[jj] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, t1), __builtin_bit_cast(unsigned, t0), 0x07060302);
+        }
+        p1[ba] = u32x4{h[0], h[1], h[2], h[3]};
+        p2[ba] = u32x4{m[0], m[1], m[2], m[3]};
+        p3[ba] = u32x4{l[0], l[1], l[2], l[3]};
+      }
+      // smallest terms first per tile, product type outermost (consecutive MFMAs hit different tiles)
+#pragma unroll
+      for (int term = 0; term < 6; ++term) {
+#pragma unroll
+        for (int ba = 0; ba < NBN; ++ba) {
+#pragma unroll
+          for (int bb = ba; bb < NBN; ++bb) {
+            const u32x4 &pa = term == 0 ? p2[ba] : (term == 1 || term == 3 || term == 5) ? p1[ba] : (term == 2 ? p3[ba] : p2[ba]);
+            const u32x4 &pb = term == 0 ? p2[bb] : term == 1 ? p3[bb] : term == 2 ? p1[bb] : term == 3 ? p2[bb] : p1[bb];
+            acc[tile_index(ba, bb, NBN)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                __builtin_bit_cast(bf16x8, pa), __builtin_bit_cast(bf16x8, pb), acc[tile_index(ba, bb, NBN)], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int ba = 0; ba < NBN; ++ba) {
+        za[ba][0] = zb[ba][0];
+        za[ba][1] = zb[ba][1];
+      }
+    }
+  } else {
+    load(ya, 0);
+    for (int s = 0; s < ksteps; ++s) {
+      if (s + 1 < ksteps) load(yb, s + 1);
+      mma4(ya);
+#pragma unroll
+      for (int ba = 0; ba < NBN; ++ba) ya[ba] = yb[ba];
+    }
   }
   const float lam = (float)(a.lambda * (double)n);
   float wcol[NBN];

@@ -155,6 +155,7 @@ void build_schedule(const int64_t *rowPtr, int64_t rowBegin, int64_t nRows, int 
 }
 
 struct DualPlan {
+  bool noX6 = false;     // YCNR_FLAG_NO_BF16X6: float32-MFMA Gramian in the dual kernels too
   int64_t nPrimal = -1;  // < 0: no dual classes, every whole row goes through the primal kernel
   const int64_t *first = nullptr, *count = nullptr;
 };
@@ -163,8 +164,11 @@ template <int M>
 int launch_dual(StepArgs<float> args, const DualPlan &dp, hipStream_t stream) {
   if (dp.count[M] > 0) {
     args.firstDual = (int32_t)dp.first[M];
-    hipLaunchKernelGGL(als_dual_solve_kernel<M>, dim3((unsigned)dp.count[M]), dim3(64), SolveMfmaF32<M>::lds_bytes(), stream,
-                       args);
+    // bf16x6 form unless switched off; NBN = 1 has a single tile and too little to gain
+    const bool x6 = !dp.noX6 && !getenv("YCNR_NO_DUAL_X6");
+    void (*kd)(StepArgs<float>) = als_dual_solve_kernel<M, false>;
+    if (x6) kd = als_dual_solve_kernel<M, true>;
+    hipLaunchKernelGGL(kd, dim3((unsigned)dp.count[M]), dim3(64), SolveMfmaF32<M>::lds_bytes(), stream, args);
     HIP_TRY(hipGetLastError());
   }
   return YCNR_OK;
@@ -865,6 +869,7 @@ int ycnr_als_step_async(ycnr_als *h, int side) {
                       (const float *)h->dZeros, (float *)h->factors[side], (float *)S.dSlabs, h->dErr, lambda, h->opt.factorsCount, 0, 0,
                       use_slab_x6(h->opt, side) ? (uint32_t)(h->rows(1 - side) * h->opt.factorsCount * 4) : 0u};
     DualPlan dp;
+    dp.noX6 = (h->opt.flags & YCNR_FLAG_NO_BF16X6) != 0;
     if (dual_max_ratings(h->opt) > 0) {
       dp.nPrimal = S.nPrimal;
       dp.first = S.dualFirst;
