@@ -1284,6 +1284,13 @@ __global__ __launch_bounds__(64, 1) void als_gram_slab_x6_kernel(StepArgs<float>
 // miscompile as the permlane swaps in transpose_rg.
 // v may be fresh out of an MFMA: hipcc pads no hazard for an asm operand, so the statement opens
 // with the 12 wait states an MFMA result needs before a non-MFMA reader.
+template <typename V4>
+__device__ __forceinline__ void bpermute4_opaque(int byteAddr, const V4 &v, float (&r)[4]) {
+  asm volatile("s_nop 7\n\ts_nop 3\n\tds_bpermute_b32 %0, %4, %5\n\tds_bpermute_b32 %1, %4, %6\n\t"
+               "ds_bpermute_b32 %2, %4, %7\n\tds_bpermute_b32 %3, %4, %8\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3])
+               : "v"(byteAddr), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+}
 __device__ __forceinline__ float bpermute_opaque(int byteAddr, float v) {
   float r;
   asm volatile("s_nop 7\n\ts_nop 3\n\tds_bpermute_b32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r) : "v"(byteAddr), "v"(v));
@@ -1505,12 +1512,11 @@ struct GramX6D {
 #pragma unroll
     for (int cb = 0; cb < NB; ++cb) {
       acc_t &tl = acc[tile_index(cb, NB - 1, NB)];
+      float w[4];
+      bpermute4_opaque(src << 2, tl, w);
       float v = 0.0f;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const float w = bpermute_opaque(src << 2, tl[t]);
-        v = (c & 3) == t ? w : v;
-      }
+      for (int t = 0; t < 4; ++t) v = (c & 3) == t ? w[t] : v;
       if (g != 0 || (cb == NB - 1 && c >= kr)) v = 0.0f;
       bacc[cb] = v;
 #pragma unroll
