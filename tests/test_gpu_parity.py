@@ -181,6 +181,43 @@ def test_every_row_length_class(als, k):
         assert (err <= np.maximum(16 * conds * EPS32, 2e-6)).all()
 
 
+@pytest.mark.parametrize("k", [4, 8, 12, 16, 24, 32, 48, 52, 80, 96, 108, 112])
+def test_lds_dma_gramian_every_block_count(als, k):
+    """The LDS-DMA staged bf16x6 Gramian (k % 4 == 0, k <= 112) at every block count, with the
+    right-hand side in the padded column (k % 16 != 0) and on the VALU (k % 16 == 0): whole rows of
+    1..4 steps including exact multiples of 32 ratings (fused row kernel; the dual form is switched
+    off so that short rows take it too) and split rows (chunk kernel + reduce)."""
+    from ycnr_als import _lib
+    items = 600
+    lens = [1, 2, 31, 32, 33, 63, 64, 65, 95, 96, 97, 127, 128, 129, 200, 256, 300, 511, 520]
+    rng = np.random.default_rng(1000 + k)
+    rowPtr = np.zeros(len(lens) + 1, np.int64)
+    rowPtr[1:] = np.cumsum(lens)
+    indx = np.concatenate([np.sort(rng.choice(items, n, replace=False)) for n in lens]).astype(np.int32)
+    vals = rng.integers(1, 11, rowPtr[-1]).astype(np.float32)
+    bu = Csr(len(lens), items, rowPtr, indx, vals)
+    U = np.zeros((len(lens), k), np.float32)
+    V = (rng.standard_normal((items, k)) / np.sqrt(k)).astype(np.float32)
+    want, conds = numpy_step(0.05, k, bu, V, U)
+    res = {}
+    for name, flags, chunk in (("fused", _lib.FLAG_NO_DUAL, 0), ("chunks", _lib.FLAG_NO_DUAL, 96),
+                               ("f32mfma", _lib.FLAG_NO_DUAL | _lib.FLAG_NO_BF16X6, 0)):
+        dev = als.AlsDevice(k, len(lens), items, flags=flags, chunkRatings=chunk)
+        dev.set_ratings("byUser", bu.rowPtr, bu.indx, bu.vals)
+        dev.set_factors("byUser", U)
+        dev.set_factors("byItem", V)
+        info = dev.step("byUser")
+        assert info.dualRows == 0 and info.numericErrors == 0
+        if name == "chunks":
+            assert info.splitRows == sum(1 for n in lens if n > 96)
+        res[name] = dev.get_factors("byUser")
+        check_rows(res[name], want, conds, np.float32)
+        dev.destroy()
+    for other in ("chunks", "f32mfma"):
+        err = row_rel_err(res["fused"], res[other])
+        assert (err <= np.maximum(16 * conds * EPS32, 2e-6)).all()
+
+
 def test_band_major_chunks(als, monkeypatch):
     """Split rows cut at common column-id boundaries (bands of the fixed matrix) instead of every
     chunkRatings ratings: same results as the plain chunks within float32 rounding, both against
