@@ -212,6 +212,30 @@ int ycnr_als_last_step_info(ycnr_als *h, ycnr_als_step_info *info);
 int ycnr_als_rmse(ycnr_als *h, int which, double globalAvgShift, int nPortions,
                   const int64_t *portionRowEnd, double *out);
 
+/* ---- Preprocessing directly before the path ------------------------------
+ *
+ * ycnr_split_to_sets replaces EmfLord.doSplitToSets (lib/emf/EmfLord.js:402-505): every user's
+ * unassigned ratings (types[q] == 0) are shuffled and cut into train / validate / test
+ * (dataset_type 1 / 2 / 3) so that the row ends up with
+ *   targetCnts[0] = ceil(total * pcts[0] / 100), targetCnts[1] = ceil(total * (pcts[0] + pcts[1]) / 100) - targetCnts[0],
+ *   targetCnts[2] = total - targetCnts[0] - targetCnts[1]
+ * where total counts the row's ratings of type 0..3 (EmfLord.js:447-457, including its rule for
+ * ratings that are already assigned and for left-overs: they go to train).  Types outside 0..3
+ * (the reference's 4 = excluded) are left alone.  The reference's shuffle is unseeded; here the
+ * shuffled order of a row's free ratings is ascending (key, j) with
+ *   key = fmix32(fmix32(seed + 0x9e3779b9 * row) ^ j),  fmix32 = MurmurHash3's 32-bit finalizer,
+ * j the rating's position inside the row, so every implementation produces the same split.
+ * rowPtr / types are host arrays (rowPtr[0] == 0); deviceMs (may be NULL) receives the kernel time.
+ *
+ * ycnr_rating_stats replaces the SQL of updateUsersStats / updateItemsStats
+ * (EmfLord.js:252-396): per row the count and the (double) sum of the ratings whose type is
+ * 1, 2 or 3 (every rating when types == NULL); avg = sum / cnt, maxRatingsPer* = max cnt and
+ * totalRatingsAvg = sum of sums / sum of counts are left to the caller. */
+int ycnr_split_to_sets(int64_t rows, const int64_t *rowPtr, int8_t *types, const int32_t pcts[3], uint32_t seed,
+                       double *deviceMs);
+int ycnr_rating_stats(int dtype, int64_t rows, const int64_t *rowPtr, const void *vals, const int8_t *types,
+                      int32_t *cnt, double *sum, double *deviceMs);
+
 #ifdef __cplusplus
 }
 #endif

@@ -99,4 +99,64 @@ int oracle_split_to_portions(const int32_t *ratingsCntPer, int nIds, int rowsCnt
   return any ? p + 1 : 0;
 }
 
-int oracle_version(void) { return 1; }
+/* ---- N1: split + stats ----------------------------------------------------
+ * oracle_split_to_sets follows EmfLord.doSplitToSets (lib/emf/EmfLord.js:402-505) row by row:
+ * counts per lines 447-457, "shuffle(freeIds)" (unseeded there) replaced by the keyed order that
+ * include/ycnr_als.h defines, slices per lines 459-468. */
+static uint32_t oracle_fmix32(uint32_t h) {
+  h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+  return h;
+}
+typedef struct { uint32_t key; int64_t j; } oracle_keyed;
+static int oracle_keyed_cmp(const void *a, const void *b) {
+  const oracle_keyed *x = (const oracle_keyed *)a, *y = (const oracle_keyed *)b;
+  if (x->key != y->key) return x->key < y->key ? -1 : 1;
+  return x->j < y->j ? -1 : (x->j > y->j ? 1 : 0);
+}
+int oracle_split_to_sets(int64_t rows, const int64_t *rowPtr, int8_t *types, const int32_t *pcts, uint32_t seed) {
+  int64_t maxLen = 0;
+  for (int64_t r = 0; r < rows; r++) if (rowPtr[r + 1] - rowPtr[r] > maxLen) maxLen = rowPtr[r + 1] - rowPtr[r];
+  oracle_keyed *fr = (oracle_keyed *)malloc((size_t)(maxLen > 0 ? maxLen : 1) * sizeof(oracle_keyed));
+  if (!fr) return -1;
+  for (int64_t r = 0; r < rows; r++) {
+    int8_t *t = types + rowPtr[r];
+    const int64_t n = rowPtr[r + 1] - rowPtr[r];
+    int64_t cnt[4] = {0, 0, 0, 0}, nf = 0;
+    for (int64_t j = 0; j < n; j++) {
+      if (t[j] >= 0 && t[j] <= 3) cnt[t[j]]++;
+      if (t[j] == 0) { fr[nf].key = oracle_fmix32(oracle_fmix32(seed + 0x9e3779b9u * (uint32_t)r) ^ (uint32_t)j); fr[nf].j = j; nf++; }
+    }
+    if (nf == 0) continue;                                     /* if (freeIds && freeIds.length) */
+    const int64_t totalCnt = nf + cnt[1] + cnt[2] + cnt[3];
+    int64_t target[3], nw[3];
+    target[0] = (int64_t)ceil((double)totalCnt * (double)pcts[0] / 100.0);
+    target[1] = (int64_t)ceil((double)totalCnt * (double)(pcts[0] + pcts[1]) / 100.0) - target[0];
+    target[2] = totalCnt - (target[0] + target[1]);
+    for (int i = 0; i < 3; i++) nw[i] = target[i] - cnt[i + 1] > 0 ? target[i] - cnt[i + 1] : 0;
+    if (nw[0] + nw[1] + nw[2] < nf) nw[0] += nf - (nw[0] + nw[1] + nw[2]);
+    qsort(fr, (size_t)nf, sizeof(oracle_keyed), oracle_keyed_cmp);  /* shuffle(freeIds) */
+    int64_t offs = 0;
+    for (int i = 0; i < 3; i++) {                              /* freeIds.slice(offs, offs + newCnts[i]) */
+      for (int64_t q = offs; q < offs + nw[i] && q < nf; q++) t[fr[q].j] = (int8_t)(i + 1);
+      offs += nw[i];
+    }
+  }
+  free(fr);
+  return 0;
+}
+
+/* count and sum of the ratings of type 1..3 per row (all when types == NULL), accumulated in
+ * row order in double: the SQL of EmfLord.js:252-396 (count(r.rating), avg(r.rating)) */
+#define ORACLE_STATS(NAME, T)                                                                                  \
+  void NAME(int64_t rows, const int64_t *rowPtr, const T *vals, const int8_t *types, int32_t *cnt, double *sum) { \
+    for (int64_t r = 0; r < rows; r++) {                                                                       \
+      double s = 0.0; int32_t c = 0;                                                                           \
+      for (int64_t q = rowPtr[r]; q < rowPtr[r + 1]; q++)                                                      \
+        if (!types || (types[q] >= 1 && types[q] <= 3)) { s += (double)vals[q]; c++; }                         \
+      cnt[r] = c; sum[r] = s;                                                                                  \
+    }                                                                                                          \
+  }
+ORACLE_STATS(oracle_sRatingStats, float)
+ORACLE_STATS(oracle_dRatingStats, double)
+
+int oracle_version(void) { return 2; }

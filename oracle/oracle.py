@@ -32,8 +32,7 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(_SO):
-        build()
+    build()  # compiles when the .so is missing or older than its sources
     L = C.CDLL(_SO)
     for pfx, fp in (("s", f32p), ("d", f64p)):
         f = getattr(L, f"oracle_{pfx}AlsCalcPortion")
@@ -54,6 +53,12 @@ def lib():
     L.oracle_split_to_portions.restype = C.c_int
     L.oracle_split_to_portions.argtypes = [i32p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int,
                                            C.c_int, i32p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.oracle_split_to_sets.restype = C.c_int
+    L.oracle_split_to_sets.argtypes = [C.c_int64, i64p, np.ctypeslib.ndpointer(np.int8, flags="C_CONTIGUOUS"), i32p, C.c_uint32]
+    for pfx, fp in (("s", f32p), ("d", f64p)):
+        f = getattr(L, f"oracle_{pfx}RatingStats")
+        f.restype = None
+        f.argtypes = [C.c_int64, i64p, fp, C.c_void_p, i32p, f64p]
     _lib = L
     return L
 
@@ -126,3 +131,26 @@ def split_to_portions(cnt_per_row, rows_cnt, ratings_in_portion, num_threads, pc
                                        int(pos.sum()), int(ratings_in_portion), int(num_threads), int(pct), out,
                                        C.byref(mr), C.byref(mw))
     return out[:p].copy(), mr.value, mw.value
+
+
+def split_to_sets(rowPtr, types, pcts=(85, 10, 5), seed=1):
+    """EmfLord.doSplitToSets (EmfLord.js:402-505) with the keyed shuffle of include/ycnr_als.h.
+    types: int8 per rating, 0 = unassigned; returns the completed copy."""
+    rp = np.ascontiguousarray(rowPtr, np.int64)
+    t = np.array(types, np.int8, copy=True)
+    rc = lib().oracle_split_to_sets(len(rp) - 1, rp, t, np.asarray(pcts, np.int32), int(seed) & 0xFFFFFFFF)
+    if rc:
+        raise MemoryError("oracle_split_to_sets")
+    return t
+
+
+def rating_stats(rowPtr, vals, types=None):
+    """count and double sum per row of the ratings of type 1..3 (all when types is None)."""
+    rp = np.ascontiguousarray(rowPtr, np.int64)
+    v = np.ascontiguousarray(vals)
+    rows = len(rp) - 1
+    cnt = np.zeros(rows, np.int32)
+    sm = np.zeros(rows, np.float64)
+    t = None if types is None else np.ascontiguousarray(types, np.int8)
+    getattr(lib(), f"oracle_{_pfx(v.dtype)}RatingStats")(rows, rp, v, None if t is None else t.ctypes.data, cnt, sm)
+    return cnt, sm

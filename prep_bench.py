@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""prep_bench.py -- N1: the train / validate / test split and the per-row rating
+statistics of the MAL-scale synthetic matrix on one GPU, next to the CPU oracle.
+
+Prints one JSON line: kernel milliseconds (HIP events around the kernel, inputs resident), the
+rate in ratings/s, the algorithmic HBM bytes against the 8 TB/s roof, and the oracle's time on a
+bounded row prefix.  The reference does this step through PostgreSQL: 1 h 05 m on MAL (README.md:127).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "you-can-not-recommend_amd", "python"))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--users", type=int, default=1_750_000)
+    ap.add_argument("--items", type=int, default=12_700)
+    ap.add_argument("--nnz", type=int, default=121_000_000)
+    ap.add_argument("--cpu-rows", type=int, default=200_000, help="user rows the CPU oracle is timed on")
+    args = ap.parse_args()
+    import ycnr_als
+    from ycnr_als.data import synth_ratings, transpose_csr
+    from oracle import oracle as orc
+    dev = torch.device("cuda:0")
+    by_user = synth_ratings(args.users, args.items, args.nnz, max_rating=10, device=dev, degree_sigma=1.2, zipf_a=0.6)[0]
+    by_item = transpose_csr(by_user)
+    rp_u, vals_u = by_user.rowPtr.cpu().numpy(), by_user.vals.cpu().numpy()
+    rp_i, vals_i = by_item.rowPtr.cpu().numpy(), by_item.vals.cpu().numpy()
+    nnz = int(rp_u[-1])
+    types0 = np.zeros(nnz, np.int8)
+    ycnr_als.split_to_sets(rp_u[:1001], types0[:rp_u[1000]])  # warm-up (module load)
+    types, ms_split = ycnr_als.split_to_sets(rp_u, types0, (85, 10, 5), 20260001)
+    cnt_u, sum_u, ms_su = ycnr_als.rating_stats(rp_u, vals_u, types)
+    cnt_i, sum_i, ms_si = ycnr_als.rating_stats(rp_i, vals_i, None)
+    # algorithmic bytes: the split reads and writes one byte per rating (+ row pointers); the
+    # statistics read a rating and a type per rating and write 12 bytes per row
+    b_split = 2 * nnz + 8 * (len(rp_u) - 1)
+    b_stats = nnz * 5 + 20 * (len(rp_u) - 1) + nnz * 4 + 20 * (len(rp_i) - 1)
+    # CPU oracle on a row prefix
+    r = min(args.cpu_rows, len(rp_u) - 1)
+    n_cpu = int(rp_u[r])
+    t0 = time.perf_counter()
+    t_cpu = orc.split_to_sets(rp_u[:r + 1], types0[:n_cpu], (85, 10, 5), 20260001)
+    t1 = time.perf_counter()
+    orc.rating_stats(rp_u[:r + 1], vals_u[:n_cpu], t_cpu)
+    t2 = time.perf_counter()
+    assert np.array_equal(t_cpu, types[:n_cpu])
+    tot = np.bincount(types, minlength=4)
+    out = {
+        "metric": "train/validate/test split + per-row statistics, ratings/s", "unit": "ratings/s",
+        "value": nnz / ((ms_split + ms_su + ms_si) * 1e-3), "n_gpus": 1, "data": "synthetic",
+        "config": {"workload": f"MAL-scale synthetic {args.users}x{args.items}", "nnz": nnz, "dataSetDistr": [85, 10, 5]},
+        "kernel_ms": {"split_to_sets": round(ms_split, 3), "rating_stats_users": round(ms_su, 3), "rating_stats_items": round(ms_si, 3)},
+        "roofline": {"bound": "hbm", "unit": "GB/s", "peak": 8000.0,
+                     "split_to_sets": round(b_split / (ms_split * 1e-3) / 1e9, 1),
+                     "rating_stats": round(b_stats / ((ms_su + ms_si) * 1e-3) / 1e9, 1),
+                     "note": "the split is compute-bound (rank of every rating among its row's by a keyed order, O(n^2/64) per row); "
+                             "the statistics stream the ratings once"},
+        "sets": {"train": int(tot[1]), "validate": int(tot[2]), "test": int(tot[3])},
+        "maxRatingsPerUser": int(cnt_u.max()), "maxRatingsPerItem": int(cnt_i.max()),
+        "totalRatingsAvg": float(sum_u.sum() / cnt_u.sum()),
+        "cpu_baseline": {"kind": "port", "cores": 1, "sample": f"first {r} user rows ({n_cpu} ratings)",
+                         "split_s": round(t1 - t0, 3), "stats_s": round(t2 - t1, 3),
+                         "value": n_cpu / (t2 - t0), "unit": "ratings/s"},
+    }
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

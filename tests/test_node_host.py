@@ -106,3 +106,31 @@ def test_js_train_matches_python_host(tmp_path, double):
     assert list(cj) == list(cp)
     assert cj["calcCnt"] == 2 and cp["calcCnt"] == 1  # the JS run warm-started from a saved calc
     assert out["portionRatings"] > 0
+
+
+@pytest.mark.gpu
+def test_node_split_and_stats_on_gpu(tmp_path):
+    """N1 through the addon: the same split as the oracle, statistics as numpy."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(5)
+    lens = rng.integers(0, 60, 300)
+    rowPtr = np.zeros(301, np.int64)
+    rowPtr[1:] = np.cumsum(lens)
+    types = rng.choice(np.array([0, 0, 0, 1, 2, 4], np.int8), rowPtr[-1])
+    vals = rng.integers(1, 6, rowPtr[-1]).astype(np.float32)
+    (tmp_path / "in.json").write_text(json.dumps({"rowPtr": rowPtr.tolist(), "types": types.tolist(), "vals": vals.tolist(),
+                                                  "dataSetDistr": [85, 10, 5], "seed": 77}))
+    r = subprocess.run(["node", os.path.join(HERE, "js", "prep_gpu.js"), str(tmp_path / "in.json")], capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    want = orc.split_to_sets(rowPtr, types, (85, 10, 5), 77)
+    assert np.array_equal(np.array(out["types"], np.int8), want)
+    cnt, sm = orc.rating_stats(rowPtr, vals, want)
+    assert np.array_equal(np.array(out["cnt"]), cnt)
+    avg = np.divide(sm, cnt, out=np.zeros_like(sm), where=cnt > 0)
+    assert np.allclose(out["avg"], avg, rtol=1e-13)
+    assert out["max"] == cnt.max() and out["total"] == cnt.sum()
+    assert np.isclose(out["totalRatingsAvg"], sm.sum() / cnt.sum(), rtol=1e-13)
+    assert out["wrongTypeMessage"] == "invalid type!"
+

@@ -395,6 +395,57 @@ napi_value Rmse(napi_env env, napi_callback_info info) {
   return out;
 }
 
+// N1: splitToSets(rowPtr, types: Int8Array (in/out), dataSetDistr: [train, validate, test], seed) -> kernel ms
+// (EmfLord.doSplitToSets, lib/emf/EmfLord.js:402-505)
+napi_value SplitToSets(napi_env env, napi_callback_info info) {
+  size_t argc = 4;
+  napi_value a[4];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, a, nullptr, nullptr));
+  if (argc < 4) return throw_msg(env, "splitToSets(rowPtr, types, dataSetDistr, seed)");
+  View rp = view_of(env, a[0]), ty = view_of(env, a[1]);
+  std::vector<int64_t> rowPtr;
+  if (!rp.ok || !ty.ok || ty.type != napi_int8_array || !to_i64(rp, rowPtr) || rowPtr.empty()) return throw_msg(env, "invalid type!");
+  if (rowPtr.back() < 0 || (size_t)rowPtr.back() > ty.length) return throw_msg(env, "types shorter than rowPtr says");
+  int32_t pcts[3];
+  for (uint32_t i = 0; i < 3; ++i) {
+    napi_value e;
+    int64_t v;
+    if (napi_get_element(env, a[2], i, &e) != napi_ok || !get_int(env, e, &v)) return throw_msg(env, "dataSetDistr must be [train, validate, test]");
+    pcts[i] = (int32_t)v;
+  }
+  int64_t seed;
+  if (!get_int(env, a[3], &seed)) return throw_msg(env, "invalid type!");
+  double ms = 0;
+  if (ycnr_split_to_sets((int64_t)rowPtr.size() - 1, rowPtr.data(), static_cast<int8_t *>(ty.data), pcts, (uint32_t)seed, &ms))
+    return throw_msg(env, ycnr_last_error());
+  return num(env, ms);
+}
+
+// N1: ratingStats(rowPtr, vals, types | null, cnt: Int32Array, sum: Float64Array) -> kernel ms
+// (ratings_count / avg_rating of EmfLord.js:252-396: avg = sum / cnt)
+napi_value RatingStats(napi_env env, napi_callback_info info) {
+  size_t argc = 5;
+  napi_value a[5];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, a, nullptr, nullptr));
+  if (argc < 5) return throw_msg(env, "ratingStats(rowPtr, vals, types, cnt, sum)");
+  View rp = view_of(env, a[0]), vals = view_of(env, a[1]), ty = view_of(env, a[2]), cnt = view_of(env, a[3]), sum = view_of(env, a[4]);
+  std::vector<int64_t> rowPtr;
+  if (!rp.ok || !vals.ok || !cnt.ok || !sum.ok || !to_i64(rp, rowPtr) || rowPtr.empty() || cnt.type != napi_int32_array ||
+      sum.type != napi_float64_array || (vals.type != napi_float32_array && vals.type != napi_float64_array) ||
+      (ty.ok && ty.type != napi_int8_array))
+    return throw_msg(env, "invalid type!");
+  const size_t rows = rowPtr.size() - 1;
+  if (cnt.length < rows || sum.length < rows) return throw_msg(env, "cnt / sum shorter than the row count");
+  if (rowPtr.back() < 0 || (size_t)rowPtr.back() > vals.length || (ty.ok && (size_t)rowPtr.back() > ty.length))
+    return throw_msg(env, "vals / types shorter than rowPtr says");
+  double ms = 0;
+  if (ycnr_rating_stats(vals.type == napi_float64_array ? YCNR_F64 : YCNR_F32, (int64_t)rows, rowPtr.data(), vals.data,
+                        ty.ok ? static_cast<const int8_t *>(ty.data) : nullptr, static_cast<int32_t *>(cnt.data),
+                        static_cast<double *>(sum.data), &ms))
+    return throw_msg(env, ycnr_last_error());
+  return num(env, ms);
+}
+
 napi_value Init(napi_env env, napi_value exports) {
   const napi_property_descriptor props[] = {
       {"sAlsCalcPortion", nullptr, AlsCalcPortion<false>, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
@@ -412,6 +463,8 @@ napi_value Init(napi_env env, napi_value exports) {
       {"getFactors", nullptr, GetFactors, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
       {"step", nullptr, Step, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
       {"rmse", nullptr, Rmse, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+      {"splitToSets", nullptr, SplitToSets, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+      {"ratingStats", nullptr, RatingStats, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
   };
   napi_define_properties(env, exports, sizeof(props) / sizeof(props[0]), props);
   return exports;

@@ -1,0 +1,189 @@
+// Preprocessing kernels for the step directly before the ALS path:
+// the per-user train / validate / test split and the per-row rating statistics.
+//
+// Reference: EmfLord.doSplitToSets (lib/emf/EmfLord.js:402-505) shuffles each user's unassigned
+// ratings and cuts the shuffle into the counts its formula gives; updateUsersStats /
+// updateItemsStats (EmfLord.js:252-396) count and average each row's ratings with
+// dataset_type IN (1, 2, 3).  Both go through PostgreSQL there (1 h 05 m on MAL, README.md:127).
+//
+// The shuffle is defined without a sequential generator so that every implementation (this
+// kernel, oracle/als_oracle.c, hosts) produces the same split: unassigned rating j of row r gets
+// the key ycnr_split_key(seed, r, j) and the "shuffled order" is ascending (key, j).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ycnr {
+
+__host__ __device__ inline uint32_t fmix32(uint32_t h) {
+  h ^= h >> 16;
+  h *= 0x85ebca6bu;
+  h ^= h >> 13;
+  h *= 0xc2b2ae35u;
+  h ^= h >> 16;
+  return h;
+}
+// the key of include/ycnr_als.h (ycnr_split_to_sets)
+__host__ __device__ inline uint32_t split_key(uint32_t seed, uint32_t row, uint32_t j) {
+  return fmix32(fmix32(seed + 0x9e3779b9u * row) ^ j);
+}
+
+// EmfLord.js:447-457: how many of a row's free ratings go to each set
+__host__ __device__ inline void split_counts(int64_t freeCnt, int64_t c1, int64_t c2, int64_t c3, int p0, int p1,
+                                             int64_t (&nw)[3]) {
+  const int64_t total = freeCnt + c1 + c2 + c3;
+  int64_t t[3];
+  t[0] = (total * p0 + 99) / 100;                // Math.ceil(totalCnt * pcts[0] / 100)
+  t[1] = (total * (p0 + p1) + 99) / 100 - t[0];  // Math.ceil(totalCnt * (pcts[0] + pcts[1]) / 100) - targetCnts[0]
+  t[2] = total - (t[0] + t[1]);
+  nw[0] = t[0] > c1 ? t[0] - c1 : 0;
+  nw[1] = t[1] > c2 ? t[1] - c2 : 0;
+  nw[2] = t[2] > c3 ? t[2] - c3 : 0;
+  if (nw[0] + nw[1] + nw[2] < freeCnt) nw[0] += freeCnt - (nw[0] + nw[1] + nw[2]);
+}
+
+constexpr int kSplitShortRow = 1024;   // rows up to this length: 5 KB of LDS per wave, many waves per CU
+constexpr int kSplitLdsKeys = 12288;   // longer rows: 60 KB per wave; beyond this keys are recomputed in the inner loop
+
+// One wave per row.  Rank of every free rating among the row's free ratings by (key, j): O(n^2 / 64)
+// compares per row with keys and free flags kept in LDS -- the ratings themselves are never read.
+// rowList: the rows this launch handles (the host sorts rows into a short and a long class so
+// that the many short rows do not pay for the long rows' LDS).  BLOCK threads share one row:
+// a wave for short rows, 16 waves for long ones (each wave ranks its own 64-blocks of j).
+template <int CAP, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void split_to_sets_kernel(const int64_t *rowPtr, const int32_t *rowList, int64_t nList, int8_t *types,
+                                                             int p0, int p1, uint32_t seed) {
+  __shared__ uint32_t keys[CAP];
+  __shared__ uint8_t isFree[CAP];
+  __shared__ int cshared[4];
+  const int tid = threadIdx.x;
+  for (int64_t li = blockIdx.x; li < nList; li += gridDim.x) {
+    const int64_t r = rowList[li];
+    const int64_t b = rowPtr[r], n = rowPtr[r + 1] - b;
+    if (n <= 0) continue;
+    int8_t *t = types + b;
+    __syncthreads();  // the previous row's LDS contents are dead
+    if (tid < 4) cshared[tid] = 0;
+    __syncthreads();
+    // existing assignments and the free count
+    int c[4] = {0, 0, 0, 0};
+    for (int64_t j = tid; j < n; j += BLOCK) {
+      const int v = t[j];
+      if (v >= 0 && v <= 3) ++c[v];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      for (int m = 32; m >= 1; m >>= 1) c[q] += __shfl_xor(c[q], m, 64);
+      if ((tid & 63) == 0 && c[q]) atomicAdd(&cshared[q], c[q]);
+    }
+    __syncthreads();
+    const int64_t c0 = cshared[0], c1 = cshared[1], c2 = cshared[2], c3 = cshared[3];
+    if (c0 == 0) continue;
+    int64_t nw[3];
+    split_counts(c0, c1, c2, c3, p0, p1, nw);
+    const bool cached = n <= CAP;
+    if (cached) {
+      for (int64_t j = tid; j < n; j += BLOCK) {
+        keys[j] = split_key(seed, (uint32_t)r, (uint32_t)j);
+        isFree[j] = t[j] == 0;
+      }
+    }
+    __syncthreads();
+    // Results are written after the whole row has been ranked when it is cached; a longer row
+    // marks what it has assigned with bit 6 so that later threads still count it as free.
+    for (int64_t j0 = 0; j0 < n; j0 += BLOCK) {
+      const int64_t j = j0 + tid;
+      const bool mine = j < n && (cached ? isFree[j] != 0 : t[j] == 0);
+      const uint32_t kj = j < n ? (cached ? keys[j] : split_key(seed, (uint32_t)r, (uint32_t)j)) : 0u;
+      int64_t rank = 0;
+      if (cached) {
+        for (int64_t i = 0; i < n; ++i) {
+          const uint32_t ki = keys[i];
+          rank += (isFree[i] && (ki < kj || (ki == kj && i < j))) ? 1 : 0;
+        }
+      } else {
+        for (int64_t i = 0; i < n; ++i) {
+          const int v = t[i];
+          const uint32_t ki = split_key(seed, (uint32_t)r, (uint32_t)i);
+          rank += ((v == 0 || (v & 0x40)) && (ki < kj || (ki == kj && i < j))) ? 1 : 0;
+        }
+        __syncthreads();  // every thread has finished reading t[] for this block of j
+      }
+      if (mine) {
+        const int8_t set = rank < nw[0] ? 1 : rank < nw[0] + nw[1] ? 2 : rank < nw[0] + nw[1] + nw[2] ? 3 : 0;
+        t[j] = cached ? set : (int8_t)(set | 0x40);
+      }
+      if (!cached) __syncthreads();
+    }
+    if (!cached) {
+      __syncthreads();
+      for (int64_t j = tid; j < n; j += BLOCK)
+        if (t[j] & 0x40) t[j] = (int8_t)(t[j] & 0x3f);
+    }
+  }
+}
+
+// One 16-lane group per row: count and double sum of the ratings whose set is 1, 2 or 3
+// (every rating when types == nullptr), fixed summation tree per row.
+template <typename T>
+__global__ __launch_bounds__(256) void rating_stats_kernel(const int64_t *rowPtr, int64_t rows, const T *vals, const int8_t *types,
+                                                          int32_t *cnt, double *sum, int64_t longRow) {
+  const int sub = threadIdx.x & 15;
+  const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  if (r >= rows) return;
+  const int64_t b = rowPtr[r], e = rowPtr[r + 1];
+  if (e - b > longRow) return;  // rating_stats_long_kernel's
+  double s = 0.0;
+  int32_t c = 0;
+  for (int64_t q = b + sub; q < e; q += 16) {
+    const bool in = types == nullptr || (types[q] >= 1 && types[q] <= 3);
+    if (in) {
+      s += (double)vals[q];
+      ++c;
+    }
+  }
+  for (int m = 8; m >= 1; m >>= 1) {
+    s += __shfl_xor(s, m, 16);
+    c += __shfl_xor(c, m, 16);
+  }
+  if (sub == 0) {
+    cnt[r] = c;
+    sum[r] = s;
+  }
+}
+
+// The same for long rows (item rows of a popular title have 10^5 ratings): one 256-thread
+// workgroup per listed row, strided partial sums, fixed tree.
+template <typename T>
+__global__ __launch_bounds__(256) void rating_stats_long_kernel(const int64_t *rowPtr, const int32_t *rowList, const T *vals,
+                                                               const int8_t *types, int32_t *cnt, double *sum) {
+  __shared__ double ss[256];
+  __shared__ int32_t sc[256];
+  const int64_t r = rowList[blockIdx.x];
+  const int64_t b = rowPtr[r], e = rowPtr[r + 1];
+  double s = 0.0;
+  int32_t c = 0;
+  for (int64_t q = b + threadIdx.x; q < e; q += 256) {
+    const bool in = types == nullptr || (types[q] >= 1 && types[q] <= 3);
+    if (in) {
+      s += (double)vals[q];
+      ++c;
+    }
+  }
+  ss[threadIdx.x] = s;
+  sc[threadIdx.x] = c;
+  __syncthreads();
+  for (int m = 128; m >= 1; m >>= 1) {
+    if ((int)threadIdx.x < m) {
+      ss[threadIdx.x] += ss[threadIdx.x + m];
+      sc[threadIdx.x] += sc[threadIdx.x + m];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    cnt[r] = sc[0];
+    sum[r] = ss[0];
+  }
+}
+
+}  // namespace ycnr

@@ -7,6 +7,8 @@
 #include "../../include/ycnr_als.h"
 #include "als_kernels.hip.h"
 #include "als_big_kernels.hip.h"
+#include "prep_kernels.hip.h"
+#include "prep_kernels.hip.h"
 
 #include <algorithm>
 #include <cstdarg>
@@ -390,27 +392,6 @@ int copy_in(void *dst, const void *src, size_t bytes, int memKind, hipStream_t s
 }
 
 // out[i] = dSrc[pos[i]] for a host list of positions (one small gather kernel + two copies)
-int gather_i32(const int32_t *dSrc, const std::vector<int64_t> &pos, std::vector<int32_t> &out, hipStream_t stream) {
-  const size_t n = pos.size();
-  out.resize(n);
-  if (n == 0) return YCNR_OK;
-  int64_t *dPos = nullptr;
-  int32_t *dOut = nullptr;
-  HIP_TRY(hipMalloc(&dPos, n * sizeof(int64_t)));
-  hipError_t e = hipMalloc(&dOut, n * sizeof(int32_t));
-  if (e == hipSuccess) e = hipMemcpyAsync(dPos, pos.data(), n * sizeof(int64_t), hipMemcpyHostToDevice, stream);
-  if (e == hipSuccess) {
-    hipLaunchKernelGGL(gather_i32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dSrc, dPos, dOut, (int64_t)n);
-    e = hipGetLastError();
-  }
-  if (e == hipSuccess) e = hipMemcpyAsync(out.data(), dOut, n * sizeof(int32_t), hipMemcpyDeviceToHost, stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(stream);
-  if (dPos) (void)hipFree(dPos);
-  if (dOut) (void)hipFree(dOut);
-  if (e != hipSuccess) return fail(YCNR_ERR_HIP, "gather_i32: %s", hipGetErrorString(e));
-  return YCNR_OK;
-}
-
 // out[q] = first position p in [beg[q], end[q]) with indx[p] >= key[q] (end[q] if none); rows sorted by column id
 __global__ void lower_bound_i32_kernel(const int32_t *indx, const int64_t *beg, const int64_t *end, const int32_t *key,
                                        int64_t *out, int64_t n) {
@@ -507,6 +488,138 @@ int ycnr_device_count(void) {
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess) return fail(YCNR_ERR_HIP, "hipGetDeviceCount failed: %s", hipGetErrorString(e));
   return n;
+}
+
+// ---- N1: split + stats (prep_kernels.hip.h) ----
+namespace {
+struct DevBuf {
+  void *p = nullptr;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+};
+int timed(hipEvent_t e0, hipEvent_t e1, double *ms) {
+  HIP_TRY(hipEventRecord(e1, nullptr));
+  HIP_TRY(hipEventSynchronize(e1));
+  float f = 0;
+  HIP_TRY(hipEventElapsedTime(&f, e0, e1));
+  if (ms) *ms = f;
+  return YCNR_OK;
+}
+}  // namespace
+
+int ycnr_split_to_sets(int64_t rows, const int64_t *rowPtr, int8_t *types, const int32_t pcts[3], uint32_t seed,
+                       double *deviceMs) {
+  if (rows < 0 || !rowPtr || !pcts) return fail(YCNR_ERR_INVALID, "ycnr_split_to_sets: null argument");
+  if (pcts[0] < 0 || pcts[1] < 0 || pcts[2] < 0 || pcts[0] + pcts[1] + pcts[2] != 100)
+    return fail(YCNR_ERR_INVALID, "ycnr_split_to_sets: dataSetDistr %d/%d/%d does not sum to 100", pcts[0], pcts[1], pcts[2]);
+  if (rows == 0) return YCNR_OK;
+  if (rowPtr[0] != 0) return fail(YCNR_ERR_INVALID, "ycnr_split_to_sets: rowPtr[0] != 0");
+  const int64_t nnz = rowPtr[rows];
+  if (nnz < 0 || (nnz > 0 && !types)) return fail(YCNR_ERR_INVALID, "ycnr_split_to_sets: bad nnz / null types");
+  if (rows >= ((int64_t)1 << 31)) return fail(YCNR_ERR_UNSUPPORTED, "ycnr_split_to_sets: more than 2^31 rows");
+  for (int64_t r = 0; r < rows; ++r) {
+    if (rowPtr[r + 1] < rowPtr[r]) return fail(YCNR_ERR_INVALID, "ycnr_split_to_sets: rowPtr decreases at row %lld", (long long)r);
+    if (rowPtr[r + 1] - rowPtr[r] >= ((int64_t)1 << 31)) return fail(YCNR_ERR_UNSUPPORTED, "row %lld too long", (long long)r);
+  }
+  if (nnz == 0) return YCNR_OK;
+  DevBuf dPtr, dTypes;
+  HIP_TRY(hipMalloc(&dPtr.p, (size_t)(rows + 1) * 8));
+  HIP_TRY(hipMalloc(&dTypes.p, (size_t)nnz));
+  HIP_TRY(hipMemcpy(dPtr.p, rowPtr, (size_t)(rows + 1) * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dTypes.p, types, (size_t)nnz, hipMemcpyHostToDevice));
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  HIP_TRY(hipEventRecord(e0, nullptr));
+  // short rows and long rows apart: the long rows' 60 KB of LDS would leave two waves per CU for everybody
+  std::vector<int32_t> lists[2];
+  for (int64_t r = 0; r < rows; ++r) {
+    const int64_t n = rowPtr[r + 1] - rowPtr[r];
+    if (n > 0) lists[n > kSplitShortRow ? 1 : 0].push_back((int32_t)r);
+  }
+  // longest first within the long class (they set the tail)
+  std::stable_sort(lists[1].begin(), lists[1].end(),
+                   [&](int32_t x, int32_t y) { return rowPtr[x + 1] - rowPtr[x] > rowPtr[y + 1] - rowPtr[y]; });
+  DevBuf dList[2];
+  for (int q = 0; q < 2; ++q) {
+    if (lists[q].empty()) continue;
+    HIP_TRY(hipMalloc(&dList[q].p, lists[q].size() * 4));
+    HIP_TRY(hipMemcpy(dList[q].p, lists[q].data(), lists[q].size() * 4, hipMemcpyHostToDevice));
+  }
+  HIP_TRY(hipEventRecord(e0, nullptr));  // the kernels only (lists are part of the upload)
+  if (!lists[1].empty())
+    hipLaunchKernelGGL((split_to_sets_kernel<kSplitLdsKeys, 1024>), dim3((unsigned)lists[1].size()), dim3(1024), 0, nullptr, (const int64_t *)dPtr.p,
+                       (const int32_t *)dList[1].p, (int64_t)lists[1].size(), (int8_t *)dTypes.p, (int)pcts[0], (int)pcts[1], seed);
+  if (!lists[0].empty())
+    hipLaunchKernelGGL((split_to_sets_kernel<kSplitShortRow, 64>), dim3((unsigned)std::min<size_t>(lists[0].size(), (size_t)1 << 20)), dim3(64), 0,
+                       nullptr, (const int64_t *)dPtr.p, (const int32_t *)dList[0].p, (int64_t)lists[0].size(), (int8_t *)dTypes.p,
+                       (int)pcts[0], (int)pcts[1], seed);
+  hipError_t le = hipGetLastError();
+  int rc = le == hipSuccess ? timed(e0, e1, deviceMs) : fail(YCNR_ERR_HIP, "split_to_sets launch: %s", hipGetErrorString(le));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpy(types, dTypes.p, (size_t)nnz, hipMemcpyDeviceToHost));
+  return YCNR_OK;
+}
+
+int ycnr_rating_stats(int dtype, int64_t rows, const int64_t *rowPtr, const void *vals, const int8_t *types,
+                      int32_t *cnt, double *sum, double *deviceMs) {
+  if (rows < 0 || !rowPtr || !cnt || !sum) return fail(YCNR_ERR_INVALID, "ycnr_rating_stats: null argument");
+  if (dtype != YCNR_F32 && dtype != YCNR_F64) return fail(YCNR_ERR_INVALID, "bad dtype %d", dtype);
+  if (rows == 0) return YCNR_OK;
+  if (rowPtr[0] != 0) return fail(YCNR_ERR_INVALID, "ycnr_rating_stats: rowPtr[0] != 0");
+  const int64_t nnz = rowPtr[rows];
+  if (nnz < 0 || (nnz > 0 && !vals)) return fail(YCNR_ERR_INVALID, "ycnr_rating_stats: bad nnz / null vals");
+  const size_t ts = tsize(dtype);
+  DevBuf dPtr, dVals, dTypes, dCnt, dSum;
+  HIP_TRY(hipMalloc(&dPtr.p, (size_t)(rows + 1) * 8));
+  HIP_TRY(hipMalloc(&dVals.p, std::max<size_t>((size_t)nnz * ts, 8)));
+  HIP_TRY(hipMalloc(&dCnt.p, (size_t)rows * 4));
+  HIP_TRY(hipMalloc(&dSum.p, (size_t)rows * 8));
+  HIP_TRY(hipMemcpy(dPtr.p, rowPtr, (size_t)(rows + 1) * 8, hipMemcpyHostToDevice));
+  if (nnz) HIP_TRY(hipMemcpy(dVals.p, vals, (size_t)nnz * ts, hipMemcpyHostToDevice));
+  if (types && nnz) {
+    HIP_TRY(hipMalloc(&dTypes.p, (size_t)nnz));
+    HIP_TRY(hipMemcpy(dTypes.p, types, (size_t)nnz, hipMemcpyHostToDevice));
+  }
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  HIP_TRY(hipEventRecord(e0, nullptr));
+  constexpr int64_t kLongRow = 2048;  // longer rows get a workgroup each
+  std::vector<int32_t> longRows;
+  for (int64_t r = 0; r < rows; ++r)
+    if (rowPtr[r + 1] - rowPtr[r] > kLongRow) longRows.push_back((int32_t)r);
+  DevBuf dLong;
+  if (!longRows.empty()) {
+    HIP_TRY(hipMalloc(&dLong.p, longRows.size() * 4));
+    HIP_TRY(hipMemcpy(dLong.p, longRows.data(), longRows.size() * 4, hipMemcpyHostToDevice));
+  }
+  HIP_TRY(hipEventRecord(e0, nullptr));
+  const unsigned blocks = (unsigned)((rows * 16 + 255) / 256);
+  if (dtype == YCNR_F32) {
+    hipLaunchKernelGGL(rating_stats_kernel<float>, dim3(blocks), dim3(256), 0, nullptr, (const int64_t *)dPtr.p, rows,
+                       (const float *)dVals.p, (const int8_t *)dTypes.p, (int32_t *)dCnt.p, (double *)dSum.p, kLongRow);
+    if (!longRows.empty())
+      hipLaunchKernelGGL(rating_stats_long_kernel<float>, dim3((unsigned)longRows.size()), dim3(256), 0, nullptr, (const int64_t *)dPtr.p,
+                         (const int32_t *)dLong.p, (const float *)dVals.p, (const int8_t *)dTypes.p, (int32_t *)dCnt.p, (double *)dSum.p);
+  } else {
+    hipLaunchKernelGGL(rating_stats_kernel<double>, dim3(blocks), dim3(256), 0, nullptr, (const int64_t *)dPtr.p, rows,
+                       (const double *)dVals.p, (const int8_t *)dTypes.p, (int32_t *)dCnt.p, (double *)dSum.p, kLongRow);
+    if (!longRows.empty())
+      hipLaunchKernelGGL(rating_stats_long_kernel<double>, dim3((unsigned)longRows.size()), dim3(256), 0, nullptr, (const int64_t *)dPtr.p,
+                         (const int32_t *)dLong.p, (const double *)dVals.p, (const int8_t *)dTypes.p, (int32_t *)dCnt.p, (double *)dSum.p);
+  }
+  hipError_t le = hipGetLastError();
+  int rc = le == hipSuccess ? timed(e0, e1, deviceMs) : fail(YCNR_ERR_HIP, "rating_stats launch: %s", hipGetErrorString(le));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpy(cnt, dCnt.p, (size_t)rows * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(sum, dSum.p, (size_t)rows * 8, hipMemcpyDeviceToHost));
+  return YCNR_OK;
 }
 
 int ycnr_als_create(const ycnr_als_options *o, ycnr_als **out) {

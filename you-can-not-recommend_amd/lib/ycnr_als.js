@@ -48,5 +48,36 @@
       native.sRmsePortion(factorsCount, rmseRows, rmseIndx, rmseVals, userFactors, itemFactors, globalAvgShift || 0);
   };
 
+  /**
+   * EmfLord.doSplitToSets (lib/emf/EmfLord.js:402-505) for ratings held as CSR by user:
+   * completes `types` (Int8Array, 0 = unassigned, 1/2/3 = train/validate/test, others untouched)
+   * in place with the reference's per-user counts and a keyed, seedable shuffle.
+   * Returns the kernel time in ms.
+   */
+  als.splitToSets = function (rowPtr, types, dataSetDistr, seed) {
+    if (types.constructor !== Int8Array) throw new Error('invalid type!');
+    return native.splitToSets(rowPtr, types, dataSetDistr || [85, 10, 5], seed === undefined ? 1 : seed);
+  };
+
+  /**
+   * ratings_count / avg_rating of every row over dataset_type IN (1, 2, 3)
+   * (EmfLord.updateUsersStats / updateItemsStats, lib/emf/EmfLord.js:252-396).
+   * types may be null (every rating counts). Returns {cnt: Int32Array, avg: Float64Array,
+   * max, total, totalRatingsAvg}.
+   */
+  als.ratingStats = function (rowPtr, vals, types) {
+    typeCheck(vals);
+    var rows = rowPtr.length - 1, cnt = new Int32Array(rows), sum = new Float64Array(rows);
+    native.ratingStats(rowPtr, vals, types || null, cnt, sum);
+    var avg = new Float64Array(rows), max = 0, total = 0, totalSum = 0;
+    for (var r = 0; r < rows; r++) {
+      avg[r] = cnt[r] ? sum[r] / cnt[r] : 0;
+      if (cnt[r] > max) max = cnt[r];
+      total += cnt[r];
+      totalSum += sum[r];
+    }
+    return { cnt: cnt, avg: avg, max: max, total: total, totalRatingsAvg: total ? totalSum / total : 0 };
+  };
+
   module.exports = als;
 }());

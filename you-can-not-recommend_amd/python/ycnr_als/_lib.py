@@ -27,6 +27,7 @@ EXPORTS = [
     "ycnr_als_set_rmse_ratings", "ycnr_als_set_factors", "ycnr_als_get_factors", "ycnr_als_factors_ptr",
     "ycnr_als_bind_factors", "ycnr_als_step", "ycnr_als_step_async", "ycnr_als_sync",
     "ycnr_als_last_step_info", "ycnr_als_rmse",
+    "ycnr_split_to_sets", "ycnr_rating_stats",
 ]
 
 
@@ -104,6 +105,10 @@ def load():
     L.ycnr_als_last_step_info.argtypes = [vp, C.POINTER(StepInfo)]
     L.ycnr_als_rmse.restype = i32
     L.ycnr_als_rmse.argtypes = [vp, i32, dbl, i32, vp, vp]
+    L.ycnr_split_to_sets.restype = i32
+    L.ycnr_split_to_sets.argtypes = [i64, vp, vp, vp, C.c_uint32, C.POINTER(dbl)]
+    L.ycnr_rating_stats.restype = i32
+    L.ycnr_rating_stats.argtypes = [i32, i64, vp, vp, vp, vp, vp, C.POINTER(dbl)]
     _lib = L
     return L
 

@@ -76,6 +76,36 @@ def rmse_portion(k, rmseRows, rmseIndx, rmseVals, userFactors, itemFactors, glob
     return out
 
 
+def split_to_sets(rowPtr, types, dataSetDistr=(85, 10, 5), seed=1):
+    """EmfLord.doSplitToSets (lib/emf/EmfLord.js:402-505) on the GPU: completes the int8 array of
+    dataset types (0 = unassigned) of a CSR-by-user matrix.  Returns (types, kernel ms)."""
+    L = _lib.load()
+    rp = np.ascontiguousarray(rowPtr, np.int64)
+    t = np.array(types, np.int8, copy=True)
+    pc = np.asarray(dataSetDistr, np.int32)
+    ms = C.c_double(0.0)
+    _lib.check(L.ycnr_split_to_sets(len(rp) - 1, rp.ctypes.data, t.ctypes.data, pc.ctypes.data, int(seed) & 0xFFFFFFFF, C.byref(ms)))
+    return t, ms.value
+
+
+def rating_stats(rowPtr, vals, types=None):
+    """Per-row count and double sum of the ratings of type 1..3 (all when types is None): the
+    ratings_count / avg_rating columns of EmfLord.js:252-396.  Returns (cnt, sum, kernel ms)."""
+    L = _lib.load()
+    rp = np.ascontiguousarray(rowPtr, np.int64)
+    v = np.ascontiguousarray(vals)
+    if v.dtype not in (np.float32, np.float64):
+        raise TypeError("invalid type!")
+    rows = len(rp) - 1
+    cnt = np.zeros(rows, np.int32)
+    sm = np.zeros(rows, np.float64)
+    t = None if types is None else np.ascontiguousarray(types, np.int8)
+    ms = C.c_double(0.0)
+    _lib.check(L.ycnr_rating_stats(_lib.F64 if v.dtype == np.float64 else _lib.F32, rows, rp.ctypes.data, v.ctypes.data,
+                                   None if t is None else t.ctypes.data, cnt.ctypes.data, sm.ctypes.data, C.byref(ms)))
+    return cnt, sm, ms.value
+
+
 class AlsDevice:
     """Level 2: resident trainer handle (one per GPU / process)."""
 
