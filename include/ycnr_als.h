@@ -236,6 +236,29 @@ int ycnr_split_to_sets(int64_t rows, const int64_t *rowPtr, int8_t *types, const
 int ycnr_rating_stats(int dtype, int64_t rows, const int64_t *rowPtr, const void *vals, const int8_t *types,
                       int32_t *cnt, double *sum, double *deviceMs);
 
+/* ---- Ratings ingestion ------------------------------------------------------
+ *
+ * The reference feeds the path from PostgreSQL, portion by portion (EmfMaster.js:501-614), after
+ * importing MovieLens files into it (YcnrController.importML, lib/YcnrController.js:94-150).  Here
+ * the input of a training run is a pair of binary CSR files -- the train ratings by user and the
+ * same ratings by item -- in the layout below, produced once from (user, item, rating) triplets.
+ *
+ * ycnr_csr_from_triplets: CSR of n triplets (0-based ids), rows ordered by id, entries of a row
+ * by column id (the ORDER BY of EmfMaster.js:511-529), equal (row, col) pairs in input order.
+ * ycnr_csr_transpose: the same matrix by column (CSR by user -> CSR by item); entries of an
+ * output row are ordered by the input row id.  Host arrays in and out; the sort runs on the GPU.
+ *
+ * File layout (little endian, no padding): char magic[4] = "YCSR"; uint32 version = 1;
+ * uint32 dtype (YCNR_F32 / YCNR_F64); uint32 flags (bit 0: entries of every row ascending by
+ * column id); int64 rows, cols, nnz; int64 rowPtr[rows + 1]; int32 indx[nnz]; T vals[nnz].
+ * Readers and writers: python/ycnr_als/csrfile.py, lib/CsrFile.js (byte-identical output). */
+#define YCNR_CSR_MAGIC "YCSR"
+#define YCNR_CSR_VERSION 1
+int ycnr_csr_from_triplets(int dtype, int64_t n, const int32_t *rowIdx, const int32_t *colIdx, const void *vals,
+                           int64_t rows, int64_t cols, int64_t *rowPtr, int32_t *indx, void *outVals, double *deviceMs);
+int ycnr_csr_transpose(int dtype, int64_t rows, int64_t cols, const int64_t *rowPtr, const int32_t *indx, const void *vals,
+                       int64_t *outPtr, int32_t *outIndx, void *outVals, double *deviceMs);
+
 #ifdef __cplusplus
 }
 #endif

@@ -159,4 +159,30 @@ int oracle_split_to_sets(int64_t rows, const int64_t *rowPtr, int8_t *types, con
 ORACLE_STATS(oracle_sRatingStats, float)
 ORACLE_STATS(oracle_dRatingStats, double)
 
-int oracle_version(void) { return 2; }
+/* ---- N2: CSR from triplets ---------------------------------------------------
+ * rows by id, entries of a row by column id -- the ORDER BY user_list_id, item_id of
+ * EmfMaster.js:511-529 -- equal pairs in input order.  valSize = 4 or 8 (values are only moved). */
+typedef struct { uint64_t key; int64_t pos; } oracle_trip;
+static int oracle_trip_cmp(const void *a, const void *b) {
+  const oracle_trip *x = (const oracle_trip *)a, *y = (const oracle_trip *)b;
+  if (x->key != y->key) return x->key < y->key ? -1 : 1;
+  return x->pos < y->pos ? -1 : (x->pos > y->pos ? 1 : 0);
+}
+int oracle_csr_from_triplets(int valSize, int64_t n, const int32_t *rowIdx, const int32_t *colIdx, const void *vals,
+                             int64_t rows, int64_t *rowPtr, int32_t *indx, void *outVals) {
+  oracle_trip *t = (oracle_trip *)malloc((size_t)(n > 0 ? n : 1) * sizeof(oracle_trip));
+  if (!t) return -1;
+  for (int64_t q = 0; q < n; q++) { t[q].key = ((uint64_t)(uint32_t)rowIdx[q] << 32) | (uint32_t)colIdx[q]; t[q].pos = q; }
+  qsort(t, (size_t)n, sizeof(oracle_trip), oracle_trip_cmp);
+  for (int64_t r = 0; r <= rows; r++) rowPtr[r] = 0;
+  for (int64_t q = 0; q < n; q++) {
+    rowPtr[(t[q].key >> 32) + 1]++;
+    indx[q] = (int32_t)(uint32_t)t[q].key;
+    memcpy((char *)outVals + (size_t)q * valSize, (const char *)vals + (size_t)t[q].pos * valSize, (size_t)valSize);
+  }
+  for (int64_t r = 0; r < rows; r++) rowPtr[r + 1] += rowPtr[r];
+  free(t);
+  return 0;
+}
+
+int oracle_version(void) { return 3; }

@@ -59,6 +59,8 @@ def lib():
         f = getattr(L, f"oracle_{pfx}RatingStats")
         f.restype = None
         f.argtypes = [C.c_int64, i64p, fp, C.c_void_p, i32p, f64p]
+    L.oracle_csr_from_triplets.restype = C.c_int
+    L.oracle_csr_from_triplets.argtypes = [C.c_int, C.c_int64, i32p, i32p, C.c_void_p, C.c_int64, i64p, i32p, C.c_void_p]
     _lib = L
     return L
 
@@ -154,3 +156,17 @@ def rating_stats(rowPtr, vals, types=None):
     t = None if types is None else np.ascontiguousarray(types, np.int8)
     getattr(lib(), f"oracle_{_pfx(v.dtype)}RatingStats")(rows, rp, v, None if t is None else t.ctypes.data, cnt, sm)
     return cnt, sm
+
+
+def csr_from_triplets(row, col, vals, rows):
+    """(rowPtr, indx, vals) ordered by (row, col, input position)."""
+    r = np.ascontiguousarray(row, np.int32)
+    c = np.ascontiguousarray(col, np.int32)
+    v = np.ascontiguousarray(vals)
+    rp = np.zeros(rows + 1, np.int64)
+    ix = np.zeros(len(r), np.int32)
+    ov = np.zeros_like(v)
+    rc = lib().oracle_csr_from_triplets(v.dtype.itemsize, len(r), r, c, v.ctypes.data, rows, rp, ix, ov.ctypes.data)
+    if rc:
+        raise MemoryError("oracle_csr_from_triplets")
+    return rp, ix, ov

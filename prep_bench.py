@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""prep_bench.py -- N1: the train / validate / test split and the per-row rating
-statistics of the MAL-scale synthetic matrix on one GPU, next to the CPU oracle.
+"""prep_bench.py -- N1 and N2: the train / validate / test split, the per-row rating
+statistics and the construction of the CSR pair from triplets, for the MAL-scale synthetic matrix
+on one GPU, next to the CPU oracle.
 
 Prints one JSON line: kernel milliseconds (HIP events around the kernel, inputs resident), the
 rate in ratings/s, the algorithmic HBM bytes against the 8 TB/s roof, and the oracle's time on a
@@ -41,6 +42,16 @@ def main():
     types, ms_split = ycnr_als.split_to_sets(rp_u, types0, (85, 10, 5), 20260001)
     cnt_u, sum_u, ms_su = ycnr_als.rating_stats(rp_u, vals_u, types)
     cnt_i, sum_i, ms_si = ycnr_als.rating_stats(rp_i, vals_i, None)
+    # N2: the same matrix built from shuffled (user, item, rating) triplets, then transposed
+    from ycnr_als import csrfile
+    rows_of = torch.repeat_interleave(torch.arange(by_user.rows, device=dev, dtype=torch.int32), by_user.counts())
+    perm = torch.randperm(nnz, device=dev)
+    t_user, t_item, t_val = rows_of[perm].cpu().numpy(), by_user.indx[perm].cpu().numpy(), by_user.vals[perm].cpu().numpy()
+    del rows_of, perm
+    built, ms_build = csrfile.csr_from_triplets(t_user, t_item, t_val, by_user.rows, by_user.cols)
+    assert np.array_equal(built.rowPtr, rp_u) and np.array_equal(built.indx, by_user.indx.cpu().numpy()) and np.array_equal(built.vals, vals_u)
+    tr, ms_tr = csrfile.transpose(built)
+    assert np.array_equal(tr.rowPtr, rp_i) and np.array_equal(tr.indx, by_item.indx.cpu().numpy()) and np.array_equal(tr.vals, vals_i)
     # algorithmic bytes: the split reads and writes one byte per rating (+ row pointers); the
     # statistics read a rating and a type per rating and write 12 bytes per row
     b_split = 2 * nnz + 8 * (len(rp_u) - 1)
@@ -65,6 +76,11 @@ def main():
                      "rating_stats": round(b_stats / ((ms_su + ms_si) * 1e-3) / 1e9, 1),
                      "note": "the split is compute-bound (rank of every rating among its row's by a keyed order, O(n^2/64) per row); "
                              "the statistics stream the ratings once"},
+        "ingest": {"csr_from_triplets_ms": round(ms_build, 3), "csr_transpose_ms": round(ms_tr, 3),
+                   "ratings_per_s": nnz / ((ms_build + ms_tr) * 1e-3),
+                   # 12 B in + 8 B out per rating is the least a sort by (row, col) can move; the radix sort makes 6-7 passes
+                   "algorithmic_GBs": round(2 * 20 * nnz / ((ms_build + ms_tr) * 1e-3) / 1e9, 1),
+                   "checked": "equal to the generator's CSR by user and by item"},
         "sets": {"train": int(tot[1]), "validate": int(tot[2]), "test": int(tot[3])},
         "maxRatingsPerUser": int(cnt_u.max()), "maxRatingsPerItem": int(cnt_i.max()),
         "totalRatingsAvg": float(sum_u.sum() / cnt_u.sum()),

@@ -395,6 +395,60 @@ napi_value Rmse(napi_env env, napi_callback_info info) {
   return out;
 }
 
+// N2: csrFromTriplets(rowIdx: Int32Array, colIdx: Int32Array, vals, rows, cols, rowPtr: Float64Array(rows+1) out,
+//                     indx: Int32Array(n) out, outVals out) -> kernel ms
+napi_value CsrFromTriplets(napi_env env, napi_callback_info info) {
+  size_t argc = 8;
+  napi_value a[8];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, a, nullptr, nullptr));
+  if (argc < 8) return throw_msg(env, "csrFromTriplets(rowIdx, colIdx, vals, rows, cols, rowPtr, indx, outVals)");
+  View ri = view_of(env, a[0]), ci = view_of(env, a[1]), va = view_of(env, a[2]), rp = view_of(env, a[5]), ix = view_of(env, a[6]),
+       ov = view_of(env, a[7]);
+  int64_t rows, cols;
+  if (!ri.ok || !ci.ok || !va.ok || !rp.ok || !ix.ok || !ov.ok || !get_int(env, a[3], &rows) || !get_int(env, a[4], &cols) ||
+      ri.type != napi_int32_array || ci.type != napi_int32_array || ix.type != napi_int32_array || rp.type != napi_float64_array ||
+      (va.type != napi_float32_array && va.type != napi_float64_array) || ov.type != va.type)
+    return throw_msg(env, "invalid type!");
+  const size_t n = ri.length;
+  if (ci.length != n || va.length != n || ix.length < n || ov.length < n || rows < 0 || rp.length != (size_t)rows + 1)
+    return throw_msg(env, "array lengths do not match");
+  std::vector<int64_t> rowPtr((size_t)rows + 1);
+  double ms = 0;
+  if (ycnr_csr_from_triplets(va.type == napi_float64_array ? YCNR_F64 : YCNR_F32, (int64_t)n, static_cast<const int32_t *>(ri.data),
+                             static_cast<const int32_t *>(ci.data), va.data, rows, cols, rowPtr.data(), static_cast<int32_t *>(ix.data),
+                             ov.data, &ms))
+    return throw_msg(env, ycnr_last_error());
+  for (size_t r = 0; r < rowPtr.size(); ++r) static_cast<double *>(rp.data)[r] = (double)rowPtr[r];
+  return num(env, ms);
+}
+
+// N2: csrTranspose(rows, cols, rowPtr, indx, vals, outPtr: Float64Array(cols+1), outIndx, outVals) -> kernel ms
+napi_value CsrTranspose(napi_env env, napi_callback_info info) {
+  size_t argc = 8;
+  napi_value a[8];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, a, nullptr, nullptr));
+  if (argc < 8) return throw_msg(env, "csrTranspose(rows, cols, rowPtr, indx, vals, outPtr, outIndx, outVals)");
+  int64_t rows, cols;
+  View rp = view_of(env, a[2]), ix = view_of(env, a[3]), va = view_of(env, a[4]), op = view_of(env, a[5]), oi = view_of(env, a[6]),
+       ov = view_of(env, a[7]);
+  std::vector<int64_t> rowPtr;
+  if (!get_int(env, a[0], &rows) || !get_int(env, a[1], &cols) || !rp.ok || !ix.ok || !va.ok || !op.ok || !oi.ok || !ov.ok ||
+      !to_i64(rp, rowPtr) || ix.type != napi_int32_array || oi.type != napi_int32_array || op.type != napi_float64_array ||
+      (va.type != napi_float32_array && va.type != napi_float64_array) || ov.type != va.type)
+    return throw_msg(env, "invalid type!");
+  if (rows < 0 || cols < 0 || rowPtr.size() != (size_t)rows + 1 || op.length != (size_t)cols + 1) return throw_msg(env, "array lengths do not match");
+  const int64_t n = rowPtr.back();
+  if (n < 0 || (size_t)n > ix.length || (size_t)n > va.length || (size_t)n > oi.length || (size_t)n > ov.length)
+    return throw_msg(env, "indx / vals shorter than rowPtr says");
+  std::vector<int64_t> outPtr((size_t)cols + 1);
+  double ms = 0;
+  if (ycnr_csr_transpose(va.type == napi_float64_array ? YCNR_F64 : YCNR_F32, rows, cols, rowPtr.data(), static_cast<const int32_t *>(ix.data),
+                         va.data, outPtr.data(), static_cast<int32_t *>(oi.data), ov.data, &ms))
+    return throw_msg(env, ycnr_last_error());
+  for (size_t c = 0; c < outPtr.size(); ++c) static_cast<double *>(op.data)[c] = (double)outPtr[c];
+  return num(env, ms);
+}
+
 // N1: splitToSets(rowPtr, types: Int8Array (in/out), dataSetDistr: [train, validate, test], seed) -> kernel ms
 // (EmfLord.doSplitToSets, lib/emf/EmfLord.js:402-505)
 napi_value SplitToSets(napi_env env, napi_callback_info info) {
@@ -465,6 +519,8 @@ napi_value Init(napi_env env, napi_value exports) {
       {"rmse", nullptr, Rmse, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
       {"splitToSets", nullptr, SplitToSets, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
       {"ratingStats", nullptr, RatingStats, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+      {"csrFromTriplets", nullptr, CsrFromTriplets, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+      {"csrTranspose", nullptr, CsrTranspose, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
   };
   napi_define_properties(env, exports, sizeof(props) / sizeof(props[0]), props);
   return exports;

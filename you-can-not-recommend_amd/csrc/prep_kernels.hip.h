@@ -186,4 +186,46 @@ __global__ __launch_bounds__(256) void rating_stats_long_kernel(const int64_t *r
   }
 }
 
+// ---- N2: CSR construction (sort by a 64-bit (row, col) key with rocPRIM's radix sort; these
+// kernels build the keys and unpack the result) ----
+__global__ void make_keys_kernel(const int32_t *rowIdx, const int32_t *colIdx, int64_t n, uint64_t *keys, uint32_t *pos) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  keys[q] = ((uint64_t)(uint32_t)rowIdx[q] << 32) | (uint32_t)colIdx[q];
+  pos[q] = (uint32_t)q;
+}
+// transposing: entry q of a CSR belongs to row = upper_bound(rowPtr, q) - 1; its key is (col, row)
+__global__ void make_transpose_keys_kernel(const int64_t *rowPtr, int64_t rows, const int32_t *indx, int64_t n, uint64_t *keys,
+                                           uint32_t *pos) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  int64_t lo = 0, hi = rows;  // first r with rowPtr[r + 1] > q
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (rowPtr[mid + 1] <= q) lo = mid + 1;
+    else hi = mid;
+  }
+  keys[q] = ((uint64_t)(uint32_t)indx[q] << 32) | (uint32_t)lo;
+  pos[q] = (uint32_t)q;
+}
+template <typename T>
+__global__ void unpack_sorted_kernel(const uint64_t *keys, const uint32_t *pos, const T *vals, int64_t n, int32_t *indx, T *outVals) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  indx[q] = (int32_t)(uint32_t)keys[q];
+  outVals[q] = vals[pos[q]];
+}
+// rowPtr[r] = first sorted position whose row (high key half) is >= r, r = 0..rows
+__global__ void row_ptr_kernel(const uint64_t *keys, int64_t n, int64_t rows, int64_t *rowPtr) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > rows) return;
+  int64_t lo = 0, hi = n;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if ((int64_t)(keys[mid] >> 32) < r) lo = mid + 1;
+    else hi = mid;
+  }
+  rowPtr[r] = lo;
+}
+
 }  // namespace ycnr

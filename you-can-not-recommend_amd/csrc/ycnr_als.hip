@@ -8,6 +8,7 @@
 #include "als_kernels.hip.h"
 #include "als_big_kernels.hip.h"
 #include "prep_kernels.hip.h"
+#include <hipcub/hipcub.hpp>
 #include "prep_kernels.hip.h"
 
 #include <algorithm>
@@ -620,6 +621,125 @@ int ycnr_rating_stats(int dtype, int64_t rows, const int64_t *rowPtr, const void
   HIP_TRY(hipMemcpy(cnt, dCnt.p, (size_t)rows * 4, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(sum, dSum.p, (size_t)rows * 8, hipMemcpyDeviceToHost));
   return YCNR_OK;
+}
+
+// ---- N2: CSR from triplets / transpose ----
+namespace {
+int bits_for(int64_t n) {
+  int b = 1;
+  while (b < 32 && ((int64_t)1 << b) < n) ++b;
+  return b;
+}
+// keys / pos prepared on the device; sorts, unpacks into host arrays
+int sort_and_unpack(int dtype, int64_t n, int64_t outRows, int64_t outCols, uint64_t *dKeys, uint32_t *dPos, const void *dVals,
+                    int64_t *rowPtr, int32_t *indx, void *outVals, hipEvent_t e0, hipEvent_t e1, double *deviceMs) {
+  const size_t ts = tsize(dtype);
+  DevBuf dKeys2, dPos2, dTmp, dIndx, dOutVals, dPtr;
+  HIP_TRY(hipMalloc(&dKeys2.p, (size_t)n * 8));
+  HIP_TRY(hipMalloc(&dPos2.p, (size_t)n * 4));
+  HIP_TRY(hipMalloc(&dIndx.p, (size_t)n * 4));
+  HIP_TRY(hipMalloc(&dOutVals.p, (size_t)n * ts));
+  HIP_TRY(hipMalloc(&dPtr.p, (size_t)(outRows + 1) * 8));
+  size_t tmpBytes = 0;
+  const int endBit = 32 + bits_for(outRows);
+  (void)outCols;
+  HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmpBytes, dKeys, (uint64_t *)dKeys2.p, dPos, (uint32_t *)dPos2.p, (int)n, 0, endBit));
+  HIP_TRY(hipMalloc(&dTmp.p, std::max<size_t>(tmpBytes, 8)));
+  HIP_TRY(hipcub::DeviceRadixSort::SortPairs(dTmp.p, tmpBytes, dKeys, (uint64_t *)dKeys2.p, dPos, (uint32_t *)dPos2.p, (int)n, 0, endBit));
+  const unsigned b256 = (unsigned)((n + 255) / 256);
+  if (dtype == YCNR_F32)
+    hipLaunchKernelGGL(unpack_sorted_kernel<float>, dim3(b256), dim3(256), 0, nullptr, (const uint64_t *)dKeys2.p, (const uint32_t *)dPos2.p,
+                       (const float *)dVals, n, (int32_t *)dIndx.p, (float *)dOutVals.p);
+  else
+    hipLaunchKernelGGL(unpack_sorted_kernel<double>, dim3(b256), dim3(256), 0, nullptr, (const uint64_t *)dKeys2.p, (const uint32_t *)dPos2.p,
+                       (const double *)dVals, n, (int32_t *)dIndx.p, (double *)dOutVals.p);
+  hipLaunchKernelGGL(row_ptr_kernel, dim3((unsigned)((outRows + 1 + 255) / 256)), dim3(256), 0, nullptr, (const uint64_t *)dKeys2.p, n, outRows,
+                     (int64_t *)dPtr.p);
+  hipError_t le = hipGetLastError();
+  if (le != hipSuccess) return fail(YCNR_ERR_HIP, "csr build: %s", hipGetErrorString(le));
+  int rc = timed(e0, e1, deviceMs);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpy(rowPtr, dPtr.p, (size_t)(outRows + 1) * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(indx, dIndx.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(outVals, dOutVals.p, (size_t)n * ts, hipMemcpyDeviceToHost));
+  return YCNR_OK;
+}
+}  // namespace
+
+int ycnr_csr_from_triplets(int dtype, int64_t n, const int32_t *rowIdx, const int32_t *colIdx, const void *vals,
+                           int64_t rows, int64_t cols, int64_t *rowPtr, int32_t *indx, void *outVals, double *deviceMs) {
+  if (dtype != YCNR_F32 && dtype != YCNR_F64) return fail(YCNR_ERR_INVALID, "bad dtype %d", dtype);
+  if (n < 0 || rows < 0 || cols < 0 || !rowPtr) return fail(YCNR_ERR_INVALID, "ycnr_csr_from_triplets: bad sizes / null rowPtr");
+  if (rows >= ((int64_t)1 << 31) || cols >= ((int64_t)1 << 31) || n >= ((int64_t)1 << 31))
+    return fail(YCNR_ERR_UNSUPPORTED, "ycnr_csr_from_triplets: more than 2^31 rows, columns or ratings");
+  if (n == 0) {
+    for (int64_t r = 0; r <= rows; ++r) rowPtr[r] = 0;
+    return YCNR_OK;
+  }
+  if (!rowIdx || !colIdx || !vals || !indx || !outVals) return fail(YCNR_ERR_INVALID, "ycnr_csr_from_triplets: null array");
+  for (int64_t q = 0; q < n; ++q)
+    if (rowIdx[q] < 0 || rowIdx[q] >= rows || colIdx[q] < 0 || colIdx[q] >= cols)
+      return fail(YCNR_ERR_INVALID, "triplet %lld: (%d, %d) outside %lld x %lld", (long long)q, rowIdx[q], colIdx[q], (long long)rows,
+                  (long long)cols);
+  const size_t ts = tsize(dtype);
+  DevBuf dR, dC, dV, dKeys, dPos;
+  HIP_TRY(hipMalloc(&dR.p, (size_t)n * 4));
+  HIP_TRY(hipMalloc(&dC.p, (size_t)n * 4));
+  HIP_TRY(hipMalloc(&dV.p, (size_t)n * ts));
+  HIP_TRY(hipMalloc(&dKeys.p, (size_t)n * 8));
+  HIP_TRY(hipMalloc(&dPos.p, (size_t)n * 4));
+  HIP_TRY(hipMemcpy(dR.p, rowIdx, (size_t)n * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dC.p, colIdx, (size_t)n * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dV.p, vals, (size_t)n * ts, hipMemcpyHostToDevice));
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  HIP_TRY(hipEventRecord(e0, nullptr));
+  hipLaunchKernelGGL(make_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, (const int32_t *)dR.p, (const int32_t *)dC.p, n,
+                     (uint64_t *)dKeys.p, (uint32_t *)dPos.p);
+  int rc = sort_and_unpack(dtype, n, rows, cols, (uint64_t *)dKeys.p, (uint32_t *)dPos.p, dV.p, rowPtr, indx, outVals, e0, e1, deviceMs);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return rc;
+}
+
+int ycnr_csr_transpose(int dtype, int64_t rows, int64_t cols, const int64_t *rowPtr, const int32_t *indx, const void *vals,
+                       int64_t *outPtr, int32_t *outIndx, void *outVals, double *deviceMs) {
+  if (dtype != YCNR_F32 && dtype != YCNR_F64) return fail(YCNR_ERR_INVALID, "bad dtype %d", dtype);
+  if (rows < 0 || cols < 0 || !rowPtr || !outPtr) return fail(YCNR_ERR_INVALID, "ycnr_csr_transpose: bad sizes / null rowPtr");
+  if (rowPtr[0] != 0) return fail(YCNR_ERR_INVALID, "ycnr_csr_transpose: rowPtr[0] != 0");
+  const int64_t n = rowPtr[rows];
+  if (rows >= ((int64_t)1 << 31) || cols >= ((int64_t)1 << 31) || n >= ((int64_t)1 << 31))
+    return fail(YCNR_ERR_UNSUPPORTED, "ycnr_csr_transpose: more than 2^31 rows, columns or ratings");
+  for (int64_t r = 0; r < rows; ++r)
+    if (rowPtr[r + 1] < rowPtr[r]) return fail(YCNR_ERR_INVALID, "ycnr_csr_transpose: rowPtr decreases at row %lld", (long long)r);
+  if (n == 0) {
+    for (int64_t c = 0; c <= cols; ++c) outPtr[c] = 0;
+    return YCNR_OK;
+  }
+  if (!indx || !vals || !outIndx || !outVals) return fail(YCNR_ERR_INVALID, "ycnr_csr_transpose: null array");
+  for (int64_t q = 0; q < n; ++q)
+    if (indx[q] < 0 || indx[q] >= cols) return fail(YCNR_ERR_INVALID, "entry %lld: column %d outside %lld", (long long)q, indx[q], (long long)cols);
+  const size_t ts = tsize(dtype);
+  DevBuf dP, dI, dV, dKeys, dPos;
+  HIP_TRY(hipMalloc(&dP.p, (size_t)(rows + 1) * 8));
+  HIP_TRY(hipMalloc(&dI.p, (size_t)n * 4));
+  HIP_TRY(hipMalloc(&dV.p, (size_t)n * ts));
+  HIP_TRY(hipMalloc(&dKeys.p, (size_t)n * 8));
+  HIP_TRY(hipMalloc(&dPos.p, (size_t)n * 4));
+  HIP_TRY(hipMemcpy(dP.p, rowPtr, (size_t)(rows + 1) * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dI.p, indx, (size_t)n * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dV.p, vals, (size_t)n * ts, hipMemcpyHostToDevice));
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  HIP_TRY(hipEventRecord(e0, nullptr));
+  hipLaunchKernelGGL(make_transpose_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, (const int64_t *)dP.p, rows,
+                     (const int32_t *)dI.p, n, (uint64_t *)dKeys.p, (uint32_t *)dPos.p);
+  int rc = sort_and_unpack(dtype, n, cols, rows, (uint64_t *)dKeys.p, (uint32_t *)dPos.p, dV.p, outPtr, outIndx, outVals, e0, e1, deviceMs);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return rc;
 }
 
 int ycnr_als_create(const ycnr_als_options *o, ycnr_als **out) {

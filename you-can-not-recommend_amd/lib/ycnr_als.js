@@ -79,5 +79,24 @@
     return { cnt: cnt, avg: avg, max: max, total: total, totalRatingsAvg: total ? totalSum / total : 0 };
   };
 
+  /**
+   * CSR of (row, col, value) triplets, rows by id and entries of a row by column id (the
+   * ORDER BY of lib/emf/EmfMaster.js:511-529), sorted on the GPU. Returns {rowPtr, indx, vals}.
+   */
+  als.csrFromTriplets = function (rowIdx, colIdx, vals, rows, cols) {
+    typeCheck(vals);
+    var n = rowIdx.length, rowPtr = new Float64Array(rows + 1), indx = new Int32Array(n), out = new vals.constructor(n);
+    native.csrFromTriplets(rowIdx, colIdx, vals, rows, cols, rowPtr, indx, out);
+    return { rowPtr: rowPtr, indx: indx, vals: out };
+  };
+
+  /** The same ratings by column: CSR by user -> CSR by item. Returns {rowPtr, indx, vals}. */
+  als.csrTranspose = function (rows, cols, rowPtr, indx, vals) {
+    typeCheck(vals);
+    var n = rowPtr[rows], outPtr = new Float64Array(cols + 1), outIndx = new Int32Array(n), out = new vals.constructor(n);
+    native.csrTranspose(rows, cols, rowPtr, indx, vals, outPtr, outIndx, out);
+    return { rowPtr: outPtr, indx: outIndx, vals: out };
+  };
+
   module.exports = als;
 }());

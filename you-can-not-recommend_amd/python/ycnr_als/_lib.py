@@ -27,7 +27,7 @@ EXPORTS = [
     "ycnr_als_set_rmse_ratings", "ycnr_als_set_factors", "ycnr_als_get_factors", "ycnr_als_factors_ptr",
     "ycnr_als_bind_factors", "ycnr_als_step", "ycnr_als_step_async", "ycnr_als_sync",
     "ycnr_als_last_step_info", "ycnr_als_rmse",
-    "ycnr_split_to_sets", "ycnr_rating_stats",
+    "ycnr_split_to_sets", "ycnr_rating_stats", "ycnr_csr_from_triplets", "ycnr_csr_transpose",
 ]
 
 
@@ -109,6 +109,10 @@ def load():
     L.ycnr_split_to_sets.argtypes = [i64, vp, vp, vp, C.c_uint32, C.POINTER(dbl)]
     L.ycnr_rating_stats.restype = i32
     L.ycnr_rating_stats.argtypes = [i32, i64, vp, vp, vp, vp, vp, C.POINTER(dbl)]
+    L.ycnr_csr_from_triplets.restype = i32
+    L.ycnr_csr_from_triplets.argtypes = [i32, i64, vp, vp, vp, i64, i64, vp, vp, vp, C.POINTER(dbl)]
+    L.ycnr_csr_transpose.restype = i32
+    L.ycnr_csr_transpose.argtypes = [i32, i64, i64, vp, vp, vp, vp, vp, vp, C.POINTER(dbl)]
     _lib = L
     return L
 
