@@ -259,6 +259,22 @@ int ycnr_csr_from_triplets(int dtype, int64_t n, const int32_t *rowIdx, const in
 int ycnr_csr_transpose(int dtype, int64_t rows, int64_t cols, const int64_t *rowPtr, const int32_t *indx, const void *vals,
                        int64_t *outPtr, int32_t *outIndx, void *outVals, double *deviceMs);
 
+/* ---- Top-N recommend ---------------------------------------------------------
+ *
+ * ycnr_recommend_items replaces the loop of YcnrController.recommendItemsForUser
+ * (lib/YcnrController.js:255-274) for a batch of users: for every item id 0 .. totalItems-1 that is
+ * not in the user's skip list (rated + "unrated_items" ids, :244-250),
+ *   predict = userRow . itemFactors[item] + globalAvgShift        (EmfBase._alsPredict, EmfBase.js:825-827)
+ * items with predict >= minRecommendRating compete, best first.  The reference pushes, sorts and
+ * pops so that its list never holds more than limit - 1 items (:264-269: the pop happens when the
+ * length REACHES limit); outCount[u] <= limit - 1 reproduces that.  Equal predicts rank by item
+ * id (the reference's Array.sort leaves them unspecified on the Node versions of its time).
+ * userRows: nUsers x k; itemFactors: totalItems x k; skipPtr / skipIds: CSR of 0-based item ids,
+ * ascending per user; outIds / outPredict: nUsers x limit (unused slots -1 / 0).  Host arrays. */
+int ycnr_recommend_items(int dtype, int32_t k, int64_t nUsers, const void *userRows, int64_t totalItems, const void *itemFactors,
+                         const int64_t *skipPtr, const int32_t *skipIds, double globalAvgShift, double minRecommendRating,
+                         int32_t limit, int32_t *outIds, double *outPredict, int32_t *outCount, double *deviceMs);
+
 #ifdef __cplusplus
 }
 #endif

@@ -185,4 +185,35 @@ int oracle_csr_from_triplets(int valSize, int64_t n, const int32_t *rowIdx, cons
   return 0;
 }
 
-int oracle_version(void) { return 3; }
+/* ---- N3: top-N recommend -----------------------------------------------------
+ * The loop of YcnrController.recommendItemsForUser (lib/YcnrController.js:255-274) statement by
+ * statement, for one user: recItems.push / sort (descending predict; equal predicts keep their
+ * push order = ascending item id) / minRatingInSelection / pop.  skip = ascending 0-based ids.
+ * predict = uF.dot(iF) + globalAvgShift (EmfBase.js:825-827), the dot accumulated in T in index
+ * order.  Returns recItems.length (<= limit - 1, the reference's off-by-one). */
+#define ORACLE_RECOMMEND(NAME, T)                                                                              \
+  int NAME(int k, const T *uF, int64_t totalItems, const T *items, int64_t nSkip, const int32_t *skip,        \
+           double shift, double minRecommendRating, int limit, int32_t *outIds, double *outPredict) {          \
+    int len = 0;                                                                                               \
+    double minRatingInSelection = 0;                                                                           \
+    int64_t sp = 0;                                                                                            \
+    for (int64_t itemId0 = 0; itemId0 < totalItems; itemId0++) {                                               \
+      while (sp < nSkip && skip[sp] < itemId0) sp++;                                                           \
+      if (sp < nSkip && skip[sp] == itemId0) continue;                  /* if (!skipItemIds[itemId1]) */       \
+      T dot = 0;                                                                                               \
+      for (int f = 0; f < k; f++) dot += uF[f] * items[itemId0 * k + f];                                       \
+      const double predict = (double)dot + shift;                                                              \
+      if (predict >= minRecommendRating && (len < limit || predict > minRatingInSelection)) {                  \
+        int p = len++;                                                   /* push, then a stable sort */        \
+        while (p > 0 && outPredict[p - 1] < predict) { outPredict[p] = outPredict[p - 1]; outIds[p] = outIds[p - 1]; p--; } \
+        outPredict[p] = predict; outIds[p] = (int32_t)itemId0;                                                 \
+        if (predict > minRatingInSelection) minRatingInSelection = predict;                                    \
+        if (len >= limit) len--;                                         /* recItems.pop() */                  \
+      }                                                                                                        \
+    }                                                                                                          \
+    return len;                                                                                                \
+  }
+ORACLE_RECOMMEND(oracle_sRecommend, float)
+ORACLE_RECOMMEND(oracle_dRecommend, double)
+
+int oracle_version(void) { return 4; }

@@ -59,6 +59,10 @@ def lib():
         f = getattr(L, f"oracle_{pfx}RatingStats")
         f.restype = None
         f.argtypes = [C.c_int64, i64p, fp, C.c_void_p, i32p, f64p]
+    for pfx, fp in (("s", f32p), ("d", f64p)):
+        f = getattr(L, f"oracle_{pfx}Recommend")
+        f.restype = C.c_int
+        f.argtypes = [C.c_int, fp, C.c_int64, fp, C.c_int64, i32p, C.c_double, C.c_double, C.c_int, i32p, f64p]
     L.oracle_csr_from_triplets.restype = C.c_int
     L.oracle_csr_from_triplets.argtypes = [C.c_int, C.c_int64, i32p, i32p, C.c_void_p, C.c_int64, i64p, i32p, C.c_void_p]
     _lib = L
@@ -170,3 +174,16 @@ def csr_from_triplets(row, col, vals, rows):
     if rc:
         raise MemoryError("oracle_csr_from_triplets")
     return rp, ix, ov
+
+
+def recommend(user_row, items, skip, shift, min_rating, limit):
+    """YcnrController.recommendItemsForUser (lib/YcnrController.js:255-274) for one user.
+    Returns (ids, predicts) of recItems, best first."""
+    it = np.ascontiguousarray(items)
+    u = np.ascontiguousarray(user_row, it.dtype)
+    sk = np.ascontiguousarray(skip, np.int32)
+    ids = np.zeros(limit + 1, np.int32)
+    pr = np.zeros(limit + 1, np.float64)
+    n = getattr(lib(), f"oracle_{_pfx(it.dtype)}Recommend")(it.shape[1], u, it.shape[0], it, len(sk), sk, float(shift), float(min_rating),
+                                                          int(limit), ids, pr)
+    return ids[:n].copy(), pr[:n].copy()

@@ -52,6 +52,20 @@ def main():
     assert np.array_equal(built.rowPtr, rp_u) and np.array_equal(built.indx, by_user.indx.cpu().numpy()) and np.array_equal(built.vals, vals_u)
     tr, ms_tr = csrfile.transpose(built)
     assert np.array_equal(tr.rowPtr, rp_i) and np.array_equal(tr.indx, by_item.indx.cpu().numpy()) and np.array_equal(tr.vals, vals_i)
+    # N3: top-N recommend for 2048 users against all items (k = 100 random factors, the users' rated items skipped)
+    rng = np.random.default_rng(3)
+    kf, nrec = 100, 2048
+    Vf = (rng.standard_normal((by_user.cols, kf)) * 0.8 / np.sqrt(kf) * 3).astype(np.float32)
+    Uf = (rng.standard_normal((nrec, kf)) * 0.8 / np.sqrt(kf) * 3).astype(np.float32)
+    sp = (rp_u[:nrec + 1] - rp_u[0]).astype(np.int64)
+    sk = by_user.indx[:int(rp_u[nrec])].cpu().numpy()
+    ycnr_als.recommend_items(Uf[:8], Vf, sp[:9], sk[:int(sp[8])], 6.4, 7.0, 20)  # warm-up
+    rec_ids, rec_pred, rec_cnt, ms_rec = ycnr_als.recommend_items(Uf, Vf, sp, sk, globalAvgShift=6.4, minRecommendRating=7.0, limit=20)
+    t0r = time.perf_counter()
+    for uu in range(64):
+        oid, opr = orc.recommend(Uf[uu], Vf, sk[sp[uu]:sp[uu + 1]], 6.4, 7.0, 20)
+        assert len(oid) == rec_cnt[uu] and np.allclose(opr, rec_pred[uu, :len(oid)], atol=1e-4)
+    cpu_rec_s = (time.perf_counter() - t0r) / 64
     # algorithmic bytes: the split reads and writes one byte per rating (+ row pointers); the
     # statistics read a rating and a type per rating and write 12 bytes per row
     b_split = 2 * nnz + 8 * (len(rp_u) - 1)
@@ -81,6 +95,12 @@ def main():
                    # 12 B in + 8 B out per rating is the least a sort by (row, col) can move; the radix sort makes 6-7 passes
                    "algorithmic_GBs": round(2 * 20 * nnz / ((ms_build + ms_tr) * 1e-3) / 1e9, 1),
                    "checked": "equal to the generator's CSR by user and by item"},
+        "recommend": {"users": nrec, "items": int(by_user.cols), "factorsCount": kf, "limit": 20, "kernel_ms": round(ms_rec, 3),
+                      "users_per_s": nrec / (ms_rec * 1e-3),
+                      # every user reads the whole item matrix (L2-resident) and writes / re-reads a score per item
+                      "algorithmic_GBs": round(nrec * by_user.cols * (kf * 4 + 16) / (ms_rec * 1e-3) / 1e9, 1),
+                      "mean_recommended": float(rec_cnt.mean()), "cpu_oracle_s_per_user": round(cpu_rec_s, 5),
+                      "checked": "64 users against the oracle"},
         "sets": {"train": int(tot[1]), "validate": int(tot[2]), "test": int(tot[3])},
         "maxRatingsPerUser": int(cnt_u.max()), "maxRatingsPerItem": int(cnt_i.max()),
         "totalRatingsAvg": float(sum_u.sum() / cnt_u.sum()),

@@ -12,5 +12,11 @@ const ms = als.splitToSets(rowPtr, types, input.dataSetDistr, input.seed);
 const st = als.ratingStats(rowPtr, vals, types);
 let bad = null;
 try { als.splitToSets(rowPtr, new Int32Array(types.length), input.dataSetDistr, input.seed); } catch (e) { bad = e.message; }
-console.log(JSON.stringify({ ms, types: Array.from(types), cnt: Array.from(st.cnt), avg: Array.from(st.avg), max: st.max,
+// N3 for one user: ids 1-based in and out, as the controller uses them
+let rec = null;
+if (input.rec) {
+  const F = Float32Array;
+  rec = als.recommendItemsForUser(F.from(input.rec.user), F.from(input.rec.items), input.rec.k, input.rec.skip1, input.rec.shift, input.rec.min, input.rec.limit);
+}
+console.log(JSON.stringify({ rec, ms, types: Array.from(types), cnt: Array.from(st.cnt), avg: Array.from(st.avg), max: st.max,
   total: st.total, totalRatingsAvg: st.totalRatingsAvg, wrongTypeMessage: bad }));

@@ -118,8 +118,14 @@ def test_node_split_and_stats_on_gpu(tmp_path):
     rowPtr[1:] = np.cumsum(lens)
     types = rng.choice(np.array([0, 0, 0, 1, 2, 4], np.int8), rowPtr[-1])
     vals = rng.integers(1, 6, rowPtr[-1]).astype(np.float32)
+    k, items = 12, 90
+    Vf = (rng.standard_normal((items, k)) * 0.9).astype(np.float32)
+    uf = (rng.standard_normal(k) * 0.9).astype(np.float32)
+    skip1 = [5, 1, 17, 5, 60]   # 1-based, unsorted, one duplicate: the wrapper sorts and de-duplicates
     (tmp_path / "in.json").write_text(json.dumps({"rowPtr": rowPtr.tolist(), "types": types.tolist(), "vals": vals.tolist(),
-                                                  "dataSetDistr": [85, 10, 5], "seed": 77}))
+                                                  "dataSetDistr": [85, 10, 5], "seed": 77,
+                                                  "rec": {"user": uf.tolist(), "items": Vf.ravel().tolist(), "k": k, "skip1": skip1,
+                                                          "shift": 0.2, "min": 0.5, "limit": 8}}))
     r = subprocess.run(["node", os.path.join(HERE, "js", "prep_gpu.js"), str(tmp_path / "in.json")], capture_output=True,
                        text=True, timeout=300)
     assert r.returncode == 0, r.stderr
@@ -133,4 +139,7 @@ def test_node_split_and_stats_on_gpu(tmp_path):
     assert out["max"] == cnt.max() and out["total"] == cnt.sum()
     assert np.isclose(out["totalRatingsAvg"], sm.sum() / cnt.sum(), rtol=1e-13)
     assert out["wrongTypeMessage"] == "invalid type!"
+    oid, opr = orc.recommend(uf, Vf, np.array([0, 4, 16, 59], np.int32), 0.2, 0.5, 8)
+    assert [r["id"] for r in out["rec"]] == (oid + 1).tolist() and len(oid) <= 7
+    assert np.allclose([r["predict"] for r in out["rec"]], opr, atol=1e-5)
 

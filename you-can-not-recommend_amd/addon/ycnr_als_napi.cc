@@ -395,6 +395,36 @@ napi_value Rmse(napi_env env, napi_callback_info info) {
   return out;
 }
 
+// N3: recommendItems(userRows, itemFactors, k, skipPtr, skipIds: Int32Array, globalAvgShift, minRecommendRating, limit,
+//                    outIds: Int32Array(nUsers * limit), outPredict: Float64Array(nUsers * limit), outCount: Int32Array(nUsers)) -> kernel ms
+napi_value RecommendItems(napi_env env, napi_callback_info info) {
+  size_t argc = 11;
+  napi_value a[11];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, a, nullptr, nullptr));
+  if (argc < 11) return throw_msg(env, "recommendItems(userRows, itemFactors, k, skipPtr, skipIds, shift, minRating, limit, outIds, outPredict, outCount)");
+  View ur = view_of(env, a[0]), it = view_of(env, a[1]), sp = view_of(env, a[3]), sk = view_of(env, a[4]), oi = view_of(env, a[8]),
+       op = view_of(env, a[9]), oc = view_of(env, a[10]);
+  int64_t k, limit;
+  double shift, minRating;
+  std::vector<int64_t> skipPtr;
+  if (!ur.ok || !it.ok || !sp.ok || !sk.ok || !oi.ok || !op.ok || !oc.ok || !get_int(env, a[2], &k) || !get_double(env, a[5], &shift) ||
+      !get_double(env, a[6], &minRating) || !get_int(env, a[7], &limit) || !to_i64(sp, skipPtr) || skipPtr.empty() ||
+      (it.type != napi_float32_array && it.type != napi_float64_array) || ur.type != it.type || sk.type != napi_int32_array ||
+      oi.type != napi_int32_array || op.type != napi_float64_array || oc.type != napi_int32_array)
+    return throw_msg(env, "invalid type!");  // cpp_utils/cpp_utils.js:12
+  if (k < 1 || limit < 1 || ur.length % (size_t)k || it.length % (size_t)k) return throw_msg(env, "factor arrays are not multiples of k");
+  const size_t nUsers = ur.length / (size_t)k;
+  if (skipPtr.size() != nUsers + 1 || skipPtr.back() < 0 || (size_t)skipPtr.back() > sk.length || oi.length < nUsers * (size_t)limit ||
+      op.length < nUsers * (size_t)limit || oc.length < nUsers)
+    return throw_msg(env, "array lengths do not match");
+  double ms = 0;
+  if (ycnr_recommend_items(it.type == napi_float64_array ? YCNR_F64 : YCNR_F32, (int32_t)k, (int64_t)nUsers, ur.data, (int64_t)(it.length / (size_t)k),
+                           it.data, skipPtr.data(), static_cast<const int32_t *>(sk.data), shift, minRating, (int32_t)limit,
+                           static_cast<int32_t *>(oi.data), static_cast<double *>(op.data), static_cast<int32_t *>(oc.data), &ms))
+    return throw_msg(env, ycnr_last_error());
+  return num(env, ms);
+}
+
 // N2: csrFromTriplets(rowIdx: Int32Array, colIdx: Int32Array, vals, rows, cols, rowPtr: Float64Array(rows+1) out,
 //                     indx: Int32Array(n) out, outVals out) -> kernel ms
 napi_value CsrFromTriplets(napi_env env, napi_callback_info info) {
@@ -521,6 +551,7 @@ napi_value Init(napi_env env, napi_value exports) {
       {"ratingStats", nullptr, RatingStats, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
       {"csrFromTriplets", nullptr, CsrFromTriplets, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
       {"csrTranspose", nullptr, CsrTranspose, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+      {"recommendItems", nullptr, RecommendItems, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
   };
   napi_define_properties(env, exports, sizeof(props) / sizeof(props[0]), props);
   return exports;

@@ -228,4 +228,94 @@ __global__ void row_ptr_kernel(const uint64_t *keys, int64_t n, int64_t rows, in
   rowPtr[r] = lo;
 }
 
+// ---- N3: top-N recommend (YcnrController.recommendItemsForUser, lib/YcnrController.js:227-284) ----
+// predict = u . I[item] + globalAvgShift for every item that is not in the user's skip list;
+// items below minRecommendRating score -inf.  One 256-thread workgroup per user, a 16-lane group
+// per item row (float4 / double2 loads, fixed summation tree), 16 items per pass.
+template <typename T>
+__global__ __launch_bounds__(256) void recommend_scores_kernel(const T *userRows, const T *items, int64_t totalItems, int k,
+                                                              const int64_t *skipPtr, const int32_t *skipIds, double shift,
+                                                              double minRating, double *scores) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smemRec[];
+  T *u = reinterpret_cast<T *>(smemRec);
+  const int64_t user = blockIdx.x;
+  for (int f = threadIdx.x; f < k; f += 256) u[f] = userRows[user * k + f];
+  __syncthreads();
+  const int sub = threadIdx.x & 15, slot = threadIdx.x >> 4;
+  const int32_t *skip = skipIds + skipPtr[user];
+  const int64_t nSkip = skipPtr[user + 1] - skipPtr[user];
+  double *out = scores + user * totalItems;
+  for (int64_t it0 = 0; it0 < totalItems; it0 += 16) {
+    const int64_t it = it0 + slot;
+    double s = 0.0;
+    if (it < totalItems) {
+      const T *row = items + it * k;
+      T acc = T(0);
+      for (int f = sub; f < k; f += 16) acc = fma(u[f], row[f], acc);  // uF.dot(iF) in the factors' precision
+      s = (double)acc;
+    }
+    for (int m = 8; m >= 1; m >>= 1) s += __shfl_xor(s, m, 16);
+    if (it < totalItems && sub == 0) {
+      int64_t lo = 0, hi = nSkip;  // is `it` in the ascending skip list?
+      while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (skip[mid] < it) lo = mid + 1;
+        else hi = mid;
+      }
+      const bool skipped = lo < nSkip && skip[lo] == it;
+      const double predict = s + shift;
+      out[it] = (!skipped && predict >= minRating) ? predict : -INFINITY;
+    }
+  }
+}
+
+// picks the `take` best scores of a user, best first, ties by the lower item id; -1 pads
+__global__ __launch_bounds__(256) void recommend_select_kernel(double *scores, int64_t totalItems, int take, int stride, int32_t *outIds,
+                                                              double *outPredict, int32_t *outCount) {
+  __shared__ double bestV[256];
+  __shared__ int64_t bestI[256];
+  const int64_t user = blockIdx.x;
+  double *sc = scores + user * totalItems;
+  int found = 0;
+  for (int round = 0; round < stride; ++round) {
+    double v = -INFINITY;
+    int64_t idx = -1;
+    if (round < take) {
+      for (int64_t it = threadIdx.x; it < totalItems; it += 256) {
+        const double x = sc[it];
+        if (x > v) {  // strict: the lowest id among equal scores of this thread stays
+          v = x;
+          idx = it;
+        }
+      }
+    }
+    bestV[threadIdx.x] = v;
+    bestI[threadIdx.x] = idx;
+    __syncthreads();
+    for (int m = 128; m >= 1; m >>= 1) {
+      if ((int)threadIdx.x < m) {
+        const double ov = bestV[threadIdx.x + m];
+        const int64_t oi = bestI[threadIdx.x + m];
+        const bool better = oi >= 0 && (bestI[threadIdx.x] < 0 || ov > bestV[threadIdx.x] || (ov == bestV[threadIdx.x] && oi < bestI[threadIdx.x]));
+        if (better) {
+          bestV[threadIdx.x] = ov;
+          bestI[threadIdx.x] = oi;
+        }
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      const bool got = bestI[0] >= 0 && bestV[0] > -INFINITY;
+      outIds[user * stride + round] = got ? (int32_t)bestI[0] : -1;
+      outPredict[user * stride + round] = got ? bestV[0] : 0.0;
+      if (got) {
+        sc[bestI[0]] = -INFINITY;
+        ++found;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) outCount[user] = found;
+}
+
 }  // namespace ycnr

@@ -742,6 +742,78 @@ int ycnr_csr_transpose(int dtype, int64_t rows, int64_t cols, const int64_t *row
   return rc;
 }
 
+// ---- N3: top-N recommend ----
+int ycnr_recommend_items(int dtype, int32_t k, int64_t nUsers, const void *userRows, int64_t totalItems, const void *itemFactors,
+                         const int64_t *skipPtr, const int32_t *skipIds, double globalAvgShift, double minRecommendRating,
+                         int32_t limit, int32_t *outIds, double *outPredict, int32_t *outCount, double *deviceMs) {
+  if (dtype != YCNR_F32 && dtype != YCNR_F64) return fail(YCNR_ERR_INVALID, "bad dtype %d", dtype);
+  if (k < 1 || k > 4096 || nUsers < 0 || totalItems < 0 || limit < 1 || limit > 4096)
+    return fail(YCNR_ERR_INVALID, "ycnr_recommend_items: bad k / sizes / limit");
+  if (totalItems >= ((int64_t)1 << 31)) return fail(YCNR_ERR_UNSUPPORTED, "ycnr_recommend_items: more than 2^31 items");
+  if (nUsers == 0) return YCNR_OK;
+  if (!userRows || !skipPtr || !outIds || !outPredict || !outCount || (totalItems > 0 && !itemFactors))
+    return fail(YCNR_ERR_INVALID, "ycnr_recommend_items: null argument");
+  if (skipPtr[0] != 0) return fail(YCNR_ERR_INVALID, "ycnr_recommend_items: skipPtr[0] != 0");
+  for (int64_t u = 0; u < nUsers; ++u) {
+    if (skipPtr[u + 1] < skipPtr[u]) return fail(YCNR_ERR_INVALID, "ycnr_recommend_items: skipPtr decreases at user %lld", (long long)u);
+    for (int64_t q = skipPtr[u]; q < skipPtr[u + 1]; ++q)
+      if (q > skipPtr[u] && skipIds[q] <= skipIds[q - 1])
+        return fail(YCNR_ERR_INVALID, "ycnr_recommend_items: skip ids of user %lld are not strictly ascending", (long long)u);
+  }
+  const int64_t nSkip = skipPtr[nUsers];
+  if (nSkip > 0 && !skipIds) return fail(YCNR_ERR_INVALID, "ycnr_recommend_items: null skipIds");
+  const size_t ts = tsize(dtype);
+  const int take = limit - 1;  // lib/YcnrController.js:268-269
+  // users in batches whose score matrix stays below 1 GB
+  const int64_t batch = std::max<int64_t>(1, std::min<int64_t>(nUsers, ((int64_t)1 << 27) / std::max<int64_t>(1, totalItems)));
+  DevBuf dItems, dUsers, dSkipPtr, dSkip, dScores, dIds, dPred, dCnt;
+  HIP_TRY(hipMalloc(&dItems.p, std::max<size_t>((size_t)totalItems * k * ts, 8)));
+  HIP_TRY(hipMalloc(&dUsers.p, (size_t)batch * k * ts));
+  HIP_TRY(hipMalloc(&dSkipPtr.p, (size_t)(batch + 1) * 8));
+  HIP_TRY(hipMalloc(&dSkip.p, std::max<size_t>((size_t)nSkip * 4, 8)));
+  HIP_TRY(hipMalloc(&dScores.p, std::max<size_t>((size_t)batch * totalItems * 8, 8)));
+  HIP_TRY(hipMalloc(&dIds.p, (size_t)batch * limit * 4));
+  HIP_TRY(hipMalloc(&dPred.p, (size_t)batch * limit * 8));
+  HIP_TRY(hipMalloc(&dCnt.p, (size_t)batch * 4));
+  if (totalItems) HIP_TRY(hipMemcpy(dItems.p, itemFactors, (size_t)totalItems * k * ts, hipMemcpyHostToDevice));
+  if (nSkip) HIP_TRY(hipMemcpy(dSkip.p, skipIds, (size_t)nSkip * 4, hipMemcpyHostToDevice));
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  double total = 0.0;
+  int rc = YCNR_OK;
+  std::vector<int64_t> localPtr;
+  for (int64_t u0 = 0; u0 < nUsers && !rc; u0 += batch) {
+    const int64_t nb = std::min(batch, nUsers - u0);
+    localPtr.assign(skipPtr + u0, skipPtr + u0 + nb + 1);  // absolute offsets into dSkip
+    HIP_TRY(hipMemcpy(dUsers.p, (const char *)userRows + (size_t)u0 * k * ts, (size_t)nb * k * ts, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dSkipPtr.p, localPtr.data(), (size_t)(nb + 1) * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipEventRecord(e0, nullptr));
+    if (dtype == YCNR_F32)
+      hipLaunchKernelGGL(recommend_scores_kernel<float>, dim3((unsigned)nb), dim3(256), (size_t)k * ts, nullptr, (const float *)dUsers.p,
+                         (const float *)dItems.p, totalItems, (int)k, (const int64_t *)dSkipPtr.p, (const int32_t *)dSkip.p, globalAvgShift,
+                         minRecommendRating, (double *)dScores.p);
+    else
+      hipLaunchKernelGGL(recommend_scores_kernel<double>, dim3((unsigned)nb), dim3(256), (size_t)k * ts, nullptr, (const double *)dUsers.p,
+                         (const double *)dItems.p, totalItems, (int)k, (const int64_t *)dSkipPtr.p, (const int32_t *)dSkip.p, globalAvgShift,
+                         minRecommendRating, (double *)dScores.p);
+    hipLaunchKernelGGL(recommend_select_kernel, dim3((unsigned)nb), dim3(256), 0, nullptr, (double *)dScores.p, totalItems, take, (int)limit,
+                       (int32_t *)dIds.p, (double *)dPred.p, (int32_t *)dCnt.p);
+    hipError_t le = hipGetLastError();
+    double ms = 0.0;
+    rc = le == hipSuccess ? timed(e0, e1, &ms) : fail(YCNR_ERR_HIP, "recommend launch: %s", hipGetErrorString(le));
+    total += ms;
+    if (rc) break;
+    HIP_TRY(hipMemcpy(outIds + u0 * limit, dIds.p, (size_t)nb * limit * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(outPredict + u0 * limit, dPred.p, (size_t)nb * limit * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(outCount + u0, dCnt.p, (size_t)nb * 4, hipMemcpyDeviceToHost));
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (deviceMs) *deviceMs = total;
+  return rc;
+}
+
 int ycnr_als_create(const ycnr_als_options *o, ycnr_als **out) {
   if (!o || !out) return fail(YCNR_ERR_INVALID, "ycnr_als_create: null argument");
   if (o->struct_size != (int32_t)sizeof(ycnr_als_options))

@@ -98,5 +98,25 @@
     return { rowPtr: outPtr, indx: outIndx, vals: out };
   };
 
+  /**
+   * The item loop of YcnrController.recommendItemsForUser (lib/YcnrController.js:255-274) for one
+   * user on the GPU. userFactors: the user's k factors; skipItemIds: 1-based ids to leave out
+   * (rated + unrated_items, :244-250). Returns recItems: [{predict, id}] (id 1-based), best
+   * first -- like the reference at most limit - 1 of them.
+   */
+  als.recommendItemsForUser = function (userFactors, itemFactors, factorsCount, skipItemIds, globalAvgShift, minRecommendRating, limit) {
+    typeCheck(itemFactors);
+    if (userFactors.constructor !== itemFactors.constructor) throw new Error('invalid type!');
+    limit = limit || 20;
+    var skip = Int32Array.from(skipItemIds || [], function (id1) { return id1 - 1; }).sort();
+    var uniq = skip.filter(function (v, i) { return i === 0 || v !== skip[i - 1]; });
+    var ids = new Int32Array(limit), pred = new Float64Array(limit), cnt = new Int32Array(1);
+    native.recommendItems(userFactors, itemFactors, factorsCount, Float64Array.of(0, uniq.length), uniq, globalAvgShift || 0,
+      minRecommendRating, limit, ids, pred, cnt);
+    var recItems = [];
+    for (var i = 0; i < cnt[0]; i++) recItems.push({ predict: pred[i], id: ids[i] + 1 });
+    return recItems;
+  };
+
   module.exports = als;
 }());

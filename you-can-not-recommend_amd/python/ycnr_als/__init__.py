@@ -6,6 +6,6 @@ and the parity tests.  The NodeJS host lives in ../../lib/emf and ../../addon.
 """
 from . import _lib
 from ._lib import YcnrError
-from .trainer import AlsDevice, als_calc_portion, rmse_portion, split_to_sets, rating_stats
+from .trainer import AlsDevice, als_calc_portion, rmse_portion, split_to_sets, rating_stats, recommend_items
 
-__all__ = ["AlsDevice", "als_calc_portion", "rmse_portion", "split_to_sets", "rating_stats", "YcnrError", "_lib"]
+__all__ = ["AlsDevice", "als_calc_portion", "rmse_portion", "split_to_sets", "rating_stats", "recommend_items", "YcnrError", "_lib"]

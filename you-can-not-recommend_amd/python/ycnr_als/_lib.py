@@ -28,6 +28,7 @@ EXPORTS = [
     "ycnr_als_bind_factors", "ycnr_als_step", "ycnr_als_step_async", "ycnr_als_sync",
     "ycnr_als_last_step_info", "ycnr_als_rmse",
     "ycnr_split_to_sets", "ycnr_rating_stats", "ycnr_csr_from_triplets", "ycnr_csr_transpose",
+    "ycnr_recommend_items",
 ]
 
 
@@ -111,6 +112,8 @@ def load():
     L.ycnr_rating_stats.argtypes = [i32, i64, vp, vp, vp, vp, vp, C.POINTER(dbl)]
     L.ycnr_csr_from_triplets.restype = i32
     L.ycnr_csr_from_triplets.argtypes = [i32, i64, vp, vp, vp, i64, i64, vp, vp, vp, C.POINTER(dbl)]
+    L.ycnr_recommend_items.restype = i32
+    L.ycnr_recommend_items.argtypes = [i32, i32, i64, vp, i64, vp, vp, vp, dbl, dbl, i32, vp, vp, vp, C.POINTER(dbl)]
     L.ycnr_csr_transpose.restype = i32
     L.ycnr_csr_transpose.argtypes = [i32, i64, i64, vp, vp, vp, vp, vp, vp, C.POINTER(dbl)]
     _lib = L

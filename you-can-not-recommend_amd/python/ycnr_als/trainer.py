@@ -106,6 +106,30 @@ def rating_stats(rowPtr, vals, types=None):
     return cnt, sm, ms.value
 
 
+def recommend_items(userRows, itemFactors, skipPtr, skipIds, globalAvgShift=0.0, minRecommendRating=7.0, limit=20):
+    """YcnrController.recommendItemsForUser (lib/YcnrController.js:227-284) for a batch of users on
+    the GPU.  userRows: [nUsers x k]; skipPtr / skipIds: CSR of 0-based item ids to leave out
+    (rated + unrated_items), ascending per user.  Returns (ids [nUsers x limit] with -1 padding,
+    predicts, counts, kernel ms); like the reference, at most limit - 1 items per user."""
+    L = _lib.load()
+    it = np.ascontiguousarray(itemFactors)
+    if it.dtype not in (np.float32, np.float64):
+        raise TypeError("invalid type!")
+    ur = np.ascontiguousarray(userRows, it.dtype).reshape(-1, it.shape[1])
+    sp = np.ascontiguousarray(skipPtr, np.int64)
+    sk = np.ascontiguousarray(skipIds, np.int32)
+    n = ur.shape[0]
+    ids = np.full((n, limit), -1, np.int32)
+    pred = np.zeros((n, limit), np.float64)
+    cnt = np.zeros(n, np.int32)
+    ms = C.c_double(0.0)
+    _lib.check(L.ycnr_recommend_items(_lib.F64 if it.dtype == np.float64 else _lib.F32, it.shape[1], n, ur.ctypes.data, it.shape[0],
+                                      it.ctypes.data, sp.ctypes.data, sk.ctypes.data if len(sk) else None, float(globalAvgShift),
+                                      float(minRecommendRating), int(limit), ids.ctypes.data, pred.ctypes.data, cnt.ctypes.data,
+                                      C.byref(ms)))
+    return ids, pred, cnt, ms.value
+
+
 class AlsDevice:
     """Level 2: resident trainer handle (one per GPU / process)."""
 
