@@ -14,7 +14,11 @@ const t = { user: Int32Array.from(input.user), item: Int32Array.from(input.item)
 const ds = new Dataset(input.users, input.items, t, Int8Array.from(input.type), F);
 const lord = Emf.createLord();
 lord.init({}, { factorsCount: input.k, trainIters: input.iters, dataDir: input.dir, dbType: 'ml', useDoublePrecision: input.useDoublePrecision,
-  ratingsInPortionForRmse: input.rip, numThreadsForTrain: { als: input.threads } });
+  ratingsInPortionForRmse: input.rip, numThreadsForTrain: { als: input.threads },
+  saveCalcResultsEveryIter: true });  // N4: a checkpoint after every iteration must not change the result
+let checkpoints = 0;
+const save = lord.saveCalcResults.bind(lord);
+lord.saveCalcResults = (ci) => { checkpoints++; return save(ci); };
 lord.train(ds).then((history) => {
   // level-1 portion op on the first 5 users, against the final item factors
   const k = input.k, bu = ds.trainByUser;
@@ -23,7 +27,7 @@ lord.train(ds).then((history) => {
   const e = bu.rowPtr[cnt];
   const solved = new F(cnt * k);
   const ratings = als.alsCalcPortion(0.05, k, Int32Array.from(rows), bu.indx.slice(0, e), bu.vals.slice(0, e), lord.itemFactors, solved);
-  console.log(JSON.stringify({ history, calcInfo: lord.getCalcInfo(), stepInfo: lord.lastStepInfo, portionRatings: ratings,
+  console.log(JSON.stringify({ checkpoints, history, calcInfo: lord.getCalcInfo(), stepInfo: lord.lastStepInfo, portionRatings: ratings,
     portionSolved: Array.from(solved) }));
   lord.destroy();
 }).catch((e) => { console.error(e); process.exit(1); });

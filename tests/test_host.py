@@ -96,6 +96,69 @@ def test_train_loop_and_result_files(tmp_path):
     assert other.loadCalcResults() is None
 
 
+def test_warm_start_extends_factors_for_new_users_and_items(tmp_path):
+    """N4: prepareSharedFactors over _loadSharedFactorsForTrain (EmfMaster.js:347-358,
+    EmfManager.js:405-457): a compatible previous result is kept, rows are drawn only for users and
+    items added since (initSharedFactorsRandom(oldUsersCnt, oldItemsCnt), EmfBase.js:457-513);
+    incompatible or larger previous results are discarded."""
+    ds, U, V = small_dataset()
+    opts = {"factorsCount": 8, "trainIters": 1, "dataDir": str(tmp_path), "dbType": "ml", "ratingsInPortionForRmse": 40}
+    first = EmfLord(options=opts, backend_factory=oracle_factory)
+    first.prepareToTrain(ds, U, V)
+    first.train()
+    U1, V1 = first.backend.get_factors(0).copy(), first.backend.get_factors(1).copy()
+    # same sizes: plain warm start
+    again = EmfLord(options=dict(opts, warmStart=True), backend_factory=oracle_factory)
+    again.prepareToTrain(ds)
+    assert (again.recreated, again.extended) == (False, False) and again.calcCnt == 1
+    assert np.array_equal(again.backend.get_factors(0), U1) and np.array_equal(again.backend.get_factors(1), V1)
+    # 7 more users and 4 more items
+    import copy
+    big = copy.copy(ds)
+    big.totalUsersCount, big.totalItemsCount = ds.totalUsersCount + 7, ds.totalItemsCount + 4
+
+    def grow(a, rows, cols):
+        from ycnr_als.data import Csr
+        rp = np.concatenate([_np(a.rowPtr), np.full(rows - a.rows, _np(a.rowPtr)[-1])])
+        return Csr(rows, cols, rp, a.indx, a.vals)
+    _np = lambda x: x if isinstance(x, np.ndarray) else x.cpu().numpy()
+    big.train_by_user = grow(ds.train_by_user, big.totalUsersCount, big.totalItemsCount)
+    big.train_by_item = grow(ds.train_by_item, big.totalItemsCount, big.totalUsersCount)
+    big.validate = grow(ds.validate, big.totalUsersCount, big.totalItemsCount)
+    big.test = grow(ds.test, big.totalUsersCount, big.totalItemsCount)
+    ext = EmfLord(options=dict(opts, warmStart=True), backend_factory=oracle_factory)
+    ext.prepareToTrain(big, seed=5)
+    assert (ext.recreated, ext.extended) == (False, True)
+    Ue, Ve = ext.backend.get_factors(0), ext.backend.get_factors(1)
+    assert Ue.shape == (57, 8) and Ve.shape == (39, 8)
+    assert np.array_equal(Ue[:50], U1) and np.array_equal(Ve[:35], V1)          # old rows kept
+    assert np.array_equal(Ue[50:], init_factors(57, 8, 10)[50:]) and np.abs(Ue[50:]).max() > 0   # new rows N(0, 1/k), seeded
+    ext.train()
+    assert json.loads((tmp_path / "ml_factors_ready" / "calc_info.json").read_text())["calcCnt"] == 2
+    # a previous result with MORE users than now cannot be reused: everything is drawn again
+    shrunk = EmfLord(options=dict(opts, warmStart=True), backend_factory=oracle_factory)
+    shrunk.prepareToTrain(ds, seed=5)
+    assert (shrunk.recreated, shrunk.extended) == (True, False)
+    assert np.array_equal(shrunk.backend.get_factors(0), init_factors(50, 8, 10))
+
+
+def test_checkpoint_after_every_iteration(tmp_path):
+    """N4: the reference's open todo 'saveCalcResults every iter' (lib/YcnrController.js:288)."""
+    ds, U, V = small_dataset()
+    seen = []
+
+    class Spy(EmfLord):
+        def saveCalcResults(self, calcInfo):
+            super().saveCalcResults(calcInfo)
+            seen.append((self.trainIter, calcInfo["calcCnt"], np.fromfile(os.path.join(self.factorsReadyPath, "user_factors"), np.float32)))
+    lord = Spy(options={"factorsCount": 8, "trainIters": 3, "dataDir": str(tmp_path), "dbType": "ml", "ratingsInPortionForRmse": 40,
+                        "saveCalcResultsEveryIter": True}, backend_factory=oracle_factory)
+    lord.prepareToTrain(ds, U, V)
+    lord.train()
+    assert [(i, c) for i, c, _ in seen] == [(1, 0), (2, 0), (3, 1)]   # two checkpoints, then the final save
+    assert not np.array_equal(seen[0][2], seen[1][2]) and np.array_equal(seen[2][2], lord.backend.get_factors(0).ravel())
+
+
 def test_rmse_reduce_and_shift_quirk(oracle):
     """rmse = sqrt(sum / cnt) over all portions, but predAvg (hence globalAvgShift) uses the LAST
     portion's sums only (EmfMaster.js:778-782)."""

@@ -105,6 +105,7 @@ def test_js_train_matches_python_host(tmp_path, double):
     cp = json.loads((pydir / "ml_factors_ready" / "calc_info.json").read_text())
     assert list(cj) == list(cp)
     assert cj["calcCnt"] == 2 and cp["calcCnt"] == 1  # the JS run warm-started from a saved calc
+    assert out["checkpoints"] == len(out["history"])    # one save per iteration: n - 1 checkpoints + the final one
     assert out["portionRatings"] > 0
 
 

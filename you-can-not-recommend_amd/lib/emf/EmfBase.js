@@ -48,6 +48,7 @@ class EmfBase extends EventEmitter {
       },
       factorsCount: 100,
       trainIters: 10,
+      saveCalcResultsEveryIter: false, // checkpoint after every iteration (reference todo, lib/YcnrController.js:288)
       alg: 'als',
       dataSetDistr: [85, 10, 5],
       ratingsInPortionForRmse: 10 * 1000,

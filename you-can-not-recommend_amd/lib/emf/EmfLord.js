@@ -152,6 +152,10 @@ class EmfLord extends EmfMaster {
             rec.globalAvgShift = this.globalAvgShift;
             this.history.push(rec);
             this.trainIter++;
+            // the reference's open todo "saveCalcResults every iter!" (lib/YcnrController.js:288): a
+            // checkpoint the next train() warm-starts from (_loadSharedFactorsForTrain)
+            if (this.options.saveCalcResultsEveryIter && this.trainIter < this.options.trainIters)
+              return Promise.resolve(this.saveCalcResults(this.getCalcInfo())).then(loop);
             return loop();
           });
       };

@@ -27,6 +27,8 @@ def default_options():
         "dbType": "ml",
         "maxRating": {"mal": 10, "ml": 5},
         "als": {"userFactReg": 0.05, "itemFactReg": 0.05, "initFirstFactorAsAvgRating": False},
+        "warmStart": False,                 # prepareToTrain reuses / extends <dbType>_factors_ready (EmfManager.js:405-457)
+        "saveCalcResultsEveryIter": False,  # checkpoint after every iteration (reference todo, YcnrController.js:288)
         "factorsCount": 100,
         "trainIters": 10,
         "alg": "als",
@@ -324,6 +326,25 @@ class EmfLord:
         from .data import init_factors
         dt = np.float64 if self.options["useDoublePrecision"] else np.float32
         k = self.factorsCount
+        # prepareSharedFactors (EmfMaster.js:347-358) over _loadSharedFactorsForTrain
+        # (EmfManager.js:405-457): explicit matrices win; else reuse the ready files when they
+        # are compatible, keeping the old rows and drawing random rows only for users / items
+        # added since (initSharedFactorsRandom(oldUsersCnt, oldItemsCnt), EmfBase.js:457-513);
+        # else draw everything
+        self.recreated, self.extended = True, False
+        if userFactors is None and itemFactors is None and self.options.get("warmStart", False):
+            prev = self.loadCalcResults()
+            if prev is not None and prev[1].shape[0] <= self.totalUsersCount and prev[2].shape[0] <= self.totalItemsCount \
+                    and prev[1].shape[0] == prev[0]["totalUsersCount"] and prev[2].shape[0] == prev[0]["totalItemsCount"]:
+                ci_prev, U0, V0 = prev
+                userFactors = init_factors(self.totalUsersCount, k, seed * 2 + 0, dt)
+                itemFactors = init_factors(self.totalItemsCount, k, seed * 2 + 1, dt)
+                userFactors[:U0.shape[0]] = U0
+                itemFactors[:V0.shape[0]] = V0
+                self.calcCnt = int(ci_prev.get("calcCnt") or 0)
+                self.globalAvgShift = ci_prev.get("globalAvgShift") or 0
+                self.recreated = False
+                self.extended = U0.shape[0] != self.totalUsersCount or V0.shape[0] != self.totalItemsCount
         if userFactors is None:
             userFactors = init_factors(self.totalUsersCount, k, seed * 2 + 0, dt)
         if itemFactors is None:
@@ -358,6 +379,10 @@ class EmfLord:
             rec["globalAvgShift"] = self.globalAvgShift
             self.history.append(rec)
             self.trainIter += 1
+            # the reference's open todo "saveCalcResults every iter!" (lib/YcnrController.js:288): a
+            # checkpoint a later prepareToTrain(warmStart) can resume from; calcCnt counts finished trains
+            if self.options.get("saveCalcResultsEveryIter", False) and self.rank == 0 and self.trainIter < self.options["trainIters"]:
+                self.saveCalcResults(self.getCalcInfo())
         self.calcCnt += 1
         if self.rank == 0:
             self.saveCalcResults(self.getCalcInfo())
