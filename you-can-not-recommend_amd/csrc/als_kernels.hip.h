@@ -754,6 +754,10 @@ struct SolveMfmaF32 {
   // Solves (A + lam I) x = b.  In: upper tiles of A in acc, per-lane-group partials of b in
   // bacc.  Out: xcol[cb] = x[16 cb + c] in every lane group; returns true when a real pivot
   // was not positive.  acc is destroyed.
+  // BATCH: read all multipliers of a pivot before its updates (fewer s_nop between v_readlane and
+  // the v_fma that uses its SGPR).  Faster in the row kernels (8.3 -> 8.1 ms), slower in the
+  // dual-form kernels (7.2 -> 7.4 ms), so the caller chooses.
+  template <bool BATCH = false>
   static __device__ __forceinline__ bool solve(acc_t (&acc)[NT], const float (&bacc)[NB], float *S, int k, float lam,
                                                float (&xcol)[NB], int lane) {
     const int g = lane >> 4, c = lane & 15;
@@ -813,10 +817,18 @@ struct SolveMfmaF32 {
         // median / p99 / max with and without it (devtest/errstats.py), 0.37 ms per MAL iteration.
         const float rs = __builtin_amdgcn_rsqf(d);
         R[p] *= rs;                             // L[i][p] in lanes 0-15, Linv[p][c] in lanes 16-31
+        if constexpr (BATCH) {
+          float mult[16];
 #pragma unroll
-        for (int j = p + 1; j < 16; ++j) {
-          const float s = readlane(R[p], j);  // L[j][p]
-          R[j] = fmaf(-R[p], s, R[j]);
+          for (int j = p + 1; j < 16; ++j) mult[j] = readlane(R[p], j);  // L[j][p]
+#pragma unroll
+          for (int j = p + 1; j < 16; ++j) R[j] = fmaf(-R[p], mult[j], R[j]);
+        } else {
+#pragma unroll
+          for (int j = p + 1; j < 16; ++j) {
+            const float s = readlane(R[p], j);  // L[j][p]
+            R[j] = fmaf(-R[p], s, R[j]);
+          }
         }
       }
       // ---- 2. W = L^-1 (column c in lanes 16-31) -> LDS -> C/D layout and A-operand layout
@@ -896,7 +908,7 @@ struct SolveMfmaF32 {
                                              float *__restrict__ out_row, int row, ErrInfo *err, int lane) {
     const int g = lane >> 4, c = lane & 15;
     float xcol[NB];
-    const bool bad = solve(acc, bacc, S, k, lam, xcol, lane);
+    const bool bad = solve<true>(acc, bacc, S, k, lam, xcol, lane);
     // lane group g stores blocks g and g + 4: two full 256-byte stores per row for k >= 64
 #pragma unroll
     for (int cb = 0; cb < NB; ++cb) {
