@@ -1703,12 +1703,22 @@ __global__ __launch_bounds__(64) void als_dual_solve_kernel(StepArgs<float> a) {
         y[ba][1] = *reinterpret_cast<const float4 *>(f + 4 < k ? rowp[ba] + f + 4 : a.zeros);
       }
     };
-    load8(za, 0);
+    // NBN <= 6: the next K-step's rows are loaded while this one is split and multiplied.  Larger
+    // classes (k > 128 only) have no registers for that: each block is loaded just before its split.
+    constexpr bool AHEAD = NBN <= 6;
+    if constexpr (AHEAD) load8(za, 0);
     for (int s = 0; s < ksteps32; ++s) {
-      if (s + 1 < ksteps32) load8(zb, s + 1);
+      if constexpr (AHEAD) {
+        if (s + 1 < ksteps32) load8(zb, s + 1);
+      }
       u32x4 p1[NBN], p2[NBN], p3[NBN];
 #pragma unroll
       for (int ba = 0; ba < NBN; ++ba) {
+        if constexpr (!AHEAD) {
+          const int f = 32 * s + 8 * g;
+          za[ba][0] = *reinterpret_cast<const float4 *>(f < k ? rowp[ba] + f : a.zeros);
+          za[ba][1] = *reinterpret_cast<const float4 *>(f + 4 < k ? rowp[ba] + f + 4 : a.zeros);
+        }
         const float x[8] = {za[ba][0].x, za[ba][0].y, za[ba][0].z, za[ba][0].w, za[ba][1].x, za[ba][1].y, za[ba][1].z, za[ba][1].w};
         unsigned h[4], m[4], l[4];
 #pragma unroll
@@ -1742,10 +1752,12 @@ __global__ __launch_bounds__(64) void als_dual_solve_kernel(StepArgs<float> a) {
           }
         }
       }
+      if constexpr (AHEAD) {
 #pragma unroll
-      for (int ba = 0; ba < NBN; ++ba) {
-        za[ba][0] = zb[ba][0];
-        za[ba][1] = zb[ba][1];
+        for (int ba = 0; ba < NBN; ++ba) {
+          za[ba][0] = zb[ba][0];
+          za[ba][1] = zb[ba][1];
+        }
       }
     }
   } else {

@@ -52,7 +52,8 @@ constexpr int kDefaultChunk = 1024;  // ratings per split unit (and the largest 
 constexpr int kMaxSlabsPerRow = 64;  // heavier rows get proportionally longer chunks
 constexpr int64_t kBandBytes = (int64_t)96 << 20;  // slice of the fixed matrix one band of chunks gathers from (cache-sized)
 constexpr size_t kZeroRowBytes = 2048;  // >= kMaxFactors doubles
-constexpr int kMaxDualBlocks = 6;        // dual-form kernels exist for 1..6 blocks of 16 ratings
+constexpr int kMaxDualBlocks = 10;       // dual-form kernels exist for 1..10 blocks of 16 ratings
+constexpr int kMaxDualBlocksSmallK = 6;  // k <= 128: beyond 96 ratings the row kernel (k x k) is as cheap
 
 size_t tsize(int dtype) { return dtype == YCNR_F64 ? 8 : 4; }
 
@@ -181,7 +182,11 @@ template <typename T>
 int launch_duals(const StepArgs<T> &, const DualPlan &, hipStream_t) { return YCNR_OK; }
 template <>
 int launch_duals<float>(const StepArgs<float> &args, const DualPlan &dp, hipStream_t stream) {
-  int rc = launch_dual<6>(args, dp, stream);
+  int rc = launch_dual<10>(args, dp, stream);
+  if (!rc) rc = launch_dual<9>(args, dp, stream);
+  if (!rc) rc = launch_dual<8>(args, dp, stream);
+  if (!rc) rc = launch_dual<7>(args, dp, stream);
+  if (!rc) rc = launch_dual<6>(args, dp, stream);
   if (!rc) rc = launch_dual<5>(args, dp, stream);
   if (!rc) rc = launch_dual<4>(args, dp, stream);
   if (!rc) rc = launch_dual<3>(args, dp, stream);
@@ -381,7 +386,9 @@ int64_t slab_regs(const ycnr_als_options &o, int side) {
 int dual_max_ratings(const ycnr_als_options &o) {
   if (o.dtype != YCNR_F32 || (o.flags & (YCNR_FLAG_LDS_SOLVER | YCNR_FLAG_NO_DUAL)) || o.factorsCount % 4 != 0) return 0;
   const int nb = slab_nb(o.factorsCount);
-  return 16 * std::min(kMaxDualBlocks, nb - 1);
+  // k > 128: every row that is not dual goes through slabs and the 4-wave LDS solve, whose cost
+  // grows with k^3; an n x n problem with n <= 160 still fits one wave's registers
+  return 16 * std::min(o.factorsCount > kMaxFactors ? kMaxDualBlocks : kMaxDualBlocksSmallK, nb - 1);
 }
 
 // copy `bytes` from src (host or device) to a device destination
