@@ -808,9 +808,9 @@ struct SolveMfmaF32 {
         // multipliers are 0, so skipping them is exact (a wave-uniform branch)
         if (J * 16 + p >= k) break;
         const float d = readlane(R[p], p);  // D[p][p] after the updates of pivots < p (lane p, group 0)
-        // a pivot that is not positive (or NaN) poisons dmin; the row is reported, its values are
-        // whatever the NaNs make of them (as before: garbage that the error count announces)
-        dmin = d > 0.0f ? (d < dmin ? d : dmin) : -1.0f;
+        // the smallest pivot decides whether the row is reported: the first pivot that is not
+        // positive is an ordinary number (NaNs only appear after it), so a plain minimum keeps it
+        dmin = fminf(dmin, d);
         // v_rsq_f32 as it is (1 ulp).  A Newton step on top of it (3 more instructions on the
         // critical path of each of the 16 pivots) changed nothing measurable: lanes 16-31 invert
         // the L that was actually computed, and the row errors against float64 had the same
@@ -901,7 +901,11 @@ struct SolveMfmaF32 {
       }
       xcol[J] = group_sum(s);
     }
-    return !(dmin > 0.0f);
+    // NaN / Inf in the input never shows as a small pivot (fminf drops NaNs) but ends up in x
+    float chk = 0.0f;
+#pragma unroll
+    for (int J = 0; J < NB; ++J) chk = fmaf(xcol[J], 0.0f, chk);
+    return !(dmin > 0.0f) || __any(!(chk == 0.0f));
   }
 
   static __device__ __forceinline__ void run(acc_t (&acc)[NT], const float (&bacc)[NB], float *S, int k, float lam,
