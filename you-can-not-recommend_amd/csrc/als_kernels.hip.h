@@ -805,8 +805,9 @@ struct SolveMfmaF32 {
 #pragma unroll
       for (int p = 0; p < 16; ++p) {
         // padded pivots (index >= k) are rows of the identity: their scale is 1 and their
-        // multipliers are 0, so skipping them is exact (a wave-uniform branch)
-        if (J * 16 + p >= k) break;
+        // multipliers are 0, so skipping them is exact (a wave-uniform branch).  Only the last
+        // tile has any: 16 (NB - 1) < k by the choice of NB (and of the dual class).
+        if (J == NB - 1 && J * 16 + p >= k) break;
         const float d = readlane(R[p], p);  // D[p][p] after the updates of pivots < p (lane p, group 0)
         // the smallest pivot decides whether the row is reported: the first pivot that is not
         // positive is an ordinary number (NaNs only appear after it), so a plain minimum keeps it
