@@ -1,5 +1,7 @@
 // Many short units at once (8 blocks per CU): als_gram_slab_x6d_kernel against the float32-MFMA
-// slab kernel, unit by unit.  x6many <nb:4|7> <k> <n> <units> [ldspad]
+// slab kernel, unit by unit.  x6many <nb:4|7> <k> <n> <units>
+// Built with -DYCNR_X6D_ALLOW_PK (the right-hand side's multiply-adds packed across blocks) the
+// k % 16 == 0 form fails for a few per cent of the units at 8 workgroups per CU.
 #include "../als_kernels.hip.h"
 #include <cstdio>
 #include <cstdlib>
@@ -26,52 +28,10 @@ int run(int k, int n, int units, int items) {
   StepArgs<float> a{du, nullptr, dindx, dvals, dV, dz, nullptr, dA, nullptr, 0.05, k, 0, 0, (uint32_t)(V.size() * 4)};
   hipLaunchKernelGGL((als_gram_slab_kernel<float, NB, false>), dim3(units), dim3(64), 0, 0, a);
   a.slabs = dB;
-#ifdef YCNR_X6D_DEBUG_RR
-  float *dbg; const size_t dbgN = (size_t)units * 64 * 64 * 8;
-  hipMalloc(&dbg, dbgN * 4); hipMemset(dbg, 0, dbgN * 4);
-  hipMemcpyToSymbol(HIP_SYMBOL(g_debug_rr), &dbg, sizeof dbg);
-#endif
   hipLaunchKernelGGL((als_gram_slab_x6d_kernel<NB, PAD>), dim3(units), dim3(64), 0, 0, a);
   hipError_t e = hipDeviceSynchronize();
-#if defined(YCNR_X6D_SENTINEL)
-  { unsigned h[8]; hipMemcpyFromSymbol(h, HIP_SYMBOL(g_probe_late), sizeof h);
-    printf("sentinel: %u block reads had to spin, %u gave up; %u phases\n", h[0], h[1], h[7]); }
-#endif
   std::vector<float> A(se * units), B(se * units);
   hipMemcpy(A.data(), dA, A.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(B.data(), dB, B.size() * 4, hipMemcpyDeviceToHost);
-#ifdef YCNR_X6D_DEBUG_RR
-  {
-    std::vector<float> D(dbgN);
-    hipMemcpy(D.data(), dbg, dbgN * 4, hipMemcpyDeviceToHost);
-    const int steps = (n + 31) / 32; long wrong = 0; int shownD = 0;
-    // slots 0..NB-1 hold the running b partials of the lane after the step (block NB-1 of that step not yet added)
-    for (int u = 0; u < units; ++u) {
-      std::vector<double> part((size_t)64 * NB, 0.0);
-      for (int st = 0; st < steps && st < 64; ++st) {
-        for (int lane = 0; lane < 64; ++lane) for (int cb = 0; cb < NB; ++cb) for (int j = 0; j < 8; ++j) {
-          const int q = st * 32 + 8 * (lane >> 4) + j, col = cb * 16 + (lane & 15);
-          if (q < n && col < k) part[lane * NB + cb] += (double)V[(size_t)indx[(size_t)u * n + q] * k + col] * vals[(size_t)u * n + q];
-        }
-        for (int lane = 0; lane < 64; ++lane) for (int cb = 0; cb < NB; ++cb) {
-          const float got = D[(((size_t)u * 64 + st) * 64 + lane) * 8 + cb];
-          const double want = part[lane * NB + cb];
-          if (std::fabs(got - want) > 1e-3) {
-            ++wrong;
-            if (shownD++ < 24) {
-              // candidates for what was added instead of this step's contribution
-              auto contrib = [&](int sx, int sr) { double c = 0; for (int j = 0; j < 8; ++j) { const int qx = sx * 32 + 8 * (lane >> 4) + j, qr = sr * 32 + 8 * (lane >> 4) + j, col = cb * 16 + (lane & 15);
-                  if (qx >= 0 && qx < n && qr >= 0 && qr < n) c += (double)V[(size_t)indx[(size_t)u * n + qx] * k + col] * vals[(size_t)u * n + qr]; } return c; };
-              printf("  unit %d step %d lane %d (g %d c %d) block %d: added %g instead of %g; x(st)r(st-1) %g  x(st-1)r(st) %g  x(st)r(st+1) %g x(st+1)r(st) %g\n", u, st, lane, lane >> 4, lane & 15, cb,
-                     got - (want - contrib(st, st)), contrib(st, st), contrib(st, st - 1), contrib(st - 1, st), contrib(st, st + 1), contrib(st + 1, st));
-            }
-            part[lane * NB + cb] = got;
-          }
-        }
-      }
-    }
-    printf("rr values wrong: %ld\n", wrong);
-  }
-#endif
   const size_t ntile = (size_t)tile_count(NB) * 4 * 64;
   int badUnits = 0, shown = 0;
   for (int u = 0; u < units; ++u) {
