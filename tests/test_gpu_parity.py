@@ -466,10 +466,12 @@ def test_full_iterations_ml100k_shape(als, oracle):
     assert h1[-1]["rmseValidate"] < h1[0]["rmseValidate"]  # it learns
 
 
-def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path):
-    """The sharded HIP path end to end: two gloo ranks sharing cuda:0 (functional stand-in for
-    two GPUs over RCCL) must reproduce the single-process factors bit for bit -- shard
-    ranges, per-shard CSR upload, the padded all-gather and the RMSE all-reduce included."""
+@pytest.mark.parametrize("world", [2, 8])
+def test_ranks_on_one_gpu_equal_one_rank(tmp_path, world):
+    """The sharded HIP path end to end: 2 / 8 gloo ranks sharing cuda:0 (functional stand-in for
+    that many GPUs over RCCL) must reproduce the single-process factors bit for bit -- shard
+    ranges, per-shard CSR upload, the chunked pipelined exchange, the padded all-gather and
+    the RMSE all-reduce included."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -477,9 +479,9 @@ def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path):
     one = str(tmp_path / "one.npz")
     two = str(tmp_path / "two.npz")
     subprocess.check_call([sys.executable, os.path.join(root, "bench.py")] + common + ["--dump-factors", one], timeout=600)
-    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                           "--master-addr", "127.0.0.1", "--master-port", "29541", os.path.join(root, "bench.py"),
-                           "--gpus", "2", "--backend", "gloo", "--same-device", "--dump-factors", two] + common, timeout=900)
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                           "--master-addr", "127.0.0.1", "--master-port", str(29541 + world), os.path.join(root, "bench.py"),
+                           "--gpus", str(world), "--backend", "gloo", "--same-device", "--dump-factors", two] + common, timeout=900)
     a, b = np.load(one), np.load(two)
     assert np.array_equal(a["U"], b["U"]) and np.array_equal(a["V"], b["V"])
     assert abs(float(a["rmse"]) - float(b["rmse"])) < 1e-12
