@@ -142,6 +142,24 @@ def test_warm_start_extends_factors_for_new_users_and_items(tmp_path):
     assert np.array_equal(shrunk.backend.get_factors(0), init_factors(50, 8, 10))
 
 
+def test_first_factor_as_average_rating():
+    """als.initFirstFactorAsAvgRating (EmfBase.js:74, :493-511): rows drawn at prepareToTrain get
+    their average train rating as first factor; rows without ratings keep the random draw."""
+    ds, _, _ = small_dataset()
+    lord = EmfLord(options={"factorsCount": 8, "als": {"initFirstFactorAsAvgRating": True}}, backend_factory=oracle_factory)
+    lord.prepareToTrain(ds, seed=4)
+    U, V = lord.backend.get_factors(0), lord.backend.get_factors(1)
+    plain_u, plain_v = init_factors(50, 8, 8), init_factors(35, 8, 9)
+    for fac, plain, csr in ((U, plain_u, ds.train_by_user), (V, plain_v, ds.train_by_item)):
+        rp, vals = np.asarray(csr.rowPtr), np.asarray(csr.vals)
+        assert np.array_equal(fac[:, 1:], plain[:, 1:])
+        for r in range(len(rp) - 1):
+            if rp[r + 1] > rp[r]:
+                assert abs(fac[r, 0] - vals[rp[r]:rp[r + 1]].astype(np.float64).mean()) < 1e-6
+            else:
+                assert fac[r, 0] == plain[r, 0]
+
+
 def test_checkpoint_after_every_iteration(tmp_path):
     """N4: the reference's open todo 'saveCalcResults every iter' (lib/YcnrController.js:288)."""
     ds, U, V = small_dataset()

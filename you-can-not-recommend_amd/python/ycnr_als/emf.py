@@ -345,10 +345,25 @@ class EmfLord:
                 self.globalAvgShift = ci_prev.get("globalAvgShift") or 0
                 self.recreated = False
                 self.extended = U0.shape[0] != self.totalUsersCount or V0.shape[0] != self.totalItemsCount
+        drawn = (0 if userFactors is None else None, 0 if itemFactors is None else None)  # first row drawn here, per side
+        if not self.recreated:
+            drawn = (U0.shape[0], V0.shape[0])
         if userFactors is None:
             userFactors = init_factors(self.totalUsersCount, k, seed * 2 + 0, dt)
         if itemFactors is None:
             itemFactors = init_factors(self.totalItemsCount, k, seed * 2 + 1, dt)
+        if self.options["als"].get("initFirstFactorAsAvgRating", False):
+            # EmfBase.js:493-511: the first factor of every row drawn here = the row's average rating
+            # (ratings_count / avg_rating over the train sets), rows without ratings keep the draw
+            for fac, csr, first in ((userFactors, ds.train_by_user, drawn[0]), (itemFactors, ds.train_by_item, drawn[1])):
+                if first is None:
+                    continue
+                rp, vals = _to_np(csr.rowPtr), _to_np(csr.vals).astype(np.float64)
+                cnt = np.diff(rp)
+                sums = np.add.reduceat(np.concatenate([vals, [0.0]]), np.minimum(rp[:-1], len(vals))) * (cnt > 0)
+                rows = np.flatnonzero(cnt > 0)
+                rows = rows[rows >= first]
+                fac[rows, 0] = (sums[rows] / cnt[rows]).astype(dt)
         self.backend.set_factors(0, userFactors)
         self.backend.set_factors(1, itemFactors)
         self._status = "ready"
