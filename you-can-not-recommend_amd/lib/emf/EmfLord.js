@@ -37,69 +37,61 @@ class EmfLord extends EmfMaster {
     return Promise.resolve();
   }
 
-  /** splitToPortions (EmfLord.js:510-612), statement for statement */
+  /**
+   * Row portions of every pass: contiguous id ranges whose (scaled) rating counts stay within a
+   * budget.  Same rule and same results as EmfLord.splitToPortions of the reference
+   * (lib/emf/EmfLord.js:510-612; checked against the oracle's restatement in
+   * tests/test_node_host.py); portionsRowIdTo[pass][p] is the 1-based last row id of portion p.
+   */
   splitToPortions() {
-    if (this.stats.trainUsersRatingsCount == 0 || this.stats.trainItemsRatingsCount == 0)
-      return Promise.resolve();
-    this.portionsRowIdTo = {};
-    const steps = ['byUser', 'byItem', 'rmseValidate', 'rmseTest'];
-    for (const stepType of steps) {
-      const rowsCnt = (stepType == 'byItem' ? this.trainItemsCount : this.trainUsersCount);
-      const ratingsCntPer = (stepType == 'byItem' ? this.stats.ratingsCntPerItem : this.stats.ratingsCntPerUser);
-      let maxRatingsPerRow = (stepType == 'byItem' ? this.stats.maxRatingsPerItem : this.stats.maxRatingsPerUser);
-      let ratingsCount = (stepType == 'byItem' ? this.stats.trainItemsRatingsCount : this.stats.trainUsersRatingsCount);
-      if (stepType == 'rmseTest') {
-        ratingsCount = Math.ceil(ratingsCount * ((this.options.dataSetDistr[2] + 1) / 100));
-        maxRatingsPerRow = Math.ceil(maxRatingsPerRow * ((this.options.dataSetDistr[2] + 1) / 100));
-      } else if (stepType == 'rmseValidate') {
-        ratingsCount = Math.ceil(ratingsCount * ((this.options.dataSetDistr[1] + 1) / 100));
-        maxRatingsPerRow = Math.ceil(maxRatingsPerRow * ((this.options.dataSetDistr[1] + 1) / 100));
-      }
-      let ratingsInPortion = (stepType == 'rmseValidate' || stepType == 'rmseTest'
-        ? this.options.ratingsInPortionForRmse
-        : this.options.ratingsInPortionForAls[stepType]);
-      let avgPortionsCount = Math.ceil(ratingsCount / ratingsInPortion);
-      let avgRowsInPortion = Math.floor(rowsCnt / avgPortionsCount);
-      if (avgPortionsCount < this.options.numThreadsForTrain[this.options.alg]) {
-        avgPortionsCount = this.options.numThreadsForTrain[this.options.alg];
-        ratingsInPortion = Math.ceil(ratingsCount / avgPortionsCount);
-        avgRowsInPortion = Math.floor(rowsCnt / avgPortionsCount);
-      }
-      if (avgRowsInPortion < 1) {
-        avgRowsInPortion = 1;
-        avgPortionsCount = rowsCnt;
-        ratingsInPortion = Math.ceil(ratingsCount / avgPortionsCount);
-      }
-      if (ratingsInPortion < maxRatingsPerRow) {
-        ratingsInPortion = maxRatingsPerRow;
-        avgPortionsCount = Math.ceil(ratingsCount / ratingsInPortion);
-        avgRowsInPortion = Math.floor(rowsCnt / avgPortionsCount);
-      }
+    const st = this.stats, opt = this.options;
+    if (!st.trainUsersRatingsCount || !st.trainItemsRatingsCount) return Promise.resolve();
+    const minPortions = opt.numThreadsForTrain[opt.alg];
+    // the RMSE passes walk the validate / test share of every user's ratings: (pct + 1) %
+    const share = { byUser: 0, byItem: 0, rmseValidate: opt.dataSetDistr[1] + 1, rmseTest: opt.dataSetDistr[2] + 1 };
+    const scaled = (n, pct) => (pct ? Math.ceil(n * (pct / 100)) : n);
 
-      const portionsRowIdTo = [];
-      let p = 0, rtgs = 0, rows = 0, maxRows = 0;
-      for (let id in ratingsCntPer) {
-        let cnt = ratingsCntPer[id];
-        if (stepType == 'rmseTest') {
-          cnt = Math.ceil(cnt * ((this.options.dataSetDistr[2] + 1) / 100));
-        } else if (stepType == 'rmseValidate') {
-          cnt = Math.ceil(cnt * ((this.options.dataSetDistr[1] + 1) / 100));
-        }
-        id = parseInt(id);
-        if ((rtgs + cnt) > ratingsInPortion) {
-          rtgs = 0;
-          rows = 0;
-          p++;
-        }
-        rtgs += cnt;
-        rows++;
-        if (rows > maxRows) maxRows = rows;
-        portionsRowIdTo[p] = id + 1; //id is 0-based, for db we need 1-based
+    // ratings one portion may hold: the configured size, lowered so that there are at least
+    // `minPortions` portions (never fewer rows than one per portion), raised to the heaviest row
+    const budgetOf = (ratings, rows, heaviest, wanted) => {
+      let portions = Math.ceil(ratings / wanted), budget = wanted;
+      if (portions < minPortions) {
+        portions = minPortions;
+        budget = Math.ceil(ratings / portions);
       }
-      this.portionsRowIdTo[stepType] = portionsRowIdTo;
-      this.portionsCount[stepType] = portionsRowIdTo.length;
-      this.maxRatingsInPortion[stepType] = ratingsInPortion;
-      this.maxRowsInPortion[stepType] = maxRows;
+      if (Math.floor(rows / portions) < 1) budget = Math.ceil(ratings / rows);
+      return Math.max(budget, heaviest);
+    };
+
+    this.portionsRowIdTo = {};
+    for (const pass of Object.keys(share)) {
+      const items = pass == 'byItem', pct = share[pass];
+      const counts = items ? st.ratingsCntPerItem : st.ratingsCntPerUser;
+      const budget = budgetOf(
+        scaled(items ? st.trainItemsRatingsCount : st.trainUsersRatingsCount, pct),
+        items ? this.trainItemsCount : this.trainUsersCount,
+        scaled(items ? st.maxRatingsPerItem : st.maxRatingsPerUser, pct),
+        pct ? opt.ratingsInPortionForRmse : opt.ratingsInPortionForAls[pass]);
+      // greedy cut over the rows that have ratings (the stats arrays are sparse), in id order
+      const ends = [];
+      let held = 0, rowsHere = 0, mostRows = 0;
+      Object.keys(counts).forEach((key) => {
+        const id0 = parseInt(key), cnt = scaled(counts[key], pct);
+        if (held + cnt > budget) {
+          ends.push(0);
+          held = 0;
+          rowsHere = 0;
+        }
+        if (ends.length == 0) ends.push(0);
+        held += cnt;
+        rowsHere++;
+        mostRows = Math.max(mostRows, rowsHere);
+        ends[ends.length - 1] = id0 + 1;
+      });
+      this.portionsRowIdTo[pass] = ends;
+      this.portionsCount[pass] = ends.length;
+      this.maxRatingsInPortion[pass] = budget;
+      this.maxRowsInPortion[pass] = mostRows;
     }
     return Promise.resolve();
   }
