@@ -1476,11 +1476,13 @@ struct GramX6D {
 #pragma unroll
             for (int j = 0; j < 8; ++j) bacc[bi] = fmaf(x[j], rr[j], bacc[bi]);
             // Keeps the compiler from pairing the multiply-adds of two blocks into v_pk_fma_f32
-            // (packed float32 beside MFMAs is slower anyway).  With that pairing, and only with many
-            // workgroups per CU, the copies it took of x right after the wait above held OLD values
-            // in lanes 48..63 of block 0 (tiles right, b wrong in ~7 % of rows; devtest/x6many.hip
-            // built with -DYCNR_X6D_ALLOW_PK reproduces it).  A sentinel word read behind the eight
-            // values never arrived late in 2.5 M reads, so the wait itself holds; the cause is open.
+            // (packed float32 beside MFMAs is slower anyway).  With that pairing, and only with >= 4
+            // workgroups per CU, the FIRST block of each pair (whose values are copied and kept until
+            // its partner arrives) got a wrong b in lanes 48..63 -- tiles right, b wrong in ~7 % of
+            // rows; devtest/x6many.hip built with -DYCNR_X6D_ALLOW_PK reproduces it and counts the
+            // failures per block.  Ruled out: late LDS data (a sentinel read behind the eight values
+            // never arrived late in 2.5 M reads, and ~20 MFMAs lie between read and wait), the two
+            // small DMAs (moving them changes nothing).  The cause is open.
 #ifndef YCNR_X6D_ALLOW_PK
             asm volatile("" : "+v"(bacc[bi]));
 #endif

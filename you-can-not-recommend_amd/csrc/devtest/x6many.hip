@@ -34,6 +34,7 @@ int run(int k, int n, int units, int items) {
   hipMemcpy(A.data(), dA, A.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(B.data(), dB, B.size() * 4, hipMemcpyDeviceToHost);
   const size_t ntile = (size_t)tile_count(NB) * 4 * 64;
   int badUnits = 0, shown = 0;
+  long badBlock[16] = {0};
   for (int u = 0; u < units; ++u) {
     const float *pa = &A[se * u], *pb = &B[se * u];
     double norm = 0, md = 0; int badTiles = 0;
@@ -41,13 +42,17 @@ int run(int k, int n, int units, int items) {
     std::vector<int> tb;
     for (int t = 0; t < tile_count(NB); ++t) { double d = 0; for (int i = 0; i < 256; ++i) d = std::fmax(d, std::fabs((double)pa[t * 256 + i] - pb[t * 256 + i])); if (d > 1e-4 * norm) { ++badTiles; tb.push_back(t); } md = std::fmax(md, d); }
     double bd = 0, bn = 1e-30;
+    for (int cb = 0; cb < NB; ++cb) { double worst = 0, nrm = 1e-30; for (int c = 0; c < 16; ++c) { double sa = 0, sb = 0; for (int g = 0; g < 4; ++g) { sa += pa[ntile + cb * 64 + g * 16 + c]; sb += pb[ntile + cb * 64 + g * 16 + c]; } worst = std::fmax(worst, std::fabs(sa - sb)); nrm = std::fmax(nrm, std::fabs(sa)); }
+      if (worst > 1e-4 * nrm) ++badBlock[cb]; }
     for (int cb = 0; cb < NB; ++cb) for (int c = 0; c < 16; ++c) { double sa = 0, sb = 0; for (int g = 0; g < 4; ++g) { sa += pa[ntile + cb * 64 + g * 16 + c]; sb += pb[ntile + cb * 64 + g * 16 + c]; } bd = std::fmax(bd, std::fabs(sa - sb)); bn = std::fmax(bn, std::fabs(sa)); }
     if (badTiles || bd > 1e-4 * bn) {
       ++badUnits;
       if (shown++ < 6) { printf("unit %d: %d bad tiles (max diff %.3g of %.3g), b diff %.3g of %.3g; tiles:", u, badTiles, md, norm, bd, bn); for (int t : tb) printf(" %d", t); printf("\n"); }
     }
   }
-  printf("%s: NB=%d k=%d n=%d units=%d: %d bad units\n", hipGetErrorString(e), NB, k, n, units, badUnits);
+  printf("%s: NB=%d k=%d n=%d units=%d: %d bad units; units with a wrong b per column block:", hipGetErrorString(e), NB, k, n, units, badUnits);
+  for (int cb = 0; cb < NB; ++cb) printf(" %ld", badBlock[cb]);
+  printf("\n");
   return badUnits;
 }
 int main(int argc, char **argv) {
