@@ -60,7 +60,7 @@ def algorithmic_bytes(nnz, rows_solved, k, s):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="mal", choices=sorted(WORKLOADS))
     ap.add_argument("--double", action="store_true", help="useDoublePrecision")
