@@ -807,7 +807,12 @@ struct SolveMfmaF32 {
         // padded pivots (index >= k) are rows of the identity: their scale is 1 and their
         // multipliers are 0, so skipping them is exact (a wave-uniform branch).  Only the last
         // tile has any: 16 (NB - 1) < k by the choice of NB (and of the dual class).
-        if (J == NB - 1 && J * 16 + p >= k) break;
+        // Not for NB = 1: there hipcc kept the pivot loop rolled because of the break (up to 120
+        // trips of three s_set_gpr_idx moves each), and a guard per pivot made it copy R between
+        // the guarded blocks; 16 straight-line pivots are cheaper than either.
+        if constexpr (NB > 1) {
+          if (J == NB - 1 && J * 16 + p >= k) break;
+        }
         const float d = readlane(R[p], p);  // D[p][p] after the updates of pivots < p (lane p, group 0)
         // the smallest pivot decides whether the row is reported: the first pivot that is not
         // positive is an ordinary number (NaNs only appear after it), so a plain minimum keeps it
@@ -997,7 +1002,9 @@ struct SolveMfmaF64 {
       }
 #pragma unroll
       for (int p = 0; p < 16; ++p) {
-        if (J * 16 + p >= k) break;
+        if constexpr (NB > 1) {  // see SolveMfmaF32: the break keeps the NB = 1 loop rolled
+          if (J * 16 + p >= k) break;
+        }
         double d = readlane(R[p], p);
         if (!(d > 0.0)) {
           bad = true;
