@@ -38,6 +38,11 @@
 
 // How many 4-rating steps ahead the Gramian-only kernel requests its gathered operands.
 // 0 selects the shallow (one step ahead) loop.
+// Dual-form kernels: read all multipliers of a pivot before its updates
+// (SolveMfmaF32::solve<BATCH>); 6.78 -> 6.54 ms over the six classes of a MAL-scale iteration
+#ifndef YCNR_DUAL_BATCH
+#define YCNR_DUAL_BATCH true
+#endif
 #ifndef YCNR_SLAB_PREFETCH
 #define YCNR_SLAB_PREFETCH 3
 #endif
@@ -755,8 +760,9 @@ struct SolveMfmaF32 {
   // bacc.  Out: xcol[cb] = x[16 cb + c] in every lane group; returns true when a real pivot
   // was not positive.  acc is destroyed.
   // BATCH: read all multipliers of a pivot before its updates (fewer s_nop between v_readlane and
-  // the v_fma that uses its SGPR).  Faster in the row kernels (8.3 -> 8.1 ms), slower in the
-  // dual-form kernels (7.2 -> 7.4 ms), so the caller chooses.
+  // the v_fma that uses its SGPR).  Faster in the row kernels (8.3 -> 8.1 ms); in the dual-form
+  // kernels it was slower while their Gramian ran on the float32 pipe (7.2 -> 7.4 ms) and is
+  // faster since it runs on the bf16 pipe (6.78 -> 6.54 ms), so the caller chooses.
   template <bool BATCH = false>
   static __device__ __forceinline__ bool solve(acc_t (&acc)[NT], const float (&bacc)[NB], float *S, int k, float lam,
                                                float (&xcol)[NB], int lane) {
@@ -1785,7 +1791,7 @@ __global__ __launch_bounds__(64) void als_dual_solve_kernel(StepArgs<float> a) {
   }
   const float lam = (float)(a.lambda * (double)n);
   float wcol[NBN];
-  const bool bad = Sv::solve(acc, bacc, reinterpret_cast<float *>(smem), n, lam, wcol, lane);
+  const bool bad = Sv::template solve<YCNR_DUAL_BATCH>(acc, bacc, reinterpret_cast<float *>(smem), n, lam, wcol, lane);
   // x[f] = sum_a Y[a][f] w[a]: per lane the 4 factors 16 s + 4 g + j of its NBN ratings,
   // summed over the 16 lanes of the group; lane c == 0 of each group stores them
   float *out = a.solved + (int64_t)u.row * k;
