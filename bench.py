@@ -277,6 +277,29 @@ def main():
         dist.destroy_process_group()
 
 
+def host_cpus():
+    """CPUs this process can really use: the affinity mask capped by the cgroup CPU quota.  (On
+    the GPU boxes os.cpu_count() is 256 but the quota is 16 CPUs; 256 OpenMP threads under that
+    quota ran the oracle 3x slower than 16.)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = min(n, max(1, int(quota + 0.5)))
+    return max(1, n)
+
+
 def cpu_baseline(lord, by_user, by_item, k, args):
     """Time the CPU oracle (kind 'port': a structure-faithful restatement of
     EmfWorker.mw_calcTrainAlsPortion) on a bounded, contiguous row sample of both half-steps,
@@ -284,7 +307,7 @@ def cpu_baseline(lord, by_user, by_item, k, args):
     extrapolated as 1 / (1/rate_user + 1/rate_item)."""
     from oracle import oracle as orc
     orc.build()
-    cores = os.cpu_count() or 1
+    cores = host_cpus()
     dt = np.float64 if args.double else np.float32
     U = lord.backend.get_factors(0)
     V = lord.backend.get_factors(1)
@@ -319,7 +342,8 @@ def cpu_baseline(lord, by_user, by_item, k, args):
     rate_u, rate_i = nu / tu, ni / ti
     return {"value": 1.0 / (1.0 / rate_u + 1.0 / rate_i), "unit": "ratings/s", "cores": cores, "kind": "port",
             "sample": f"first {ru} user rows ({nu} ratings, {tu:.1f} s) + first {ri} item rows ({ni} ratings, {ti:.1f} s) "
-                      f"of the same workload, OpenMP over rows; extrapolated to a full iteration",
+                      f"of the same workload, OpenMP over rows with {cores} threads (affinity mask capped by the cgroup CPU quota; "
+                      f"os.cpu_count() = {os.cpu_count()}); extrapolated to a full iteration",
             "rate_byUser": rate_u, "rate_byItem": rate_i}
 
 
