@@ -208,7 +208,9 @@ int ycnr_als_last_step_info(ycnr_als *h, ycnr_als_step_info *info);
  *              the local shard), so the caller can reproduce the reference's per-portion
  *              reduce including predAvg = LAST portion's rSum / rCnt (EmfMaster.js:779);
  *              nPortions == 0: one portion covering the shard
- *   out        double[3 * max(nPortions,1)] = {rSumDiff2, rCnt, rSum} per portion */
+ *   out        double[3 * max(nPortions,1)] = {rSumDiff2, rCnt, rSum} per portion
+ * How the set is cut into portions does not decide how much of the GPU works: every portion is
+ * summed in pieces of at most ceil(rows / 4096) rows, one workgroup each, added in row order. */
 int ycnr_als_rmse(ycnr_als *h, int which, double globalAvgShift, int nPortions,
                   const int64_t *portionRowEnd, double *out);
 

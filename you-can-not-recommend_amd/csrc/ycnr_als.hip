@@ -1277,12 +1277,34 @@ int ycnr_als_rmse(ycnr_als *h, int which, double shift, int nPortions, const int
       prev = e;
     }
   }
-  const int np = (int)ends.size();
+  // One workgroup per piece of at most ceil(nRows / 4096) rows, so that a caller's portioning
+  // (one portion = the whole set when nPortions == 0; the reference's default is 10 000 ratings)
+  // does not decide how much of the GPU works; the pieces of a portion are added in row order.
+  const int nPort = (int)ends.size();
+  const int64_t pieceRows = std::max<int64_t>(1, (nRows + 4095) / 4096);
+  std::vector<int64_t> pieceEnds;
+  std::vector<int> pieceOf;
+  {
+    int64_t prev = 0;
+    for (int p = 0; p < nPort; ++p) {
+      if (ends[p] == prev) {
+        pieceEnds.push_back(prev);
+        pieceOf.push_back(p);
+      }
+      for (int64_t x = prev; x < ends[p]; x += pieceRows) {
+        pieceEnds.push_back(std::min(ends[p], x + pieceRows));
+        pieceOf.push_back(p);
+      }
+      prev = ends[p];
+    }
+  }
+  const int np = (int)pieceEnds.size();
+  std::vector<double> part((size_t)3 * np);
   int64_t *dEnds = nullptr;
   double *dOut = nullptr;
   HIP_TRY(hipMalloc(&dEnds, sizeof(int64_t) * np));
   hipError_t e = hipMalloc(&dOut, sizeof(double) * 3 * np);
-  if (e == hipSuccess) e = hipMemcpyAsync(dEnds, ends.data(), sizeof(int64_t) * np, hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(dEnds, pieceEnds.data(), sizeof(int64_t) * np, hipMemcpyHostToDevice, h->stream);
   if (e == hipSuccess) {
     if (h->opt.dtype == YCNR_F32) {
       RmseArgs<float> a{R.dRowPtr, R.dIndx, (const float *)R.dVals, (const float *)h->factors[0],
@@ -1295,8 +1317,13 @@ int ycnr_als_rmse(ycnr_als *h, int which, double shift, int nPortions, const int
     }
     e = hipGetLastError();
   }
-  if (e == hipSuccess) e = hipMemcpyAsync(out, dOut, sizeof(double) * 3 * np, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(part.data(), dOut, sizeof(double) * 3 * np, hipMemcpyDeviceToHost, h->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (e == hipSuccess) {
+    for (int i = 0; i < 3 * nPort; ++i) out[i] = 0.0;
+    for (int j = 0; j < np; ++j)
+      for (int t = 0; t < 3; ++t) out[3 * pieceOf[j] + t] += part[(size_t)3 * j + t];
+  }
   if (dEnds) (void)hipFree(dEnds);
   if (dOut) (void)hipFree(dOut);
   if (e != hipSuccess) return fail(YCNR_ERR_HIP, "rmse: %s", hipGetErrorString(e));
