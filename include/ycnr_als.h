@@ -131,6 +131,11 @@ typedef struct ycnr_als_options {
  * (bands of 96 MB of the fixed matrix) and their chunks run band by band, so the waves in flight
  * gather from one cache-resident band. */
 #define YCNR_FLAG_NO_BANDS 32
+/* options.flags: launch every kernel of a half-step on the handle's stream, one after the other.
+ * Default: the dual-form kernels (rows with fewer ratings than factors) run on two side streams
+ * of the handle, next to the row kernel; they fork from and join the handle's stream, so the
+ * half-step still begins and ends in stream order. */
+#define YCNR_FLAG_NO_OVERLAP 64
 
 /* Timing / accounting of the last ycnr_als_step, measured with HIP events on the
  * handle's stream around each kernel (DESIGN.md "Measurement"). */
@@ -151,6 +156,10 @@ typedef struct ycnr_als_step_info {
   float reduceSolveMs;   /* als_reduce_solve kernel: slab sum + solve of split rows */
   float totalMs;         /* first kernel start -> last kernel end */
   int32_t numericErrors; /* rows whose matrix was not positive definite */
+  int32_t dualOverlapped; /* 1: the dual kernels ran on the side streams next to als_gram_solve
+                           * (see YCNR_FLAG_NO_OVERLAP): gramSolveMs is the time until that kernel
+                           * ended, dualSolveMs what the dual kernels still needed after it; only
+                           * their sum is the time of a kernel group */
 } ycnr_als_step_info;
 
 int ycnr_als_create(const ycnr_als_options *opts, ycnr_als **out);

@@ -75,6 +75,13 @@ def main():
         t = traffic.setdefault(f"{bn}[{d['half_step']}]", {"kb": 0.0, "launches": 0})
         t["kb"] += 2.0 * d["FETCH_SIZE"] + d.get("WRITE_SIZE", 0.0)
         t["launches"] = max(t["launches"], d["dispatches"])
+    # the whole-row kernels of a half-step as one group (bench.py's entry when the dual kernels run
+    # on side streams next to the row kernel)
+    for side in ("byUser", "byItem"):
+        a, b = traffic.get(f"als_gram_solve_kernel[{side}]"), traffic.get(f"als_dual_solve_kernel[{side}]")
+        if a and b:
+            traffic[f"als_gram_solve_kernel+als_dual_solve_kernel[{side}]"] = {
+                "kb": a["kb"] / a["launches"] + b["kb"] / b["launches"], "launches": 1}
     tpath = os.path.join(here, "traffic.json")
     tj = json.load(open(tpath)) if os.path.exists(tpath) else {"workloads": {}}
     tj["source"] = f"profiles/{tag}_*_pmc_by_kernel.json: (2 x FETCH_SIZE + WRITE_SIZE) KB per launch, rocprofv3 --pmc, own passes"

@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 from helpers import EPS32, make_problem, numpy_step, row_rel_err
-from ycnr_als.data import Csr, csr_to_portion
+from ycnr_als.data import Csr, csr_to_portion, transpose_csr
 
 pytestmark = pytest.mark.gpu
 
@@ -291,6 +291,45 @@ def test_many_rows_at_full_occupancy(als, k):
     assert info.fusedRows > 10000 and info.dualRows > 2000
     want, conds = numpy_step(0.05, k, bu, V, U)
     check_rows(got, want, conds, np.float32)
+
+
+def test_side_streams_do_not_change_results(als):
+    """The dual-form kernels run on the handle's two side streams next to the row kernel
+    (YCNR_FLAG_NO_OVERLAP: everything in stream order).  Same kernels, same rows: three
+    alternating half-steps on one handle must give the same bits either way, and the step info
+    must say which way it went."""
+    from ycnr_als import _lib
+    users, items, k = 20000, 3000, 64
+    rng = np.random.default_rng(77)
+    lens = np.clip(rng.lognormal(np.log(40), 1.0, users).astype(np.int64), 1, 2000)
+    rowPtr = np.zeros(users + 1, np.int64)
+    np.cumsum(lens, out=rowPtr[1:])
+    start = rng.integers(0, items, users)
+    indx = np.empty(rowPtr[-1], np.int32)
+    for u in range(users):
+        indx[rowPtr[u]:rowPtr[u + 1]] = np.sort((start[u] + 1 + np.arange(lens[u])) % items)
+    vals = rng.integers(1, 11, rowPtr[-1]).astype(np.float32)
+    bu = Csr(users, items, rowPtr, indx, vals)
+    import torch
+    bi = transpose_csr(Csr(users, items, torch.from_numpy(rowPtr), torch.from_numpy(indx), torch.from_numpy(vals))).numpy()
+    U0 = (rng.standard_normal((users, k)) / np.sqrt(k)).astype(np.float32)
+    V0 = (rng.standard_normal((items, k)) / np.sqrt(k)).astype(np.float32)
+    got = {}
+    for name, flags in (("side", 0), ("serial", _lib.FLAG_NO_OVERLAP)):
+        dev = als.AlsDevice(k, users, items, flags=flags)
+        dev.set_ratings("byUser", bu.rowPtr, bu.indx, bu.vals)
+        dev.set_ratings("byItem", bi.rowPtr, bi.indx, bi.vals)
+        dev.set_factors("byUser", U0)
+        dev.set_factors("byItem", V0)
+        info = dev.step("byUser")
+        assert info.dualRows > 5000 and info.fusedRows > info.dualRows
+        assert info.dualOverlapped == (1 if flags == 0 else 0)
+        dev.step("byItem")
+        dev.step("byUser")
+        got[name] = (dev.get_factors("byUser"), dev.get_factors("byItem"))
+        dev.destroy()
+    assert np.array_equal(got["side"][0], got["serial"][0])
+    assert np.array_equal(got["side"][1], got["serial"][1])
 
 
 @pytest.mark.parametrize("k", [20, 100, 128])

@@ -363,6 +363,7 @@ napi_value Step(napi_env env, napi_callback_info info) {
   set_num(env, o, "gramSolveMs", si.gramSolveMs);
   set_num(env, o, "dualSolveMs", si.dualSolveMs);
   set_num(env, o, "reduceSolveMs", si.reduceSolveMs);
+  set_num(env, o, "dualOverlapped", (double)si.dualOverlapped);
   set_num(env, o, "time", si.totalMs);  // 'time' of 'completedPortion', EmfWorker.js:258
   return o;
 }

@@ -18,6 +18,7 @@ F32, F64 = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
 RMSE_VALIDATE, RMSE_TEST = 0, 1
 FLAG_LDS_SOLVER, FLAG_NO_DUAL, FLAG_LOCALITY_SORT, FLAG_NO_VALU_EDGE, FLAG_NO_BF16X6, FLAG_NO_BANDS = 1, 2, 4, 8, 16, 32
+FLAG_NO_OVERLAP = 64
 
 # every symbol include/ycnr_als.h declares (checked by tests/test_abi.py)
 EXPORTS = [
@@ -50,7 +51,8 @@ class StepInfo(C.Structure):
                 ("units", C.c_int64), ("splitRows", C.c_int64), ("fusedRows", C.c_int64),
                 ("fusedRatings", C.c_int64), ("dualRows", C.c_int64), ("dualRatings", C.c_int64),
                 ("gramSlabMs", C.c_float), ("gramSolveMs", C.c_float), ("dualSolveMs", C.c_float),
-                ("reduceSolveMs", C.c_float), ("totalMs", C.c_float), ("numericErrors", C.c_int32)]
+                ("reduceSolveMs", C.c_float), ("totalMs", C.c_float), ("numericErrors", C.c_int32),
+                ("dualOverlapped", C.c_int32)]
 
 
 _lib = None

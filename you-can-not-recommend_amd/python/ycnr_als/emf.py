@@ -222,6 +222,7 @@ class HipBackend:
             for f in ("rows", "ratings", "units", "splitRows", "fusedRows", "fusedRatings", "dualRows", "dualRatings",
                       "gramSlabMs", "gramSolveMs", "dualSolveMs", "reduceSolveMs", "totalMs", "numericErrors"):
                 setattr(m, f, getattr(m, f) + getattr(i, f))
+            m.dualOverlapped = max(m.dualOverlapped, i.dualOverlapped)
         return m
 
     def rmse(self, which, shift, portion_row_end):
