@@ -33,24 +33,36 @@ def main():
             for r in csv.DictReader(open(f)):
                 rows.setdefault(int(r["Dispatch_Id"]), {"name": r["Kernel_Name"]})[r["Counter_Name"]] = \
                     rows.get(int(r["Dispatch_Id"]), {}).get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
-    # half-step of each dispatch: a byUser step launches [slab] fused duals [reduce], then byItem the same;
-    # the fused kernel opens a new half-step, slab kernels belong to the half-step that follows them
+    # half-step of each dispatch.  Dispatch order within a half-step: [slab] [dual classes] [row
+    # kernel] [reduce] with the dual classes on side streams (they are enqueued before the row
+    # kernel), or [slab] [row kernel] [dual classes] [reduce] in stream order; k > 128:
+    # ([gram_big] [solve_big])* [dual classes].  A new half-step begins after a reduce kernel, at
+    # a slab kernel that follows anything but slab / big kernels, and at a kernel name that the
+    # current half-step already holds.
     per = {}
-    side, seen_fused = "byUser", False
-    order = sorted(rows)
+    order = [d for d in sorted(rows) if "ycnr::als_" in rows[d]["name"] and "rmse" not in rows[d]["name"]]
     sides = {}
-    half = 0
-    for i, did in enumerate(order):
-        n = rows[did]["name"]
-        if "als_gram_slab" in n or "als_gram_big" in n:
-            # a slab kernel starts a half-step unless it directly follows another slab kernel
-            prev = rows[order[i - 1]]["name"] if i else ""
-            if not ("als_gram_slab" in prev or "als_gram_big" in prev or "als_solve_big" in prev):
-                half += 1
-        elif "als_gram_solve" in n:
-            prev = rows[order[i - 1]]["name"] if i else ""
-            if not ("als_gram_slab" in prev):
-                half += 1
+    half, seen, prev = 1, set(), ""
+    for did in order:
+        n = rows[did]["name"].split("(")[0]
+        slab = "als_gram_slab" in n
+        big = "als_gram_big" in n or "als_solve_big" in n
+        prev_big = "als_gram_big" in prev or "als_solve_big" in prev
+        new_half = False
+        if seen:
+            if "als_reduce_solve" in prev:
+                new_half = True
+            elif slab and "als_gram_slab" not in prev:
+                new_half = True
+            elif big and not prev_big:
+                new_half = True
+            elif n in seen and not big and not slab:
+                new_half = True
+        if new_half:
+            half += 1
+            seen = set()
+        seen.add(n)
+        prev = n
         sides[did] = "byUser" if half % 2 == 1 else "byItem"
     for did in order:
         r = rows[did]
