@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Checks the device assembly for uses of LDS read results that are still in flight.
+
+    hipcc --offload-arch=gfx950 <flags of the Makefile> --cuda-device-only -S -o dev.s ycnr_als.hip
+    python devtest/isa_lint.py dev.s [kernel-name-substring ...]
+
+The Gramian kernels issue their LDS reads from inline asm and count the waits by hand
+(`s_waitcnt lgkmcnt(N)` in later asm statements, MFMAs in between).  hipcc does not know that the
+outputs of the reading asm are not valid yet: it may copy them to other registers, or use them,
+before the waiting asm -- the copy then holds whatever the register held before the read for the
+lanes whose data had not returned (LDS returns lanes 48..63 last).  This walks every kernel in
+program order with a FIFO of outstanding LDS reads (LDS operations complete in order;
+`s_waitcnt lgkmcnt(N)` retires all but the youngest N) and reports any instruction that reads or
+writes a destination register of a read that has not been retired.  Compiler-generated reads must
+come out clean too (the compiler waits before every use): that is the self-check of the tool.
+
+Limits: straight-line walk (a loop back-edge is not followed; a branch does not reset the FIFO),
+scalar memory loads share the counter but may return out of order and are ignored.
+"""
+import re
+import sys
+
+REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+LGKM = re.compile(r"lgkmcnt\((\d+)\)")
+
+
+def regs_of(text):
+    out = set()
+    for m in REG.finditer(text):
+        if m.group(1) is not None:
+            out.add(int(m.group(1)))
+        else:
+            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+def lint(path, wanted):
+    text = open(path).read()
+    total = 0
+    for m in re.finditer(r"^(_Z[\w]+):[^\n]*$", text, re.M):
+        name = m.group(1)
+        if "ycnr" not in name or (wanted and not any(w in name for w in wanted)):
+            continue
+        end = text.find("s_endpgm", m.end())
+        body = text[m.end():end].split("\n")
+        fifo = []  # [(line number, instruction, dest regs)]
+        reads = issues = 0
+        for ln, raw in enumerate(body):
+            ins = raw.split(";")[0].strip()
+            if not ins or ins.endswith(":") or ins.startswith("."):
+                continue
+            op = ins.split()[0]
+            if op == "s_waitcnt":
+                mm = LGKM.search(ins)
+                if mm:
+                    keep = int(mm.group(1))
+                    fifo = fifo[len(fifo) - keep:] if keep else []
+                elif "lgkmcnt" not in ins and "vmcnt" not in ins and "expcnt" not in ins:
+                    fifo = []  # plain "s_waitcnt 0"
+                continue
+            pending = set().union(*[f[2] for f in fifo]) if fifo else set()
+            touched = regs_of(ins.split(None, 1)[1]) if " " in ins else set()
+            hit = pending & touched
+            if hit:
+                issues += 1
+                src = next(f for f in fifo if f[2] & hit)
+                if issues <= 5:
+                    print(f"  {name[:70]}: '{ins}' touches v{sorted(hit)} of in-flight '{src[1]}' ({ln - src[0]} lines earlier)")
+            if op.startswith("ds_read") or op.startswith("ds_bpermute") or op.startswith("ds_swizzle"):
+                dest = regs_of(ins.split(None, 1)[1].split(",")[0])
+                fifo.append((ln, ins, dest))
+                reads += 1
+            elif op.startswith("ds_"):
+                fifo.append((ln, ins, set()))  # writes and others occupy a counter slot
+        if reads:
+            print(f"{'FAIL' if issues else 'ok  '} {name[:90]}: {reads} LDS reads, {issues} premature uses")
+        total += issues
+    return total
+
+
+if __name__ == "__main__":
+    n = lint(sys.argv[1], sys.argv[2:])
+    print("premature uses:", n)
+    sys.exit(1 if n else 0)
