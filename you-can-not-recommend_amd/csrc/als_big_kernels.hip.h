@@ -164,22 +164,44 @@ struct SolveBig {
     float *bvec = Wt + 16 * LDW, *zvec = bvec + NB * 16, *xvec = zvec + NB * 16;
     const float lam = (float)(a.lambda * (double)sr.n);
     // ---- 0. slabs -> LDS tiles (tile ti handled by wave ti % 4), b -> bvec (wave 0)
-    for (int ti = wave; ti < NT; ti += kBigWaves) {
-      acc_t v = acc_t{0.0f, 0.0f, 0.0f, 0.0f};
+    // SUMW tiles per wave and slab at a time: their 4 SUMW loads are in flight together.  (One tile at
+    // a time was one dependent global-memory round trip per tile and slab, 34+ of them per wave with
+    // nothing else resident on the CU to hide them: most of this kernel's time.)
+    constexpr int SUMW = 8;
+    for (int t0 = wave; t0 < NT; t0 += kBigWaves * SUMW) {
+      acc_t v[SUMW];
+#pragma unroll
+      for (int u = 0; u < SUMW; ++u) v[u] = acc_t{0.0f, 0.0f, 0.0f, 0.0f};
       for (int sl = 0; sl < sr.nslabs; ++sl) {
         const float *s = a.slabs + (int64_t)(sr.slab0 + sl) * slab_elems(NB) + lane;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += s[(ti * 4 + r) * 64];
+        for (int u = 0; u < SUMW; ++u) {
+          const int ti = t0 + u * kBigWaves;
+          if (ti < NT) {  // wave-uniform
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[u][r] += s[(ti * 4 + r) * 64];
+          }
+        }
       }
-      store_cd(S + ti * 256, v, g, c);
+#pragma unroll
+      for (int u = 0; u < SUMW; ++u) {
+        const int ti = t0 + u * kBigWaves;
+        if (ti < NT) store_cd(S + ti * 256, v[u], g, c);
+      }
     }
     if (wave == 0) {
+      float v[NB];
+#pragma unroll
+      for (int cb = 0; cb < NB; ++cb) v[cb] = 0.0f;
+      for (int sl = 0; sl < sr.nslabs; ++sl) {
+        const float *s = a.slabs + (int64_t)(sr.slab0 + sl) * slab_elems(NB) + NT * 4 * 64 + lane;
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) v[cb] += s[cb * 64];
+      }
+#pragma unroll
       for (int cb = 0; cb < NB; ++cb) {
-        float v = 0.0f;
-        for (int sl = 0; sl < sr.nslabs; ++sl)
-          v += a.slabs[(int64_t)(sr.slab0 + sl) * slab_elems(NB) + (NT * 4 + cb) * 64 + lane];
-        v = Sm::group_sum(v);
-        if (g == 0) bvec[cb * 16 + c] = v;
+        const float t = Sm::group_sum(v[cb]);
+        if (g == 0) bvec[cb * 16 + c] = t;
       }
     }
     __syncthreads();
