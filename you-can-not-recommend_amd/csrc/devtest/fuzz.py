@@ -23,7 +23,7 @@ while time.time() - t0 < budget:
     order = np.lexsort((np.repeat(np.arange(users), lens), indx))
     ip = np.zeros(items + 1, np.int64); np.cumsum(np.bincount(indx, minlength=items), out=ip[1:])
     bi = Csr(items, users, ip, np.repeat(np.arange(users), lens)[order].astype(np.int32), vals[order])
-    flags = int(rng.choice([0, 0, 0, _lib.FLAG_NO_DUAL, _lib.FLAG_NO_BF16X6, _lib.FLAG_NO_BANDS, _lib.FLAG_NO_VALU_EDGE])) if k <= 128 else int(rng.choice([0, _lib.FLAG_NO_DUAL]))
+    flags = int(rng.choice([0, 0, 0, _lib.FLAG_NO_DUAL, _lib.FLAG_NO_BF16X6, _lib.FLAG_NO_BANDS, _lib.FLAG_NO_VALU_EDGE, _lib.FLAG_NO_OVERLAP])) if k <= 128 else int(rng.choice([0, _lib.FLAG_NO_DUAL]))
     chunk = int(rng.choice([0, 0, 32, 100, 512]))
     U = (rng.standard_normal((users, k)) / np.sqrt(k)).astype(np.float32)
     V = (rng.standard_normal((items, k)) / np.sqrt(k)).astype(np.float32)
