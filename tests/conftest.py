@@ -22,6 +22,9 @@ def pytest_sessionstart(session):
     csrc = os.path.join(ROOT, "you-can-not-recommend_amd", "csrc")
     if not os.path.exists(os.path.join(csrc, "libycnr_als.so")) and (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
         subprocess.run(["make", "-C", csrc], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
+    addon = os.path.join(ROOT, "you-can-not-recommend_amd", "addon")
+    if not os.path.exists(os.path.join(addon, "ycnr_als.node")) and os.path.exists("/usr/include/node/node_api.h"):
+        subprocess.run(["make", "-C", addon], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
 
 
 @pytest.fixture(scope="session")
