@@ -133,8 +133,8 @@ typedef struct ycnr_als_options {
 #define YCNR_FLAG_NO_BANDS 32
 /* options.flags: launch every kernel of a half-step on the handle's stream, one after the other.
  * Default: the dual-form kernels (rows with fewer ratings than factors) run on two side streams
- * of the handle, next to the row kernel; they fork from and join the handle's stream, so the
- * half-step still begins and ends in stream order. */
+ * of the handle, next to the row kernel, when a half-step has at least 1024 such rows; they fork
+ * from and join the handle's stream, so the half-step still begins and ends in stream order. */
 #define YCNR_FLAG_NO_OVERLAP 64
 
 /* Timing / accounting of the last ycnr_als_step, measured with HIP events on the

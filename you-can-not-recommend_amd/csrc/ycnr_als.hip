@@ -159,6 +159,7 @@ void build_schedule(const int64_t *rowPtr, int64_t rowBegin, int64_t nRows, int 
 }
 
 constexpr int kSideStreams = 2;
+constexpr int64_t kMinOverlapDualRows = 1024;  // fewer dual-form rows than this: everything in stream order
 
 struct DualPlan {
   bool noX6 = false;     // YCNR_FLAG_NO_BF16X6: float32-MFMA Gramian in the dual kernels too
@@ -1226,7 +1227,9 @@ int ycnr_als_step_async(ycnr_als *h, int side) {
       dp.nPrimal = S.nPrimal;
       dp.first = S.dualFirst;
       dp.count = S.dualCount;
-      if (!(h->opt.flags & YCNR_FLAG_NO_OVERLAP) && !getenv("YCNR_NO_OVERLAP")) {
+      // (the fork and join cost nine more runtime calls per half-step: with a few hundred rows,
+      // where the half-step is bound by the launches themselves, they made it slower)
+      if (S.dualRows >= kMinOverlapDualRows && !(h->opt.flags & YCNR_FLAG_NO_OVERLAP) && !getenv("YCNR_NO_OVERLAP")) {
         dp.nSide = kSideStreams;
         dp.fork = h->evFork;
         for (int i = 0; i < kSideStreams; ++i) {
@@ -1258,7 +1261,7 @@ int ycnr_als_step_async(ycnr_als *h, int side) {
   if (h->opt.dtype == YCNR_F32 && dual_max_ratings(h->opt) > 0) {
     h->info.dualRows = S.dualRows;
     h->info.dualRatings = S.dualRatings;
-    h->info.dualOverlapped = S.dualRows > 0 && h->opt.factorsCount <= kMaxFactors && !(h->opt.flags & YCNR_FLAG_NO_OVERLAP) &&
+    h->info.dualOverlapped = S.dualRows >= kMinOverlapDualRows && h->opt.factorsCount <= kMaxFactors && !(h->opt.flags & YCNR_FLAG_NO_OVERLAP) &&
                              !getenv("YCNR_NO_OVERLAP");
   }
   h->infoPending = true;
