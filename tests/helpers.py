@@ -8,6 +8,20 @@ from oracle import oracle as orc
 EPS32 = float(np.finfo(np.float32).eps)
 
 
+def host_cpus():
+    """CPUs this process can really use: the affinity mask capped by the cgroup CPU quota (the GPU
+    boxes report os.cpu_count() = 256 under a 16-CPU quota)."""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def make_problem(users, items, k, density=0.1, seed=0, dtype=np.float32, max_rating=5, min_per_row=0,
                  empty_rows=()):
     """Random CSR by user + the same ratings by item, and random factor matrices."""
@@ -69,11 +83,14 @@ class OracleBackend:
     """Backend with the interface of ycnr_als.emf.HipBackend, computing with the CPU oracle.
     TEST ONLY: lets the host classes and the gloo exchange be exercised without a GPU."""
 
-    def __init__(self, opts, users, items, device=0):
+    def __init__(self, opts, users, items, device=0, threads=1, dtype=None):
         import torch
         self.torch = torch
+        self.threads = threads
         self.k = opts["factorsCount"]
         self.dt = np.float64 if opts["useDoublePrecision"] else np.float32
+        if dtype is not None:  # e.g. the float64 oracle behind a float32 run's host options
+            self.dt = dtype
         self.lam = [opts["als"]["userFactReg"], opts["als"]["itemFactReg"]]
         self.fac_np = [np.zeros((users, self.k), self.dt), np.zeros((items, self.k), self.dt)]
         self.fac = [torch.from_numpy(a) for a in self.fac_np]  # shared memory views
@@ -97,7 +114,7 @@ class OracleBackend:
     def step(self, side):
         c, rb, re = self.ratings[side]
         orc.als_step_csr(self.lam[side], self.k, c.rowPtr, c.indx, c.vals, self.fac_np[1 - side], self.fac_np[side],
-                         rb, re)
+                         rb, re, threads=self.threads)
         return None
 
     def rmse(self, which, shift, ends):

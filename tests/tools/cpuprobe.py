@@ -3,7 +3,7 @@ the cgroup quota, and the oracle's row-solve rate at several OpenMP thread count
 rows of 64 ratings), so that bench.py's cpu_baseline can say which thread count it used."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from oracle import oracle as orc
 
 print("cpu_count", os.cpu_count(), "affinity", len(os.sched_getaffinity(0)))

@@ -826,7 +826,7 @@ struct SolveMfmaF32 {
         // v_rsq_f32 as it is (1 ulp).  A Newton step on top of it (3 more instructions on the
         // critical path of each of the 16 pivots) changed nothing measurable: lanes 16-31 invert
         // the L that was actually computed, and the row errors against float64 had the same
-        // median / p99 / max with and without it (devtest/errstats.py), 0.37 ms per MAL iteration.
+        // median / p99 / max with and without it (tests/tools/errstats.py), 0.37 ms per MAL iteration.
         const float rs = __builtin_amdgcn_rsqf(d);
         R[p] *= rs;                             // L[i][p] in lanes 0-15, Linv[p][c] in lanes 16-31
         if constexpr (BATCH) {

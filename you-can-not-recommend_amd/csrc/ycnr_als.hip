@@ -16,6 +16,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <type_traits>
@@ -158,6 +160,34 @@ void build_schedule(const int64_t *rowPtr, int64_t rowBegin, int64_t nRows, int 
   units.insert(units.end(), fused.begin(), fused.end());
 }
 
+// environment toggles for A/B experiments from unmodified hosts, read once per process
+struct EnvFlags {
+  bool noDualX6, noX6d, noFusedX6d, noOverlap, ignoreNumeric;
+  size_t k1LdsPad;
+  int bandMb;  // < 0: default
+};
+const EnvFlags &env_flags() {
+  static const EnvFlags f = {getenv("YCNR_NO_DUAL_X6") != nullptr, getenv("YCNR_NO_X6D") != nullptr, getenv("YCNR_NO_FUSED_X6D") != nullptr,
+                             getenv("YCNR_NO_OVERLAP") != nullptr, getenv("YCNR_IGNORE_NUMERIC") != nullptr,
+                             getenv("YCNR_K1_LDSPAD") ? (size_t)atoi(getenv("YCNR_K1_LDSPAD")) : 0,
+                             getenv("YCNR_BAND_MB") ? atoi(getenv("YCNR_BAND_MB")) : -1};
+  return f;
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize, set once per (kernel, device, size) instead of per half-step
+int set_max_lds(const void *fn, size_t bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<const void *, int>, size_t> done;
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = done.find({fn, dev});
+  if (it != done.end() && it->second == bytes) return YCNR_OK;
+  HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  done[{fn, dev}] = bytes;
+  return YCNR_OK;
+}
+
 constexpr int kSideStreams = 2;
 constexpr int64_t kMinOverlapDualRows = 1024;  // fewer dual-form rows than this: everything in stream order
 
@@ -182,7 +212,7 @@ int launch_dual(StepArgs<float> args, const DualPlan &dp, hipStream_t stream) {
     if (dp.nSide > 0) stream = dp.side[dp.nextSide++ % dp.nSide];
     args.firstDual = (int32_t)dp.first[M];
     // bf16x6 form unless switched off; NBN = 1 has a single tile and too little to gain
-    const bool x6 = !dp.noX6 && !getenv("YCNR_NO_DUAL_X6");
+    const bool x6 = !dp.noX6 && !env_flags().noDualX6;
     void (*kd)(StepArgs<float>) = als_dual_solve_kernel<M, false>;
     if (x6) kd = als_dual_solve_kernel<M, true>;
     hipLaunchKernelGGL(kd, dim3((unsigned)dp.count[M]), dim3(64), SolveMfmaF32<M>::lds_bytes(), stream, args);
@@ -241,15 +271,14 @@ int launch_nbe(StepArgs<T> args, int64_t nUnits, int64_t nSplitUnits, int64_t nS
                hipEvent_t *ev /* 5 events or null */, const DualPlan &dp) {
   const size_t lds = SolverFor<T, NB, LDS_SOLVER>::type::lds_bytes();
   void (*k0)(StepArgs<T>) = SLABX6 ? slab_x6_kernel<T, NB>() : als_gram_slab_kernel<T, NB, EDGE && !SLABX6>;
-  if (SLABX6 && slab_x6d_kernel<T, NB>(args.k) && !getenv("YCNR_NO_X6D")) k0 = slab_x6d_kernel<T, NB>(args.k);
+  if (SLABX6 && slab_x6d_kernel<T, NB>(args.k) && !env_flags().noX6d) k0 = slab_x6d_kernel<T, NB>(args.k);
   void (*k1)(StepArgs<T>) = als_gram_solve_kernel<T, NB, LDS_SOLVER, EDGE>;
-  if (SLABX6 && fused_x6d_kernel<T, NB, LDS_SOLVER>(args.k) && !getenv("YCNR_NO_X6D") && !getenv("YCNR_NO_FUSED_X6D"))
+  if (SLABX6 && fused_x6d_kernel<T, NB, LDS_SOLVER>(args.k) && !env_flags().noX6d && !env_flags().noFusedX6d)
     k1 = fused_x6d_kernel<T, NB, LDS_SOLVER>(args.k);
   auto k2 = als_reduce_solve_kernel<T, NB, LDS_SOLVER, EDGE && !SLABX6>;
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k1),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k2),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const size_t pad = env_flags().k1LdsPad;  // experiments: limits blocks per CU
+  if (int rcl = set_max_lds(reinterpret_cast<const void *>(k1), lds + pad)) return rcl;
+  if (int rcl = set_max_lds(reinterpret_cast<const void *>(k2), lds)) return rcl;
   args.firstFused = (int32_t)nSplitUnits;
   if (ev) HIP_TRY(hipEventRecord(ev[0], stream));
   if (nSplitUnits > 0) {
@@ -268,8 +297,6 @@ int launch_nbe(StepArgs<T> args, int64_t nUnits, int64_t nSplitUnits, int64_t nS
     for (int i = 0; i < dp.nSide; ++i) HIP_TRY(hipEventRecord(dp.join[i], dp.side[i]));
   }
   if (nPrimal > 0) {
-    const size_t pad = getenv("YCNR_K1_LDSPAD") ? (size_t)atoi(getenv("YCNR_K1_LDSPAD")) : 0;  // experiments: limits blocks per CU
-    if (pad) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + pad)));
     hipLaunchKernelGGL(k1, dim3((unsigned)nPrimal), dim3(64), lds + pad, stream, args);
     HIP_TRY(hipGetLastError());
   }
@@ -308,7 +335,7 @@ int launch_big_nb(StepArgs<float> args, const std::vector<Schedule::Batch> &batc
   auto kg = als_gram_big_kernel<NB>;
   auto ks = als_solve_big_kernel<NB>;
   const size_t lds = SolveBig<NB>::lds_bytes();
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (int rcl = set_max_lds(reinterpret_cast<const void *>(ks), lds)) return rcl;
   for (const Schedule::Batch &b : batches) {
     if (b.unitCount == 0) continue;
     args.firstFused = (int32_t)b.unitFirst;
@@ -534,6 +561,18 @@ struct DevBuf {
     if (p) (void)hipFree(p);
   }
 };
+// a pair of timing events that is destroyed on every return path
+struct EvPair {
+  hipEvent_t a = nullptr, b = nullptr;
+  hipError_t create() {
+    hipError_t e = hipEventCreate(&a);
+    return e == hipSuccess ? hipEventCreate(&b) : e;
+  }
+  ~EvPair() {
+    if (a) (void)hipEventDestroy(a);
+    if (b) (void)hipEventDestroy(b);
+  }
+};
 int timed(hipEvent_t e0, hipEvent_t e1, double *ms) {
   HIP_TRY(hipEventRecord(e1, nullptr));
   HIP_TRY(hipEventSynchronize(e1));
@@ -564,9 +603,9 @@ int ycnr_split_to_sets(int64_t rows, const int64_t *rowPtr, int8_t *types, const
   HIP_TRY(hipMalloc(&dTypes.p, (size_t)nnz));
   HIP_TRY(hipMemcpy(dPtr.p, rowPtr, (size_t)(rows + 1) * 8, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(dTypes.p, types, (size_t)nnz, hipMemcpyHostToDevice));
-  hipEvent_t e0, e1;
-  HIP_TRY(hipEventCreate(&e0));
-  HIP_TRY(hipEventCreate(&e1));
+  EvPair evp;
+  HIP_TRY(evp.create());
+  const hipEvent_t e0 = evp.a, e1 = evp.b;
   HIP_TRY(hipEventRecord(e0, nullptr));
   // short rows and long rows apart: the long rows' 60 KB of LDS would leave two waves per CU for everybody
   std::vector<int32_t> lists[2];
@@ -593,8 +632,6 @@ int ycnr_split_to_sets(int64_t rows, const int64_t *rowPtr, int8_t *types, const
                        (int)pcts[0], (int)pcts[1], seed);
   hipError_t le = hipGetLastError();
   int rc = le == hipSuccess ? timed(e0, e1, deviceMs) : fail(YCNR_ERR_HIP, "split_to_sets launch: %s", hipGetErrorString(le));
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
   if (rc) return rc;
   HIP_TRY(hipMemcpy(types, dTypes.p, (size_t)nnz, hipMemcpyDeviceToHost));
   return YCNR_OK;
@@ -620,9 +657,9 @@ int ycnr_rating_stats(int dtype, int64_t rows, const int64_t *rowPtr, const void
     HIP_TRY(hipMalloc(&dTypes.p, (size_t)nnz));
     HIP_TRY(hipMemcpy(dTypes.p, types, (size_t)nnz, hipMemcpyHostToDevice));
   }
-  hipEvent_t e0, e1;
-  HIP_TRY(hipEventCreate(&e0));
-  HIP_TRY(hipEventCreate(&e1));
+  EvPair evp;
+  HIP_TRY(evp.create());
+  const hipEvent_t e0 = evp.a, e1 = evp.b;
   HIP_TRY(hipEventRecord(e0, nullptr));
   constexpr int64_t kLongRow = 2048;  // longer rows get a workgroup each
   std::vector<int32_t> longRows;
@@ -650,8 +687,6 @@ int ycnr_rating_stats(int dtype, int64_t rows, const int64_t *rowPtr, const void
   }
   hipError_t le = hipGetLastError();
   int rc = le == hipSuccess ? timed(e0, e1, deviceMs) : fail(YCNR_ERR_HIP, "rating_stats launch: %s", hipGetErrorString(le));
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
   if (rc) return rc;
   HIP_TRY(hipMemcpy(cnt, dCnt.p, (size_t)rows * 4, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(sum, dSum.p, (size_t)rows * 8, hipMemcpyDeviceToHost));
@@ -726,15 +761,13 @@ int ycnr_csr_from_triplets(int dtype, int64_t n, const int32_t *rowIdx, const in
   HIP_TRY(hipMemcpy(dR.p, rowIdx, (size_t)n * 4, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(dC.p, colIdx, (size_t)n * 4, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(dV.p, vals, (size_t)n * ts, hipMemcpyHostToDevice));
-  hipEvent_t e0, e1;
-  HIP_TRY(hipEventCreate(&e0));
-  HIP_TRY(hipEventCreate(&e1));
+  EvPair evp;
+  HIP_TRY(evp.create());
+  const hipEvent_t e0 = evp.a, e1 = evp.b;
   HIP_TRY(hipEventRecord(e0, nullptr));
   hipLaunchKernelGGL(make_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, (const int32_t *)dR.p, (const int32_t *)dC.p, n,
                      (uint64_t *)dKeys.p, (uint32_t *)dPos.p);
   int rc = sort_and_unpack(dtype, n, rows, cols, (uint64_t *)dKeys.p, (uint32_t *)dPos.p, dV.p, rowPtr, indx, outVals, e0, e1, deviceMs);
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
   return rc;
 }
 
@@ -765,15 +798,13 @@ int ycnr_csr_transpose(int dtype, int64_t rows, int64_t cols, const int64_t *row
   HIP_TRY(hipMemcpy(dP.p, rowPtr, (size_t)(rows + 1) * 8, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(dI.p, indx, (size_t)n * 4, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(dV.p, vals, (size_t)n * ts, hipMemcpyHostToDevice));
-  hipEvent_t e0, e1;
-  HIP_TRY(hipEventCreate(&e0));
-  HIP_TRY(hipEventCreate(&e1));
+  EvPair evp;
+  HIP_TRY(evp.create());
+  const hipEvent_t e0 = evp.a, e1 = evp.b;
   HIP_TRY(hipEventRecord(e0, nullptr));
   hipLaunchKernelGGL(make_transpose_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, (const int64_t *)dP.p, rows,
                      (const int32_t *)dI.p, n, (uint64_t *)dKeys.p, (uint32_t *)dPos.p);
   int rc = sort_and_unpack(dtype, n, cols, rows, (uint64_t *)dKeys.p, (uint32_t *)dPos.p, dV.p, outPtr, outIndx, outVals, e0, e1, deviceMs);
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
   return rc;
 }
 
@@ -790,6 +821,7 @@ int ycnr_recommend_items(int dtype, int32_t k, int64_t nUsers, const void *userR
     return fail(YCNR_ERR_INVALID, "ycnr_recommend_items: null argument");
   if (skipPtr[0] != 0) return fail(YCNR_ERR_INVALID, "ycnr_recommend_items: skipPtr[0] != 0");
   for (int64_t u = 0; u < nUsers; ++u) {
+    if (skipPtr[u + 1] > skipPtr[u] && !skipIds) return fail(YCNR_ERR_INVALID, "ycnr_recommend_items: null skipIds");
     if (skipPtr[u + 1] < skipPtr[u]) return fail(YCNR_ERR_INVALID, "ycnr_recommend_items: skipPtr decreases at user %lld", (long long)u);
     for (int64_t q = skipPtr[u]; q < skipPtr[u + 1]; ++q)
       if (q > skipPtr[u] && skipIds[q] <= skipIds[q - 1])
@@ -812,9 +844,9 @@ int ycnr_recommend_items(int dtype, int32_t k, int64_t nUsers, const void *userR
   HIP_TRY(hipMalloc(&dCnt.p, (size_t)batch * 4));
   if (totalItems) HIP_TRY(hipMemcpy(dItems.p, itemFactors, (size_t)totalItems * k * ts, hipMemcpyHostToDevice));
   if (nSkip) HIP_TRY(hipMemcpy(dSkip.p, skipIds, (size_t)nSkip * 4, hipMemcpyHostToDevice));
-  hipEvent_t e0, e1;
-  HIP_TRY(hipEventCreate(&e0));
-  HIP_TRY(hipEventCreate(&e1));
+  EvPair evp;
+  HIP_TRY(evp.create());
+  const hipEvent_t e0 = evp.a, e1 = evp.b;
   double total = 0.0;
   int rc = YCNR_OK;
   std::vector<int64_t> localPtr;
@@ -843,8 +875,6 @@ int ycnr_recommend_items(int dtype, int32_t k, int64_t nUsers, const void *userR
     HIP_TRY(hipMemcpy(outPredict + u0 * limit, dPred.p, (size_t)nb * limit * 8, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(outCount + u0, dCnt.p, (size_t)nb * 4, hipMemcpyDeviceToHost));
   }
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
   if (deviceMs) *deviceMs = total;
   return rc;
 }
@@ -992,7 +1022,21 @@ int ycnr_als_set_ratings(ycnr_als *h, int side, const int64_t *rowPtr, const int
   if (!h) return fail(YCNR_ERR_INVALID, "null handle");
   if (side != YCNR_BY_USER && side != YCNR_BY_ITEM) return fail(YCNR_ERR_INVALID, "bad side %d", side);
   std::vector<int64_t> hp;
-  int rc = upload_ratings(h, h->ratings[side], h->rows(side), h->rows(1 - side), rowPtr, indx, vals, rowBegin,
+  // ratings and schedule are built in locals and committed together at the end: a failure on the
+  // way leaves the handle's previous upload (or none) intact, never new ratings with an old schedule
+  struct Pending {
+    Ratings R;
+    Schedule S;
+    bool keep = false;
+    ~Pending() {
+      if (!keep) {
+        R.release();
+        S.release();
+      }
+    }
+  } pend;
+  Ratings &newR = pend.R;
+  int rc = upload_ratings(h, newR, h->rows(side), h->rows(1 - side), rowPtr, indx, vals, rowBegin,
                           rowEnd, memKind, hp, side == YCNR_BY_USER ? "set_ratings(byUser)" : "set_ratings(byItem)");
   if (rc) return rc;
   std::vector<Unit> units;
@@ -1038,9 +1082,11 @@ int ycnr_als_set_ratings(ycnr_als *h, int side, const int64_t *rowPtr, const int
     const int64_t fixedRows = h->rows(1 - side);
     const int64_t rowBytes = (int64_t)h->opt.factorsCount * (int64_t)h->ts();
     int64_t bandBytes = kBandBytes;
-    if (const char *e = getenv("YCNR_BAND_MB")) bandBytes = (int64_t)atoi(e) << 20;
+    if (env_flags().bandMb >= 0) bandBytes = (int64_t)env_flags().bandMb << 20;
     if (!big && nSlabs > 1 && !(h->opt.flags & YCNR_FLAG_NO_BANDS) && bandBytes > 0 && fixedRows * rowBytes > 2 * bandBytes) {
-      const int64_t W = std::max<int64_t>(1, bandBytes / rowBytes);
+      // at most kMaxSlabsPerRow / 2 bands, so that a row present in every band still has chunks to
+      // spare (very large fixed matrices get wider bands instead of a failed upload)
+      const int64_t W = std::max<int64_t>(std::max<int64_t>(1, bandBytes / rowBytes), (fixedRows + kMaxSlabsPerRow / 2 - 1) / (kMaxSlabsPerRow / 2));
       const int nBands = (int)((fixedRows + W - 1) / W);
       const int64_t base = hp[0];
       std::vector<int64_t> qBeg, qEnd, cuts;
@@ -1053,7 +1099,7 @@ int ycnr_als_set_ratings(ycnr_als *h, int side, const int64_t *rowPtr, const int
           qKey.push_back((int32_t)(j * W));
         }
       }
-      int rc2 = lower_bound_i32(h->ratings[side].dIndx, qBeg, qEnd, qKey, cuts, h->stream);
+      int rc2 = lower_bound_i32(newR.dIndx, qBeg, qEnd, qKey, cuts, h->stream);
       if (rc2) return rc2;
       struct BandUnit { Unit u; int band; };
       std::vector<BandUnit> bu;
@@ -1106,8 +1152,7 @@ int ycnr_als_set_ratings(ycnr_als *h, int side, const int64_t *rowPtr, const int
       arenaSlabs = slabs;
     }
   }
-  Schedule &S = h->sched[side];
-  S.release();
+  Schedule &S = pend.S;
   S.nUnits = (int64_t)units.size();
   S.nSplit = (int64_t)split.size();
   S.nSlabs = nSlabs;
@@ -1140,6 +1185,12 @@ int ycnr_als_set_ratings(ycnr_als *h, int side, const int64_t *rowPtr, const int
     HIP_TRY(hipMemcpy(S.dSplit, split.data(), sizeof(SplitRow) * split.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc(&S.dSlabs, (size_t)arenaSlabs * slab_regs(h->opt, side) * 64 * h->ts()));
   }
+  HIP_TRY(hipStreamSynchronize(h->stream));  // nothing in flight still reads the previous upload
+  h->ratings[side].release();
+  h->sched[side].release();
+  h->ratings[side] = pend.R;
+  h->sched[side] = pend.S;
+  pend.keep = true;
   return YCNR_OK;
 }
 
@@ -1154,8 +1205,12 @@ int ycnr_als_set_rmse_ratings(ycnr_als *h, int which, const int64_t *rowPtr, con
   if (rc) return rc;
   const int64_t base = hp[0];
   for (auto &v : hp) v -= base;
-  HIP_TRY(hipMalloc(&R.dRowPtr, sizeof(int64_t) * hp.size()));
-  HIP_TRY(hipMemcpy(R.dRowPtr, hp.data(), sizeof(int64_t) * hp.size(), hipMemcpyHostToDevice));
+  hipError_t e = hipMalloc(&R.dRowPtr, sizeof(int64_t) * hp.size());
+  if (e == hipSuccess) e = hipMemcpy(R.dRowPtr, hp.data(), sizeof(int64_t) * hp.size(), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    R.release();  // never "loaded" without its row pointers
+    return fail(e == hipErrorOutOfMemory ? YCNR_ERR_NOMEM : YCNR_ERR_HIP, "set_rmse_ratings: %s", hipGetErrorString(e));
+  }
   return YCNR_OK;
 }
 
@@ -1229,7 +1284,7 @@ int ycnr_als_step_async(ycnr_als *h, int side) {
       dp.count = S.dualCount;
       // (the fork and join cost nine more runtime calls per half-step: with a few hundred rows,
       // where the half-step is bound by the launches themselves, they made it slower)
-      if (S.dualRows >= kMinOverlapDualRows && !(h->opt.flags & YCNR_FLAG_NO_OVERLAP) && !getenv("YCNR_NO_OVERLAP")) {
+      if (S.dualRows >= kMinOverlapDualRows && !(h->opt.flags & YCNR_FLAG_NO_OVERLAP) && !env_flags().noOverlap) {
         dp.nSide = kSideStreams;
         dp.fork = h->evFork;
         for (int i = 0; i < kSideStreams; ++i) {
@@ -1262,7 +1317,7 @@ int ycnr_als_step_async(ycnr_als *h, int side) {
     h->info.dualRows = S.dualRows;
     h->info.dualRatings = S.dualRatings;
     h->info.dualOverlapped = S.dualRows >= kMinOverlapDualRows && h->opt.factorsCount <= kMaxFactors && !(h->opt.flags & YCNR_FLAG_NO_OVERLAP) &&
-                             !getenv("YCNR_NO_OVERLAP");
+                             !env_flags().noOverlap;
   }
   h->infoPending = true;
   h->infoHasSplit = S.nSplit > 0;
@@ -1289,7 +1344,7 @@ int ycnr_als_sync(ycnr_als *h) {
     ErrInfo ei{};
     HIP_TRY(hipMemcpy(&ei, h->dErr, sizeof ei, hipMemcpyDeviceToHost));
     h->info.numericErrors = ei.count;
-    if (ei.count > 0 && !getenv("YCNR_IGNORE_NUMERIC"))  // the env var exists for timing experiments with ablated kernels
+    if (ei.count > 0 && !env_flags().ignoreNumeric)  // the env var exists for timing experiments with ablated kernels
       return fail(YCNR_ERR_NUMERIC, "%d row(s) had a normal matrix that is not positive definite (e.g. row %d)",
                   ei.count, ei.firstRow);
   }

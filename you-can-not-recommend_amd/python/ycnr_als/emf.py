@@ -226,6 +226,9 @@ class HipBackend:
         return m
 
     def rmse(self, which, shift, portion_row_end):
+        # the exchange of the last half-step runs on torch's streams, the RMSE kernel on the handle's
+        # own (non-blocking) stream: nothing else orders the two
+        self.torch.cuda.synchronize(self.device)
         return self.dev.rmse(which, shift, portion_row_end)
 
     def destroy(self):
@@ -319,7 +322,8 @@ class EmfLord:
             if csr is None:
                 continue
             self.backend.set_rmse_ratings(name, csr, int(ub), int(ue))
-            ends, _, _ = split_to_portions(cu, self.totalUsersCount, self.options["ratingsInPortionForRmse"],
+            # rows_cnt = trainUsersCount: the users that have ratings (EmfLord.js:526), not the max id
+            ends, _, _ = split_to_portions(cu, int((cu > 0).sum()), self.options["ratingsInPortionForRmse"],
                                            nthreads, pct)
             if len(ends):
                 ends[-1] = self.totalUsersCount
