@@ -261,7 +261,7 @@ def main():
     }
     if dom in traffic:
         roofline["traffic"] = traffic[dom]["hbm_bytes_per_launch"]
-        roofline["traffic_source"] = tj.get("source", "profiles/traffic.json")
+        roofline["traffic_source"] = tj.get("sources", {}).get(args.workload + ("_f64" if args.double else ""), "profiles/traffic.json")
         roofline["traffic_over_algorithmic"] = round(traffic[dom]["hbm_bytes_per_launch"] / (kern[dom]["bytes"] / kern[dom]["launches"]), 3)
         roofline["traffic_frac_of_hbm_peak"] = round(mem_frac, 4)
 

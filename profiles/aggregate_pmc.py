@@ -96,7 +96,8 @@ def main():
                 "kb": a["kb"] / a["launches"] + b["kb"] / b["launches"], "launches": 1}
     tpath = os.path.join(here, "traffic.json")
     tj = json.load(open(tpath)) if os.path.exists(tpath) else {"workloads": {}}
-    tj["source"] = f"profiles/{tag}_*_pmc_by_kernel.json: (2 x FETCH_SIZE + WRITE_SIZE) KB per launch, rocprofv3 --pmc, own passes"
+    tj.setdefault("sources", {})[workload] = (f"profiles/{tag}_{workload}_pmc_by_kernel.json: (2 x FETCH_SIZE + WRITE_SIZE) KB per launch, "
+                                              "rocprofv3 --pmc, own passes")
     tj["workloads"][workload] = {k: {"hbm_bytes_per_launch": round(v["kb"] * 1024.0 / v["launches"])} for k, v in traffic.items()}
     json.dump(tj, open(tpath, "w"), indent=1)
     for k, v in tj["workloads"][workload].items():

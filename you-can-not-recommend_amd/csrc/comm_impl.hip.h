@@ -1,0 +1,300 @@
+// comm_impl.hip.h -- the exchange step of the multi-GPU path, included by ycnr_als.hip (after its
+// fail() / HIP_TRY helpers, inside its anonymous namespace).
+//
+// The reference keeps every node's copy of the factor matrices current by streaming the rows of
+// each finished portion to all peers over TCP ('alsSaveCalcedFactors', lib/emf/EmfMaster.js:711-723,
+// receivers EmfLord.js:727-732 / EmfChief.js:207-212), copies both matrices to a joining node
+// (EmfChief.js:55-71) and sends RMSE partial sums to the Lord ('rmseSaveCalcs', EmfMaster.js:726-736).
+// Here one process drives one GPU and the same three roles are:
+//   exchange      every rank's freshly solved row range goes straight into every other rank's replica
+//                 of the matrix, at the rows' own offset -- no staging buffer, no copy in or out;
+//   broadcast     one rank's whole matrix to all (join / warm start);
+//   all-reduce    sums of doubles (RMSE partials).
+// Transports:
+//   YCNR_COMM_RCCL  the product path: RCCL over xGMI.  The exchange is ONE group of point-to-point
+//                   ncclSend / ncclRecv between all pairs of ranks (a "direct" all-gather): xGMI is a
+//                   full mesh of point-to-point links, so every link carries exactly the shard its two
+//                   ends owe each other, all seven at once, instead of a ring passing every shard
+//                   through every link in turn.  Uneven shards need no padding.  RCCL is loaded with
+//                   dlopen when a communicator is created, so single-GPU users never load it.
+//   YCNR_COMM_SHM   functional stand-in for tests: ranks on ONE node stage their rows through a POSIX
+//                   shared-memory segment (synchronous, host barriers).  It exists so that several
+//                   ranks can share one GPU (RCCL refuses duplicate devices) -- what gloo is to nccl.
+#pragma once
+#include <rccl/rccl.h>
+
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <chrono>
+
+struct RcclApi {
+  void *dl = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+// process-wide, loaded once
+int rccl_api(const RcclApi **out) {
+  static RcclApi api;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!api.dl) {
+    // librccl.so.1 is the SONAME of both ROCm's and PyTorch's copy: inside a torch process this
+    // resolves to the library torch has already loaded (one RCCL per process)
+    void *dl = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!dl) dl = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!dl) dl = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!dl) return fail(YCNR_ERR_UNSUPPORTED, "RCCL is not available: %s", dlerror());
+    RcclApi a;
+    a.dl = dl;
+#define YCNR_SYM(field, name)                                                            \
+  a.field = reinterpret_cast<decltype(a.field)>(dlsym(dl, name));                        \
+  if (!a.field) {                                                                        \
+    dlclose(dl);                                                                         \
+    return fail(YCNR_ERR_UNSUPPORTED, "RCCL: symbol %s not found", name);                \
+  }
+    YCNR_SYM(GetUniqueId, "ncclGetUniqueId")
+    YCNR_SYM(CommInitRank, "ncclCommInitRank")
+    YCNR_SYM(CommDestroy, "ncclCommDestroy")
+    YCNR_SYM(GroupStart, "ncclGroupStart")
+    YCNR_SYM(GroupEnd, "ncclGroupEnd")
+    YCNR_SYM(Send, "ncclSend")
+    YCNR_SYM(Recv, "ncclRecv")
+    YCNR_SYM(AllReduce, "ncclAllReduce")
+    YCNR_SYM(Broadcast, "ncclBroadcast")
+    YCNR_SYM(GetErrorString, "ncclGetErrorString")
+#undef YCNR_SYM
+    api = a;
+  }
+  *out = &api;
+  return YCNR_OK;
+}
+
+#define NCCL_TRY(api, expr)                                                                              \
+  do {                                                                                                   \
+    ncclResult_t r_ = (expr);                                                                            \
+    if (r_ != ncclSuccess) return fail(YCNR_ERR_HIP, "%s failed: %s", #expr, (api)->GetErrorString(r_)); \
+  } while (0)
+
+// header of the shared-memory segment of the SHM transport (zero-filled pages are its valid start state)
+struct ShmHeader {
+  std::atomic<uint32_t> count, gen;
+  std::atomic<uint32_t> attached;
+  uint32_t pad[13];
+};
+static_assert(sizeof(ShmHeader) == 64, "ShmHeader layout");
+
+struct Comm {
+  int transport = YCNR_COMM_NONE, rank = 0, world = 1;
+  hipStream_t stream = nullptr;  // exchanges run here, next to the compute stream
+  // RCCL
+  const RcclApi *api = nullptr;
+  ncclComm_t nccl = nullptr;
+  double *dScratch = nullptr;  // all-reduce staging
+  size_t scratchCount = 0;
+  // SHM
+  int fd = -1;
+  char name[80] = {0};
+  ShmHeader *hdr = nullptr;
+  char *data = nullptr;
+  size_t dataBytes = 0, mapBytes = 0;
+
+  bool active() const { return transport != YCNR_COMM_NONE && world > 1; }
+};
+
+int shm_barrier(Comm &c) {
+  const uint32_t gen = c.hdr->gen.load(std::memory_order_acquire);
+  if (c.hdr->count.fetch_add(1, std::memory_order_acq_rel) == (uint32_t)c.world - 1) {
+    c.hdr->count.store(0, std::memory_order_relaxed);
+    c.hdr->gen.fetch_add(1, std::memory_order_acq_rel);
+    return YCNR_OK;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 0; c.hdr->gen.load(std::memory_order_acquire) == gen; ++spins) {
+    if ((spins & 1023) == 1023) {
+      sched_yield();
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120))
+        return fail(YCNR_ERR_STATE, "shared-memory barrier: a peer did not arrive within 120 s (rank %d of %d)", c.rank, c.world);
+    }
+  }
+  return YCNR_OK;
+}
+
+void comm_release(Comm &c) {
+  if (c.nccl && c.api) (void)c.api->CommDestroy(c.nccl);
+  c.nccl = nullptr;
+  if (c.dScratch) (void)hipFree(c.dScratch);
+  c.dScratch = nullptr;
+  if (c.hdr) munmap(c.hdr, c.mapBytes);
+  c.hdr = nullptr;
+  if (c.fd >= 0) close(c.fd);
+  c.fd = -1;
+  if (c.stream) {
+    (void)hipStreamSynchronize(c.stream);
+    (void)hipStreamDestroy(c.stream);
+  }
+  c.stream = nullptr;
+  c.transport = YCNR_COMM_NONE;
+  c.world = 1;
+  c.rank = 0;
+}
+
+// dataBytes: the largest payload one exchange / broadcast / all-reduce of this job can stage (SHM only)
+int comm_setup(Comm &c, const void *id, int transport, int rank, int world, size_t dataBytes) {
+  if (world < 1 || rank < 0 || rank >= world) return fail(YCNR_ERR_INVALID, "comm_init: rank %d of %d", rank, world);
+  if (!id) return fail(YCNR_ERR_INVALID, "comm_init: null id");
+  c.rank = rank;
+  c.world = world;
+  HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+  if (transport == YCNR_COMM_RCCL) {
+    int rc = rccl_api(&c.api);
+    if (rc) return rc;
+    ncclUniqueId uid;
+    static_assert(sizeof(uid) == YCNR_COMM_ID_BYTES, "ncclUniqueId size");
+    memcpy(&uid, id, sizeof uid);
+    NCCL_TRY(c.api, c.api->CommInitRank(&c.nccl, world, uid, rank));
+    c.transport = YCNR_COMM_RCCL;
+    return YCNR_OK;
+  }
+  if (transport == YCNR_COMM_SHM) {
+    const unsigned char *b = (const unsigned char *)id;
+    snprintf(c.name, sizeof c.name, "/ycnr_%02x%02x%02x%02x%02x%02x%02x%02x%02x%02x%02x%02x", b[0], b[1], b[2], b[3], b[4], b[5], b[6],
+             b[7], b[8], b[9], b[10], b[11]);
+    c.dataBytes = dataBytes;
+    c.mapBytes = sizeof(ShmHeader) + dataBytes;
+    c.fd = shm_open(c.name, O_CREAT | O_RDWR, 0600);
+    if (c.fd < 0) return fail(YCNR_ERR_HIP, "shm_open(%s) failed: %s", c.name, strerror(errno));
+    if (ftruncate(c.fd, (off_t)c.mapBytes) != 0) return fail(YCNR_ERR_NOMEM, "ftruncate(%s, %zu) failed: %s", c.name, c.mapBytes, strerror(errno));
+    void *p = mmap(nullptr, c.mapBytes, PROT_READ | PROT_WRITE, MAP_SHARED, c.fd, 0);
+    if (p == MAP_FAILED) return fail(YCNR_ERR_NOMEM, "mmap(%s, %zu) failed: %s", c.name, c.mapBytes, strerror(errno));
+    c.hdr = (ShmHeader *)p;
+    c.data = (char *)p + sizeof(ShmHeader);
+    c.transport = YCNR_COMM_SHM;
+    // the name can go once everybody has mapped the segment
+    c.hdr->attached.fetch_add(1, std::memory_order_acq_rel);
+    int rc = shm_barrier(c);
+    if (rc) return rc;
+    if (rank == 0) shm_unlink(c.name);
+    return YCNR_OK;
+  }
+  return fail(YCNR_ERR_INVALID, "comm_init: unknown transport %d", transport);
+}
+
+// Rows [begin[r], end[r]) of `fac` ([rows x k] elements of ts bytes) are current on rank r; bring
+// every replica up to date.  `ready` has been recorded on the compute stream after the kernels
+// that produced this rank's rows.  RCCL: enqueued on c.stream (returns at once; `done` is recorded
+// behind it); SHM: synchronous.
+int comm_exchange(Comm &c, void *fac, int64_t k, size_t ts, const int64_t *begin, const int64_t *end, hipStream_t compute,
+                  hipEvent_t ready, hipEvent_t t0, hipEvent_t t1, int64_t *bytesMoved) {
+  const size_t rowBytes = (size_t)k * ts;
+  int64_t moved = 0;
+  for (int p = 0; p < c.world; ++p) {
+    if (end[p] < begin[p]) return fail(YCNR_ERR_INVALID, "exchange: bad row range of rank %d", p);
+    if (p != c.rank) moved += (end[p] - begin[p]) * (int64_t)rowBytes;                      // received
+    else moved += (end[p] - begin[p]) * (int64_t)rowBytes * (int64_t)(c.world - 1);         // sent
+  }
+  if (bytesMoved) *bytesMoved += moved;
+  if (c.transport == YCNR_COMM_RCCL) {
+    HIP_TRY(hipEventRecord(ready, compute));
+    HIP_TRY(hipStreamWaitEvent(c.stream, ready, 0));
+    HIP_TRY(hipEventRecord(t0, c.stream));
+    const ncclDataType_t dt = ts == 8 ? ncclDouble : ncclFloat;
+    const size_t mine = (size_t)(end[c.rank] - begin[c.rank]) * (size_t)k;
+    NCCL_TRY(c.api, c.api->GroupStart());
+    // peers in "distance" order, so that at any moment the pairs (r, r + d) talk: every link busy
+    for (int d = 1; d < c.world; ++d) {
+      const int to = (c.rank + d) % c.world, from = (c.rank - d + c.world) % c.world;
+      if (mine > 0) NCCL_TRY(c.api, c.api->Send((const char *)fac + (size_t)begin[c.rank] * rowBytes, mine, dt, to, c.nccl, c.stream));
+      const size_t theirs = (size_t)(end[from] - begin[from]) * (size_t)k;
+      if (theirs > 0) NCCL_TRY(c.api, c.api->Recv((char *)fac + (size_t)begin[from] * rowBytes, theirs, dt, from, c.nccl, c.stream));
+    }
+    NCCL_TRY(c.api, c.api->GroupEnd());
+    HIP_TRY(hipEventRecord(t1, c.stream));
+    return YCNR_OK;
+  }
+  if (c.transport == YCNR_COMM_SHM) {
+    HIP_TRY(hipEventRecord(t0, compute));
+    HIP_TRY(hipStreamSynchronize(compute));
+    int64_t lo = begin[0], hi = end[0];
+    for (int p = 1; p < c.world; ++p) {
+      lo = std::min(lo, begin[p]);
+      hi = std::max(hi, end[p]);
+    }
+    if ((size_t)(hi - lo) * rowBytes > c.dataBytes) return fail(YCNR_ERR_STATE, "exchange: %zu bytes exceed the shared segment", (size_t)(hi - lo) * rowBytes);
+    const size_t mine = (size_t)(end[c.rank] - begin[c.rank]) * rowBytes;
+    if (mine) HIP_TRY(hipMemcpy(c.data + (size_t)(begin[c.rank] - lo) * rowBytes, (const char *)fac + (size_t)begin[c.rank] * rowBytes, mine, hipMemcpyDeviceToHost));
+    int rc = shm_barrier(c);
+    if (rc) return rc;
+    for (int p = 0; p < c.world; ++p) {
+      const size_t n = (size_t)(end[p] - begin[p]) * rowBytes;
+      if (p != c.rank && n) HIP_TRY(hipMemcpy((char *)fac + (size_t)begin[p] * rowBytes, c.data + (size_t)(begin[p] - lo) * rowBytes, n, hipMemcpyHostToDevice));
+    }
+    rc = shm_barrier(c);  // the segment may be overwritten again
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(t1, compute));
+    return YCNR_OK;
+  }
+  return fail(YCNR_ERR_STATE, "exchange without a communicator");
+}
+
+// vals[i] <- sum over ranks, in rank order (SHM) / RCCL's order
+int comm_allreduce_sum(Comm &c, double *vals, int64_t n) {
+  if (n <= 0 || !c.active()) return YCNR_OK;
+  if (c.transport == YCNR_COMM_RCCL) {
+    if (c.scratchCount < (size_t)n) {
+      if (c.dScratch) (void)hipFree(c.dScratch);
+      c.dScratch = nullptr;
+      c.scratchCount = 0;
+      HIP_TRY(hipMalloc(&c.dScratch, sizeof(double) * (size_t)n));
+      c.scratchCount = (size_t)n;
+    }
+    HIP_TRY(hipMemcpyAsync(c.dScratch, vals, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c.stream));
+    NCCL_TRY(c.api, c.api->AllReduce(c.dScratch, c.dScratch, (size_t)n, ncclDouble, ncclSum, c.nccl, c.stream));
+    HIP_TRY(hipMemcpyAsync(vals, c.dScratch, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c.stream));
+    HIP_TRY(hipStreamSynchronize(c.stream));
+    return YCNR_OK;
+  }
+  if ((size_t)n * sizeof(double) * (size_t)c.world > c.dataBytes) return fail(YCNR_ERR_STATE, "all-reduce: %lld doubles exceed the shared segment", (long long)n);
+  double *all = (double *)c.data;
+  memcpy(all + (size_t)c.rank * (size_t)n, vals, sizeof(double) * (size_t)n);
+  int rc = shm_barrier(c);
+  if (rc) return rc;
+  for (int64_t i = 0; i < n; ++i) {
+    double s = 0.0;
+    for (int p = 0; p < c.world; ++p) s += all[(size_t)p * (size_t)n + (size_t)i];
+    vals[i] = s;
+  }
+  return shm_barrier(c);
+}
+
+// the whole matrix of `root` to every rank (a joining node's copy, lib/emf/EmfChief.js:55-71)
+int comm_broadcast(Comm &c, void *fac, size_t bytes, int root, hipStream_t compute) {
+  if (!c.active()) return YCNR_OK;
+  if (root < 0 || root >= c.world) return fail(YCNR_ERR_INVALID, "broadcast: root %d of %d", root, c.world);
+  HIP_TRY(hipStreamSynchronize(compute));
+  if (c.transport == YCNR_COMM_RCCL) {
+    NCCL_TRY(c.api, c.api->Broadcast(fac, fac, bytes, ncclChar, root, c.nccl, c.stream));
+    HIP_TRY(hipStreamSynchronize(c.stream));
+    return YCNR_OK;
+  }
+  if (bytes > c.dataBytes) return fail(YCNR_ERR_STATE, "broadcast: %zu bytes exceed the shared segment", bytes);
+  if (c.rank == root) HIP_TRY(hipMemcpy(c.data, fac, bytes, hipMemcpyDeviceToHost));
+  int rc = shm_barrier(c);
+  if (rc) return rc;
+  if (c.rank != root) HIP_TRY(hipMemcpy(fac, c.data, bytes, hipMemcpyHostToDevice));
+  return shm_barrier(c);
+}

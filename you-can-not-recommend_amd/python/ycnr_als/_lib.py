@@ -67,6 +67,14 @@ def load():
         raise ImportError(
             f"{SO_PATH} is missing: build it with `make -C {CSRC}` (or __graft_entry__.build()). "
             "The ALS path has no CPU fallback.")
+    # PyTorch bundles its own HIP runtime under the same SONAME (libamdhip64.so.7).  Whichever copy
+    # is loaded first serves the whole process, and torch does not see the GPU through the system's
+    # copy (observed: torch.cuda.is_available() == False when this library was loaded first).  The
+    # host classes of this package use torch for device memory and collectives, so let it go first.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(SO_PATH)
     vp, i32, i64, dbl = C.c_void_p, C.c_int, C.c_int64, C.c_double
     L.ycnr_last_error.restype = C.c_char_p
