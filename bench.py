@@ -70,6 +70,9 @@ def main():
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for functional tests)")
     ap.add_argument("--same-device", action="store_true",
                     help="functional test only: every rank uses cuda:0 (several ranks on one GPU, gloo)")
+    ap.add_argument("--transport", default="", choices=["", "rccl", "shm"],
+                    help="exchange transport inside libycnr_als.so for N > 1 (default: rccl; shm with --same-device / gloo)")
+    ap.add_argument("--exchange-chunks", type=int, default=4, help="pieces a large side's shard is solved in (exchange overlaps solve)")
     ap.add_argument("--dump-factors", default="", help="write the final factor matrices of rank 0 to this .npz")
     ap.add_argument("--debug-mod-idx", type=int, default=0,
                     help="timing experiment only: fold all column ids into [0, N) so every gather hits L1/L2")
@@ -119,7 +122,9 @@ def main():
     ds = Dataset(by_user, by_item, validate=val, test=None, total_ratings_avg=float(by_user.vals.double().mean()))
     lord = EmfLord(options={"factorsCount": k, "trainIters": args.steps, "useDoublePrecision": args.double,
                             "dbType": "mal" if max_rating == 10 else "ml", "chunkRatings": args.chunk,
-                            "dataSetDistr": [90, 10, 0]}, dist=dist)
+                            "dataSetDistr": [90, 10, 0], "exchangeChunks": args.exchange_chunks,
+                            "commTransport": args.transport or ("shm" if args.same_device or args.backend == "gloo" else "rccl")},
+                    dist=dist)
     lord.prepareToTrain(ds, seed=20260004, device=local_rank)
     t_prep = time.time() - t0 - t_gen
 
@@ -149,81 +154,89 @@ def main():
     # records on its launch stream (ycnr_als_last_step_info)
     s = 8 if args.double else 4
     peak = PEAK_FP64_TFLOPS if args.double else PEAK_FP32_TFLOPS
-    per_rating = k * (k + 1) + 2 * k            # symmetric Gramian + rhs
-    per_row = k ** 3 / 3.0 + 2 * k * k          # Cholesky + two triangular solves
+    gram_rating = k * (k + 1) + 2 * k           # symmetric Gramian + rhs, per rating
+    solve_row = k ** 3 / 3.0 + 2 * k * k        # Cholesky + two triangular solves, per row
     bytes_rating = 4 + s + k * s                # index + value + gathered factor row
+    # Every entry carries the flops its kernels EXECUTE, split by the pipe they run on: Gramian
+    # products of float32 runs go to the bf16 matrix pipe as six bf16 products each (exact 3-way
+    # split; peak 2500 / 6 TFLOP/s float32-equivalent) when the library's conditions hold, everything
+    # else (solves, float64, k > 112 Gramians) to the fp32 / fp64 MFMA peak.  Rows in dual form execute
+    # n x n work (info.dualFlops: n(n+1)k + n^3/3 + 2n^2 + 2nk per row), not the k x k model.
     # kernels are accounted per half-step: the same kernel is a different workload on the two sides
     # (user side: the 5 MB item matrix is cache-resident; item side: 700 MB of user factors are not)
     kern = {}
     step_ms = {"byUser": 0.0, "byItem": 0.0}
+    comm = {sd: {"compute_ms": 0.0, "exchange_ms": 0.0, "exposed_exchange_ms": 0.0, "wall_ms": 0.0, "bytes": 0, "pieces": 0, "n": 0}
+            for sd in ("byUser", "byItem")}
+
+    def x6_of(side):
+        fixed_rows = items if side == "byUser" else users
+        return (not args.double) and k % 4 == 0 and k <= 112 and fixed_rows * k * 4 < 2 ** 31
+
     for st in lord.stepTimes:
         i = st["info"]
         side = st["stepType"]
         step_ms[side] += i.totalMs
+        c = comm[side]
+        c["compute_ms"] += i.totalMs
+        c["exchange_ms"] += i.exchangeMs
+        c["exposed_exchange_ms"] += i.exposedExchangeMs
+        c["wall_ms"] += st["wall"] * 1e3
+        c["bytes"] += i.exchangeBytes
+        c["pieces"] = i.parts
+        c["n"] += 1
+        x6 = x6_of(side)
         chunk_ratings = i.ratings - i.fusedRatings
-        row_fl = (i.fusedRatings - i.dualRatings) * per_rating + (i.fusedRows - i.dualRows) * per_row
-        row_by = (i.fusedRatings - i.dualRatings) * bytes_rating + (i.fusedRows - i.dualRows) * (k * s + 8)
-        # dual-form rows are priced with the same (primal) algorithmic model: work the
-        # reference does for those rows, not the smaller n x n work the kernel executes
-        dual_fl = i.dualRatings * per_rating + i.dualRows * per_row
+        prim_ratings, prim_rows = i.fusedRatings - i.dualRatings, i.fusedRows - i.dualRows
+        # (name, ms, flops on the Gramian pipe, flops on the fp32/fp64 pipe, gather-model bytes)
+        row_k = ("als_gram_solve_kernel", i.gramSolveMs, prim_ratings * gram_rating, prim_rows * solve_row,
+                 prim_ratings * bytes_rating + prim_rows * (k * s + 8))
         dual_by = i.dualRatings * bytes_rating + i.dualRows * (k * s + 8)
+        # (priced on the fp32 pipe as a whole: the library reports one flop count per row class)
+        dual_k = ("als_dual_solve_kernel", i.dualSolveMs, 0.0, i.dualFlops, dual_by)
         if i.dualOverlapped:
             # the dual kernels ran on side streams next to the row kernel: one group, one wall time
-            whole_rows = (("als_gram_solve_kernel+als_dual_solve_kernel", i.gramSolveMs + i.dualSolveMs,
-                           row_fl + dual_fl, row_by + dual_by),)
+            whole_rows = (("als_gram_solve_kernel+als_dual_solve_kernel", row_k[1] + dual_k[1], row_k[2], row_k[3] + dual_k[3],
+                           row_k[4] + dual_by),)
         else:
-            whole_rows = (("als_gram_solve_kernel", i.gramSolveMs, row_fl, row_by),
-                          ("als_dual_solve_kernel", i.dualSolveMs, dual_fl, dual_by))
-        for name, ms, fl, by in whole_rows + (
-                # k > 128: this interval holds als_gram_big + als_solve_big of every batch, so the
+            whole_rows = (row_k, dual_k)
+        for name, ms, fg, fs, by in whole_rows + (
+                # k > 128: this interval holds the Gramian and solve kernels of the 4-wave path, so the
                 # rows' solve work is priced here too
                 ("als_gram_big+als_solve_big" if k > 128 else "als_gram_slab_kernel", i.gramSlabMs,
-                 chunk_ratings * per_rating + (i.splitRows * per_row if k > 128 else 0),
-                 chunk_ratings * bytes_rating),
-                ("als_reduce_solve_kernel", i.reduceSolveMs, 0 if k > 128 else i.splitRows * per_row,
+                 chunk_ratings * gram_rating, (i.splitRows * solve_row if k > 128 else 0), chunk_ratings * bytes_rating),
+                ("als_reduce_solve_kernel", i.reduceSolveMs, 0.0, 0 if k > 128 else i.splitRows * solve_row,
                  i.splitRows * (k * s + 8))):
-            if fl > 0:
-                d = kern.setdefault(f"{name}[{side}]", {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
+            if fg + fs > 0:
+                d = kern.setdefault(f"{name}[{side}]", {"ms": 0.0, "fg": 0.0, "fs": 0.0, "bytes": 0.0, "launches": 0, "x6": x6})
                 d["ms"] += ms
-                d["flops"] += fl
+                d["fg"] += fg
+                d["fs"] += fs
                 d["bytes"] += by
                 d["launches"] += 1
-    # the dominant kernel: the longest entry that is one kernel launch per half-step (what a
-    # rocprofv3 kernel trace can be compared with), unless a group of kernels that share one
-    # interval takes more than twice as long
+    # the dominant entry: the longest one (a kernel, or the group of kernels that share one interval)
     dom = max(kern, key=lambda n: kern[n]["ms"])
-    single = [n for n in kern if "+" not in n]
-    if single and "+" in dom:
-        best = max(single, key=lambda n: kern[n]["ms"])
-        if kern[best]["ms"] >= 0.5 * kern[dom]["ms"]:
-            dom = best
-
-    def peak_of(n):
-        # Gramian kernels of float32 runs use the bf16 pipe (6 products per float32 product) when the
-        # library's conditions hold: k % 4 == 0, k <= 112, fixed matrix of that half-step < 2 GB
-        side = n[n.index("[") + 1:-1]
-        fixed_rows = items if side == "byUser" else users
-        x6 = (not args.double) and k % 4 == 0 and k <= 112 and fixed_rows * k * 4 < 2 ** 31
-        # (the fused row kernel also runs its Gramian there, but more than half of its time is the
-        # float32 solve on the vector pipe: it is priced against the fp32 peak)
-        if x6 and n.startswith("als_gram_slab_kernel"):
-            return PEAK_BF16_TFLOPS / 6.0, "bf16 MFMA peak / 6"
-        return peak, "fp64 MFMA peak" if args.double else "fp32 MFMA peak"
 
     def describe(n):
         d = kern[n]
         t = d["ms"] * 1e-3
-        tf = d["flops"] / t / 1e12 if t > 0 else 0.0
+        pg = PEAK_BF16_TFLOPS / 6.0 if d["x6"] else peak
+        fl = d["fg"] + d["fs"]
+        tf = fl / t / 1e12 if t > 0 else 0.0
         gb = d["bytes"] / t / 1e9 if t > 0 else 0.0
-        pk, pk_name = peak_of(n)
+        t_min = d["fg"] / (pg * 1e12) + d["fs"] / (peak * 1e12)   # every flop at the peak of its pipe
+        pk = fl / t_min / 1e12 if t_min > 0 else peak
         return {"kernel": n, "launches": d["launches"], "avg_launch_ms": round(d["ms"] / max(d["launches"], 1), 4),
-                "achieved_TFLOPs": round(tf, 3), "mfma_peak_TFLOPs": round(pk, 1), "mfma_peak": pk_name,
-                "mfma_frac": round(tf / pk, 4),
+                "achieved_TFLOPs": round(tf, 3), "mfma_peak_TFLOPs": round(pk, 1),
+                "mfma_peak": ("blend of bf16 MFMA peak / 6 (Gramian products) and " if d["x6"] and d["fg"] > 0 else "")
+                + ("fp64 MFMA peak" if args.double else "fp32 MFMA peak") + (" (solves)" if d["x6"] and d["fg"] > 0 else ""),
+                "gramian_flops": d["fg"], "other_flops": d["fs"],
+                "mfma_frac": round(t_min / t, 4) if t > 0 else 0.0,
                 "algorithmic_GBs": round(gb, 1), "hbm_frac": round(gb / PEAK_HBM_GBS, 4)}
 
     dd = describe(dom)
     tot_ms = sum(d["ms"] for d in kern.values())
-    tot_fl = sum(d["flops"] for d in kern.values())
+    tot_fl = sum(d["fg"] + d["fs"] for d in kern.values())
     tot_by = sum(d["bytes"] for d in kern.values())
     # measured L2-miss traffic of this workload's kernels, when a PMC pass of this command has been
     # aggregated (rocprofv3 cannot run inside the timed bench): profiles/traffic.json
@@ -235,7 +248,7 @@ def main():
             traffic = tj.get("workloads", {}).get(args.workload + ("_f64" if args.double else ""), {})
         except (OSError, ValueError):
             traffic = {}
-    # the roof that binds the dominant kernel: the one it is closer to.  The memory side is judged
+    # the roof that binds the dominant entry: the one it is closer to.  The memory side is judged
     # by the measured traffic when there is one (the gather model counts every gathered row as a
     # DRAM read; on the user side the fixed matrix lives in L2)
     mem_frac = dd["hbm_frac"]
@@ -249,13 +262,15 @@ def main():
         "frac": dd["hbm_frac"] if hbm_bound else dd["mfma_frac"],
         "traffic": None, "launches": dd["launches"], "avg_launch_ms": dd["avg_launch_ms"],
         "bytes_model": "per rating: 4 (column id) + s (rating) + k s (gathered factor row); per solved row: k s + 8; s = sizeof(T)",
-        "flops_model": "k(k+1)+2k per rating + k^3/3+2k^2 per solved row (symmetric Gramian + Cholesky); "
-                       "each kernel against the matrix-core peak of the pipe its Gramian uses (mfma_peak)",
+        "flops_model": "executed flops: k(k+1)+2k per rating + k^3/3+2k^2 per row solved in primal form, n(n+1)k + n^3/3 + 2n^2 + 2nk per row "
+                       "solved in dual form (n ratings < k); each part against the peak of the pipe it runs on (mfma_peak)",
         "kernels": [describe(n) for n in kern if kern[n]["launches"]],
-        # all kernels of the iteration together, against both roofs (gather-model bytes for HBM)
+        # all kernels of the iteration together: executed flops against the fp32 (fp64) MFMA peak, gather-model bytes against HBM
         "iteration": {"kernel_ms_per_step": round(tot_ms / args.steps, 3),
-                      "mfma_frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / peak, 4) if tot_ms else 0.0,  # against the fp32 (fp64) MFMA peak
+                      "mfma_frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / peak, 4) if tot_ms else 0.0,
                       "hbm_frac": round(tot_by / (tot_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if tot_ms else 0.0,
+                      "hbm_roof_ratings_per_s": round(PEAK_HBM_GBS * 1e9 / (2 * bytes_rating)),
+                      "frac_of_hbm_roof_ratings_per_s": round(value / world / (PEAK_HBM_GBS * 1e9 / (2 * bytes_rating)), 4),
                       "byUser_ms": round(step_ms["byUser"] / args.steps, 3),
                       "byItem_ms": round(step_ms["byItem"] / args.steps, 3)},
     }
@@ -264,6 +279,21 @@ def main():
         roofline["traffic_source"] = tj.get("sources", {}).get(args.workload + ("_f64" if args.double else ""), "profiles/traffic.json")
         roofline["traffic_over_algorithmic"] = round(traffic[dom]["hbm_bytes_per_launch"] / (kern[dom]["bytes"] / kern[dom]["launches"]), 3)
         roofline["traffic_frac_of_hbm_peak"] = round(mem_frac, 4)
+
+    # where a multi-GPU iteration goes, per half-step and averaged over the timed steps (this rank;
+    # compute_ms of every rank is gathered so that a straggler shows)
+    exchange = {"path": getattr(lord, "exchangePath", "none")}
+    for sd in ("byUser", "byItem"):
+        c = comm[sd]
+        n = max(c["n"], 1)
+        exchange[sd] = {"compute_ms": round(c["compute_ms"] / n, 4), "exchange_ms": round(c["exchange_ms"] / n, 4),
+                        "exposed_exchange_ms": round(c["exposed_exchange_ms"] / n, 4), "wall_ms": round(c["wall_ms"] / n, 4),
+                        "bytes": int(c["bytes"] // n), "pieces": c["pieces"]}
+    if dist:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, {sd: exchange[sd]["compute_ms"] for sd in ("byUser", "byItem")})
+        for sd in ("byUser", "byItem"):
+            exchange[sd]["compute_ms_by_rank"] = [r[sd] for r in per_rank]
 
     rmse = lord.calcRmse("rmseValidate", False)
     if args.dump_factors and rank == 0:
@@ -280,9 +310,9 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64" if args.double else "f32", "data": "synthetic",
             "config": {"workload": desc, "users": users, "items": items, "nnz": nnz, "factorsCount": k,
-                       "lambda": 0.05, "parallelism": f"row-shard x{world} + all-gather" if world > 1 else "1 GPU"},
+                       "lambda": 0.05, "parallelism": f"row-shard x{world} + direct all-gather ({lord.exchangePath})" if world > 1 else "1 GPU"},
             "rmse_in_sample_after_iters": rmse, "iters_run": args.steps + args.warmup,
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "exchange": exchange, "cpu_baseline": cpu,
             "setup_s": {"generate": round(t_gen, 2), "prepare": round(t_prep, 2)},
         }
         print(json.dumps(out), flush=True)

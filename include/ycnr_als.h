@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define YCNR_ALS_ABI_VERSION 1
+#define YCNR_ALS_ABI_VERSION 2
 
 /* error codes */
 #define YCNR_OK 0
@@ -160,6 +160,14 @@ typedef struct ycnr_als_step_info {
                            * (see YCNR_FLAG_NO_OVERLAP): gramSolveMs is the time until that kernel
                            * ended, dualSolveMs what the dual kernels still needed after it; only
                            * their sum is the time of a kernel group */
+  /* multi-GPU (ycnr_als_comm_init + ycnr_als_set_ratings_sharded); the kernel times above are sums
+   * over the pieces of the local shard, totalMs spans the first kernel start to the last kernel end */
+  int32_t parts;           /* pieces the local shard was solved in (exchange of piece c overlaps the solve of c + 1) */
+  int32_t reserved0;
+  int64_t exchangeBytes;   /* bytes this rank sent + received in the half-step's exchange */
+  float exchangeMs;        /* sum of the exchanges' durations on the communicator's stream */
+  float exposedExchangeMs; /* what the step still waited for after its own last kernel had ended */
+  double dualFlops;        /* flops the dual form executes for the dualRows: n(n+1)k + n^3/3 + 2n^2 + 2nk per row */
 } ycnr_als_step_info;
 
 int ycnr_als_create(const ycnr_als_options *opts, ycnr_als **out);
@@ -210,6 +218,56 @@ int ycnr_als_step(ycnr_als *h, int side);
 int ycnr_als_step_async(ycnr_als *h, int side);
 int ycnr_als_sync(ycnr_als *h);
 int ycnr_als_last_step_info(ycnr_als *h, ycnr_als_step_info *info);
+
+/* ---- multi-GPU: row shards + exchange -------------------------------------------
+ *
+ * One process drives one GPU.  Both factor matrices are replicated on every GPU; each rank solves a
+ * contiguous range of rows of the side being solved and every rank's replica is brought up to date
+ * before the next half-step.  This replaces the reference's cluster path:
+ *   'alsSaveCalcedFactors' -- after each portion the solved rows are streamed to every other node
+ *       (EmfMaster.wm_completedPortion, lib/emf/EmfMaster.js:711-723; receivers EmfLord.js:727-732,
+ *       EmfChief.js:207-212)                                    -> the exchange inside ycnr_als_step
+ *   getFactors / setFactors when a node joins (EmfChief.loadFactorsFromLord, EmfChief.js:55-71,
+ *       EmfLord.js:738-740)                                     -> ycnr_als_broadcast_factors
+ *   'rmseSaveCalcs' partial sums to the Lord (EmfMaster.js:726-736, EmfLord.js:734-736)
+ *                                                               -> ycnr_als_allreduce_sum
+ * Transports: YCNR_COMM_RCCL is the product path -- one group of point-to-point ncclSend / ncclRecv
+ * between all pairs of ranks straight into the replicated matrix at each shard's row offset (xGMI
+ * is a point-to-point mesh: every link carries only what its two ends owe each other, all links at
+ * once; uneven shards need no padding or staging).  YCNR_COMM_SHM is a functional stand-in for
+ * tests (what gloo is to nccl): ranks of one node stage rows through POSIX shared memory, so that
+ * several ranks can share one GPU, which RCCL refuses.
+ *
+ * ycnr_comm_unique_id: 128 bytes created by ONE rank and handed to all ranks by the host's own
+ * control plane (the NodeJS Lord's process.send, torch.distributed's store ...), cf. ncclGetUniqueId.
+ * ycnr_als_comm_init is collective: every rank calls it with the same id. */
+#define YCNR_COMM_NONE 0
+#define YCNR_COMM_RCCL 1
+#define YCNR_COMM_SHM 2
+#define YCNR_COMM_ID_BYTES 128
+int ycnr_comm_unique_id(int transport, void *id128);
+int ycnr_als_comm_init(ycnr_als *h, int transport, const void *id128, int rank, int world);
+int ycnr_als_comm_destroy(ycnr_als *h);
+/* Sharded upload of one side for all ranks of the communicator (world = 1 without one):
+ *   bounds   int64[world * (nChunks + 1)], ascending; rank r solves rows [bounds[r (nChunks+1)],
+ *            bounds[r (nChunks+1) + nChunks]) in nChunks pieces cut at the values in between; the
+ *            shards tile the side's rows in rank order.  The host chooses the cuts (cost-balanced:
+ *            the counterpart of EmfLord.splitToPortions, lib/emf/EmfLord.js:510-612).
+ * rowPtr / indx / vals describe the WHOLE side (only this rank's slice is copied to the device).
+ * After this call ycnr_als_step(side) includes the exchange: piece c's rows travel while piece
+ * c + 1 is being solved, and the step returns when every replica holds every solved row -- the
+ * meaning of 'stepComplete' in the reference's cluster (EmfLord.alsTrainStep, EmfLord.js:963-984). */
+int ycnr_als_set_ratings_sharded(ycnr_als *h, int side, const int64_t *rowPtr, const int32_t *indx, const void *vals,
+                                 int memKind, int nChunks, const int64_t *bounds);
+/* The exchange alone, whole shards, synchronous (e.g. after ycnr_als_set_factors of local rows). */
+int ycnr_als_exchange(ycnr_als *h, int side);
+/* root's whole matrix to every rank. */
+int ycnr_als_broadcast_factors(ycnr_als *h, int side, int root);
+/* vals[i] <- sum over ranks (host doubles; the RMSE partials {rSumDiff2, rCnt, rSum} per portion). */
+int ycnr_als_allreduce_sum(ycnr_als *h, double *vals, int64_t n);
+/* A self-addressed ncclSend / ncclRecv pair of nFloats floats and a 3-value all-reduce through the
+ * handle's communicator; YCNR_ERR_STATE if the bytes or sums come back wrong. */
+int ycnr_als_comm_selftest(ycnr_als *h, int64_t nFloats);
 
 /* RMSE partial sums = EmfLord.calcRmse / EmfWorker.mw_calcRmsePortion
  * (lib/emf/EmfLord.js:1043-1081, EmfWorker.js:266-315) over the local rows of set `which`:

@@ -29,12 +29,12 @@ def test_library_exports_every_declared_symbol():
     L = _lib.load()
     for name in declared_functions():
         assert hasattr(L, name), f"{name} is declared in include/ycnr_als.h but not exported"
-    assert L.ycnr_version() == 1
+    assert L.ycnr_version() == 2
 
 
 def test_struct_layouts_match_header():
     assert C.sizeof(_lib.Options) == 56
-    assert C.sizeof(_lib.StepInfo) == 104
+    assert C.sizeof(_lib.StepInfo) == 136
     src = open(HEADER).read()
     for field, _ in _lib.Options._fields_:
         assert re.search(r"\b%s;" % field, src), field

@@ -1,0 +1,165 @@
+"""The exchange step of the multi-GPU path (include/ycnr_als.h "multi-GPU") on one MI355X.
+
+One GPU cannot show scaling, but it can show that the code the 8-GPU run depends on works:
+  * the RCCL transport: communicator creation from a unique id, a self-addressed ncclSend / ncclRecv
+    pair and an all-reduce run on hardware (world size 1), and train() end to end under
+    torch.distributed's nccl backend;
+  * the sharded, pipelined half-step: pieces + exchange ranges give bit-identical factors;
+  * the shared-memory stand-in (several ranks on one GPU): exchange, broadcast and all-reduce between
+    real processes, against the single-process result bit for bit.
+"""
+import multiprocessing as mp
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from helpers import make_problem
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def als():
+    import ycnr_als
+    L = ycnr_als._lib.load()
+    assert L.ycnr_device_count() >= 1, L.ycnr_last_error()
+    return ycnr_als
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def problem(k=36, users=900, items=400, seed=3):
+    bu, bi, U, V = make_problem(users, items, k, density=0.08, seed=seed, empty_rows=(5, 17))
+    return k, users, items, bu, bi, U, V
+
+
+def reference_iteration(als, k, users, items, bu, bi, U, V):
+    dev = als.AlsDevice(k, users, items)
+    dev.set_ratings("byUser", bu.rowPtr, bu.indx, bu.vals)
+    dev.set_ratings("byItem", bi.rowPtr, bi.indx, bi.vals)
+    dev.set_factors("byUser", U)
+    dev.set_factors("byItem", V)
+    dev.step("byUser")
+    dev.step("byItem")
+    out = dev.get_factors("byUser"), dev.get_factors("byItem")
+    dev.destroy()
+    return out
+
+
+def test_rccl_communicator_runs_on_hardware(als):
+    """World size 1 over RCCL: unique id, ncclCommInitRank, grouped ncclSend + ncclRecv (to self),
+    ncclAllReduce; then a half-step cut into 3 pieces with exchange ranges = the unsharded result."""
+    k, users, items, bu, bi, U, V = problem()
+    U1, V1 = reference_iteration(als, k, users, items, bu, bi, U, V)
+    dev = als.AlsDevice(k, users, items)
+    uid = als.AlsDevice.comm_unique_id("rccl")
+    assert len(uid) == 128 and any(uid)
+    dev.comm_init(uid, 0, 1, "rccl")
+    dev.comm_selftest(1 << 18)
+    with pytest.raises(als.YcnrError):  # one communicator per handle
+        dev.comm_init(uid, 0, 1, "rccl")
+    ub = np.array([[0, 300, 610, users]], np.int64)
+    ib = np.array([[0, items]], np.int64)
+    dev.set_ratings_sharded("byUser", bu.rowPtr, bu.indx, bu.vals, ub)
+    dev.set_ratings_sharded("byItem", bi.rowPtr, bi.indx, bi.vals, ib)
+    dev.set_factors("byUser", U)
+    dev.set_factors("byItem", V)
+    iu = dev.step("byUser")
+    ii = dev.step("byItem")
+    assert iu.parts == 3 and ii.parts == 1 and iu.ratings == bu.nnz and iu.rows == users - 2
+    assert np.array_equal(dev.get_factors("byUser"), U1) and np.array_equal(dev.get_factors("byItem"), V1)
+    s = dev.allreduce_sum(np.array([1.5, -2.0]))
+    assert np.array_equal(s, [1.5, -2.0])
+    dev.exchange("byUser")
+    dev.broadcast_factors("byItem", 0)
+    with pytest.raises(als.YcnrError):  # shards must tile the rows in rank order
+        dev.set_ratings_sharded("byUser", bu.rowPtr, bu.indx, bu.vals, np.array([[0, 500, 400, users]], np.int64))
+    dev.comm_destroy()
+    dev.destroy()
+
+
+def _nccl_train(port, out):
+    import torch
+    import torch.distributed as dist
+    from ycnr_als.data import select_csr, split_to_sets, synth_ratings, transpose_csr
+    from ycnr_als.emf import Dataset, EmfLord
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    by_user, _ = synth_ratings(600, 400, 30_000, max_rating=5, seed=11, degree_sigma=0.9, zipf_a=0.8)
+    t = split_to_sets(by_user, (85, 10, 5), seed=3)
+    tr = select_csr(by_user, t <= 2)
+    ds = Dataset(tr, transpose_csr(tr), select_csr(by_user, t == 2), select_csr(by_user, t == 3))
+    res = []
+    for d in (dist, None):
+        lord = EmfLord(options={"factorsCount": 20, "trainIters": 3, "dataDir": "/tmp/ycnr_test_nccl1"}, dist=d)
+        lord.prepareToTrain(ds, seed=7)
+        hist = lord.train()
+        res.append((hist, lord.backend.get_factors(0), lord.backend.get_factors(1), lord.getCalcInfo()["globalAvgShift"]))
+        lord.destroy()
+    dist.destroy_process_group()
+    (h1, U1, V1, s1), (h2, U2, V2, s2) = res
+    ok = np.array_equal(U1, U2) and np.array_equal(V1, V2) and h1 == h2 and s1 == s2
+    out.put(bool(ok))
+
+
+def test_train_under_the_nccl_backend(als):
+    """train() -- half-steps, the three RMSE passes and globalAvgShift -- with torch.distributed's nccl
+    backend initialised (world size 1) gives the results of the plain single-process run."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_train, args=(free_port(), q))
+    p.start()
+    p.join(600)
+    assert p.exitcode == 0, "the nccl process failed"
+    assert q.get(timeout=5) is True
+
+
+def _shm_rank(rank, world, uid, pieces, out):
+    import ycnr_als as als
+    k, users, items, bu, bi, U, V = problem()
+    dev = als.AlsDevice(k, users, items)
+    dev.comm_init(uid, rank, world, "shm")
+    dev.comm_selftest(1024)
+    cut = lambda n, parts: np.linspace(0, n, parts + 1).astype(np.int64)
+    us, its = cut(users, world), cut(items, world)
+    ub = np.stack([us[r] + cut(us[r + 1] - us[r], pieces) for r in range(world)])
+    ib = np.stack([its[r] + cut(its[r + 1] - its[r], 1) for r in range(world)])
+    dev.set_ratings_sharded("byUser", bu.rowPtr, bu.indx, bu.vals, ub)
+    dev.set_ratings_sharded("byItem", bi.rowPtr, bi.indx, bi.vals, ib)
+    dev.set_factors("byUser", U)
+    # only rank 1 holds the item factors at first: the join-time copy (EmfChief.js:55-71)
+    dev.set_factors("byItem", V if rank == 1 else np.zeros_like(V))
+    dev.broadcast_factors("byItem", 1)
+    iu = dev.step("byUser")
+    ii = dev.step("byItem")
+    s = dev.allreduce_sum(np.array([float(rank + 1), float(iu.ratings)]))
+    got = dev.get_factors("byUser"), dev.get_factors("byItem")
+    dev.destroy()
+    out.put((rank, got, s.tolist(), int(iu.parts), int(iu.exchangeBytes), int(ii.exchangeBytes)))
+
+
+@pytest.mark.parametrize("world,pieces", [(2, 1), (3, 4)])
+def test_shared_memory_ranks_on_one_gpu(als, world, pieces):
+    k, users, items, bu, bi, U, V = problem()
+    U1, V1 = reference_iteration(als, k, users, items, bu, bi, U, V)
+    uid = als.AlsDevice.comm_unique_id("shm")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_shm_rank, args=(r, world, uid, pieces, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, (Ug, Vg), s, parts, xu, xi in res:
+        assert np.array_equal(Ug, U1) and np.array_equal(Vg, V1), f"rank {rank}: replicas differ from the single-process run"
+        assert s == [world * (world + 1) / 2, float(bu.nnz)]
+        assert parts == pieces and xu > 0 and xi > 0

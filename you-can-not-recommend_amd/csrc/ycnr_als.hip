@@ -15,6 +15,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -85,6 +86,7 @@ struct Schedule {
   // whole-row units: [nSlabs, nSlabs + nPrimal) primal form, then dual classes m = kMaxDualBlocks..1
   int64_t nPrimal = 0, dualFirst[kMaxDualBlocks + 1] = {}, dualCount[kMaxDualBlocks + 1] = {};
   int64_t dualRows = 0, dualRatings = 0;
+  double dualFlops = 0;  // flops the dual form executes for those rows: G = Y Y^T (symmetric), Cholesky, x = Y^T w
   // big path (k > 128): consecutive rows whose slabs fit the arena together
   struct Batch {
     int64_t unitFirst, unitCount, splitFirst, splitCount;
@@ -99,6 +101,7 @@ struct Schedule {
     dSplit = nullptr;
     dSlabs = nullptr;
     nUnits = nSplit = nSlabs = solvedRows = fusedRatings = nPrimal = dualRows = dualRatings = 0;
+    dualFlops = 0;
     for (int m = 0; m <= kMaxDualBlocks; ++m) dualFirst[m] = dualCount[m] = 0;
   }
 };
@@ -515,26 +518,58 @@ int check_index_range(const int32_t *dIndx, int64_t n, int64_t limit, hipStream_
   return YCNR_OK;
 }
 
+#include "comm_impl.hip.h"
+
+// one pipelined piece of a side's row shard: its ratings, its work-unit schedule and the events
+// that time its kernels and its exchange
+struct Part {
+  Ratings R;
+  Schedule S;
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ready = nullptr, x0 = nullptr, x1 = nullptr;
+  hipError_t create_events() {
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 5 && e == hipSuccess; ++i) e = hipEventCreate(&ev[i]);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ready, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreate(&x0);
+    if (e == hipSuccess) e = hipEventCreate(&x1);
+    return e;
+  }
+  void release() {
+    R.release();
+    S.release();
+    for (int i = 0; i < 5; ++i)
+      if (ev[i]) (void)hipEventDestroy(ev[i]);
+    if (ready) (void)hipEventDestroy(ready);
+    if (x0) (void)hipEventDestroy(x0);
+    if (x1) (void)hipEventDestroy(x1);
+    for (int i = 0; i < 5; ++i) ev[i] = nullptr;
+    ready = x0 = x1 = nullptr;
+  }
+};
+
 }  // namespace
 
 struct ycnr_als {
   ycnr_als_options opt{};
   hipStream_t ownStream = nullptr;
   hipStream_t stream = nullptr;
-  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   hipStream_t sideStream[kSideStreams] = {};  // dual classes next to the row kernel (DualPlan)
   hipEvent_t evFork = nullptr, evJoin[kSideStreams] = {};
   void *factors[2] = {nullptr, nullptr};
   bool ownFactors[2] = {false, false};
   bool autoChunk = false;  // options.chunkRatings was 0: sized per upload (auto_chunk)
-  Ratings ratings[2];
-  Schedule sched[2];
+  std::vector<Part> parts[2];      // the side's local row shard, cut into pipelined pieces (usually one)
+  std::vector<int64_t> bounds[2];   // sharded upload: row bounds of every rank's pieces, world x (nParts + 1)
+  Comm comm;                        // exchange step of the multi-GPU path (comm_impl.hip.h)
+  hipEvent_t evComputeEnd = nullptr;
+  bool exchangedInStep = false;
   Ratings rmse[2];
   ErrInfo *dErr = nullptr;
   void *dZeros = nullptr;  // the zero "factor row" read for ratings past a unit's end
   ycnr_als_step_info info{};
   bool infoPending = false;
-  bool infoHasSplit = false;
+  int infoSide = 0;
 
   int64_t rows(int side) const { return side == YCNR_BY_USER ? opt.totalUsersCount : opt.totalItemsCount; }
   size_t ts() const { return tsize(opt.dtype); }
@@ -909,7 +944,7 @@ int ycnr_als_create(const ycnr_als_options *o, ycnr_als **out) {
   if (h->opt.chunkRatings == 0) h->opt.chunkRatings = kDefaultChunk;
   h->opt.chunkRatings = (h->opt.chunkRatings + 3) & ~3;
   hipError_t e = hipStreamCreateWithFlags(&h->ownStream, hipStreamNonBlocking);
-  for (int i = 0; i < 5 && e == hipSuccess; ++i) e = hipEventCreate(&h->ev[i]);
+  if (e == hipSuccess) e = hipEventCreate(&h->evComputeEnd);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->evFork, hipEventDisableTiming);
   for (int i = 0; i < kSideStreams && e == hipSuccess; ++i) {
     e = hipStreamCreateWithFlags(&h->sideStream[i], hipStreamNonBlocking);
@@ -942,16 +977,16 @@ int ycnr_als_destroy(ycnr_als *h) {
   if (!h) return YCNR_OK;
   (void)hipSetDevice(h->opt.device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  comm_release(h->comm);
   for (int s = 0; s < 2; ++s) {
-    h->ratings[s].release();
-    h->sched[s].release();
+    for (Part &p : h->parts[s]) p.release();
+    h->parts[s].clear();
     h->rmse[s].release();
     if (h->ownFactors[s] && h->factors[s]) (void)hipFree(h->factors[s]);
   }
   if (h->dErr) (void)hipFree(h->dErr);
   if (h->dZeros) (void)hipFree(h->dZeros);
-  for (int i = 0; i < 5; ++i)
-    if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+  if (h->evComputeEnd) (void)hipEventDestroy(h->evComputeEnd);
   if (h->evFork) (void)hipEventDestroy(h->evFork);
   for (int i = 0; i < kSideStreams; ++i) {
     if (h->sideStream[i]) {
@@ -1017,25 +1052,11 @@ static int upload_ratings(ycnr_als *h, Ratings &R, int64_t totalRows, int64_t op
   return YCNR_OK;
 }
 
-int ycnr_als_set_ratings(ycnr_als *h, int side, const int64_t *rowPtr, const int32_t *indx, const void *vals,
-                         int64_t rowBegin, int64_t rowEnd, int memKind) {
-  if (!h) return fail(YCNR_ERR_INVALID, "null handle");
-  if (side != YCNR_BY_USER && side != YCNR_BY_ITEM) return fail(YCNR_ERR_INVALID, "bad side %d", side);
+// Upload + schedule of one piece [rowBegin, rowEnd) of a side's rows into newR / S (both released
+// by the caller when this fails).
+static int build_part(ycnr_als *h, int side, const int64_t *rowPtr, const int32_t *indx, const void *vals, int64_t rowBegin,
+                      int64_t rowEnd, int memKind, Ratings &newR, Schedule &S) {
   std::vector<int64_t> hp;
-  // ratings and schedule are built in locals and committed together at the end: a failure on the
-  // way leaves the handle's previous upload (or none) intact, never new ratings with an old schedule
-  struct Pending {
-    Ratings R;
-    Schedule S;
-    bool keep = false;
-    ~Pending() {
-      if (!keep) {
-        R.release();
-        S.release();
-      }
-    }
-  } pend;
-  Ratings &newR = pend.R;
   int rc = upload_ratings(h, newR, h->rows(side), h->rows(1 - side), rowPtr, indx, vals, rowBegin,
                           rowEnd, memKind, hp, side == YCNR_BY_USER ? "set_ratings(byUser)" : "set_ratings(byItem)");
   if (rc) return rc;
@@ -1152,7 +1173,6 @@ int ycnr_als_set_ratings(ycnr_als *h, int side, const int64_t *rowPtr, const int
       arenaSlabs = slabs;
     }
   }
-  Schedule &S = pend.S;
   S.nUnits = (int64_t)units.size();
   S.nSplit = (int64_t)split.size();
   S.nSlabs = nSlabs;
@@ -1175,6 +1195,8 @@ int ycnr_als_set_ratings(ycnr_als *h, int side, const int64_t *rowPtr, const int
     ++S.dualCount[m];
     ++S.dualRows;
     S.dualRatings += n;
+    const double nd = (double)n, kd = (double)h->opt.factorsCount;
+    S.dualFlops += nd * (nd + 1) * kd + nd * nd * nd / 3.0 + 2.0 * nd * nd + 2.0 * nd * kd;
   }
   if (S.nUnits) {
     HIP_TRY(hipMalloc(&S.dUnits, sizeof(Unit) * units.size()));
@@ -1185,12 +1207,68 @@ int ycnr_als_set_ratings(ycnr_als *h, int side, const int64_t *rowPtr, const int
     HIP_TRY(hipMemcpy(S.dSplit, split.data(), sizeof(SplitRow) * split.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc(&S.dSlabs, (size_t)arenaSlabs * slab_regs(h->opt, side) * 64 * h->ts()));
   }
+  return YCNR_OK;
+}
+
+// nParts pieces [b[i], b[i + 1]) of this rank's rows.  Everything is built in locals and committed
+// together at the end: a failure on the way leaves the handle's previous upload (or none) intact,
+// never new ratings with an old schedule.
+static int set_ratings_parts(ycnr_als *h, int side, const int64_t *rowPtr, const int32_t *indx, const void *vals, int memKind,
+                             int nParts, const int64_t *b) {
+  struct Pending {
+    std::vector<Part> parts;
+    bool keep = false;
+    ~Pending() {
+      if (!keep)
+        for (Part &p : parts) p.release();
+    }
+  } pend;
+  pend.parts.resize((size_t)nParts);
+  for (int i = 0; i < nParts; ++i) {
+    Part &p = pend.parts[(size_t)i];
+    hipError_t e = p.create_events();
+    if (e != hipSuccess) return fail(YCNR_ERR_HIP, "set_ratings: hipEventCreate: %s", hipGetErrorString(e));
+    int rc = build_part(h, side, rowPtr, indx, vals, b[i], b[i + 1], memKind, p.R, p.S);
+    if (rc) return rc;
+  }
   HIP_TRY(hipStreamSynchronize(h->stream));  // nothing in flight still reads the previous upload
-  h->ratings[side].release();
-  h->sched[side].release();
-  h->ratings[side] = pend.R;
-  h->sched[side] = pend.S;
+  for (Part &p : h->parts[side]) p.release();
+  h->parts[side].swap(pend.parts);
+  pend.parts.clear();
   pend.keep = true;
+  return YCNR_OK;
+}
+
+int ycnr_als_set_ratings(ycnr_als *h, int side, const int64_t *rowPtr, const int32_t *indx, const void *vals,
+                         int64_t rowBegin, int64_t rowEnd, int memKind) {
+  if (!h) return fail(YCNR_ERR_INVALID, "null handle");
+  if (side != YCNR_BY_USER && side != YCNR_BY_ITEM) return fail(YCNR_ERR_INVALID, "bad side %d", side);
+  const int64_t b[2] = {rowBegin, rowEnd};
+  int rc = set_ratings_parts(h, side, rowPtr, indx, vals, memKind, 1, b);
+  if (rc) return rc;
+  h->bounds[side].clear();  // no exchange ranges: a plain shard (or the whole matrix)
+  return YCNR_OK;
+}
+
+int ycnr_als_set_ratings_sharded(ycnr_als *h, int side, const int64_t *rowPtr, const int32_t *indx, const void *vals, int memKind,
+                                 int nChunks, const int64_t *bounds) {
+  if (!h || !bounds) return fail(YCNR_ERR_INVALID, "null argument");
+  if (side != YCNR_BY_USER && side != YCNR_BY_ITEM) return fail(YCNR_ERR_INVALID, "bad side %d", side);
+  if (nChunks < 1 || nChunks > 64) return fail(YCNR_ERR_INVALID, "set_ratings_sharded: nChunks %d outside [1, 64]", nChunks);
+  const int world = h->comm.world, rank = h->comm.rank;
+  const size_t n = (size_t)world * (size_t)(nChunks + 1);
+  int64_t prev = 0;
+  for (size_t i = 0; i < n; ++i) {
+    if (bounds[i] < prev || bounds[i] > h->rows(side))
+      return fail(YCNR_ERR_INVALID, "set_ratings_sharded: bounds must ascend within [0, %lld]", (long long)h->rows(side));
+    prev = bounds[i];
+  }
+  for (int r = 0; r + 1 < world; ++r)
+    if (bounds[(size_t)r * (nChunks + 1) + nChunks] != bounds[(size_t)(r + 1) * (nChunks + 1)])
+      return fail(YCNR_ERR_INVALID, "set_ratings_sharded: the shards of ranks %d and %d do not meet", r, r + 1);
+  int rc = set_ratings_parts(h, side, rowPtr, indx, vals, memKind, nChunks, bounds + (size_t)rank * (nChunks + 1));
+  if (rc) return rc;
+  h->bounds[side].assign(bounds, bounds + n);
   return YCNR_OK;
 }
 
@@ -1262,16 +1340,11 @@ int ycnr_als_bind_factors(ycnr_als *h, int side, void *p) {
   return YCNR_OK;
 }
 
-int ycnr_als_step_async(ycnr_als *h, int side) {
-  if (!h) return fail(YCNR_ERR_INVALID, "null handle");
-  if (side != YCNR_BY_USER && side != YCNR_BY_ITEM) return fail(YCNR_ERR_INVALID, "bad side %d", side);
-  if (!h->ratings[side].loaded) return fail(YCNR_ERR_STATE, "step: set_ratings was not called for this side");
-  HIP_TRY(hipSetDevice(h->opt.device));
-  const Ratings &R = h->ratings[side];
-  const Schedule &S = h->sched[side];
-  HIP_TRY(hipMemsetAsync(h->dErr, 0, sizeof(ErrInfo), h->stream));
+// kernels of one piece of the shard, on the handle's stream, timed by the piece's events
+static int launch_part(ycnr_als *h, int side, Part &part) {
+  const Ratings &R = part.R;
+  const Schedule &S = part.S;
   const double lambda = side == YCNR_BY_USER ? h->opt.userFactReg : h->opt.itemFactReg;
-  int rc;
   if (h->opt.dtype == YCNR_F32) {
     StepArgs<float> a{S.dUnits, S.dSplit, R.dIndx, (const float *)R.dVals, (const float *)h->factors[1 - side],
                       (const float *)h->dZeros, (float *)h->factors[side], (float *)S.dSlabs, h->dErr, lambda, h->opt.factorsCount, 0, 0,
@@ -1293,34 +1366,77 @@ int ycnr_als_step_async(ycnr_als *h, int side) {
         }
       }
     }
-    if (h->opt.factorsCount > kMaxFactors)
-      rc = launch_step_big(a, S.batches, h->stream, h->ev, dp);
-    else
-      rc = launch_step<float>(a, S.nUnits, S.nSlabs, S.nSplit, h->stream, h->ev, (h->opt.flags & YCNR_FLAG_LDS_SOLVER) != 0, dp,
+    if (h->opt.factorsCount > kMaxFactors) return launch_step_big(a, S.batches, h->stream, part.ev, dp);
+    return launch_step<float>(a, S.nUnits, S.nSlabs, S.nSplit, h->stream, part.ev, (h->opt.flags & YCNR_FLAG_LDS_SOLVER) != 0, dp,
                               use_valu_edge(h->opt), use_slab_x6(h->opt, side));
-  } else {
-    StepArgs<double> a{S.dUnits, S.dSplit, R.dIndx, (const double *)R.dVals, (const double *)h->factors[1 - side],
-                       (const double *)h->dZeros, (double *)h->factors[side], (double *)S.dSlabs, h->dErr, lambda, h->opt.factorsCount, 0, 0, 0u};
-    rc = launch_step<double>(a, S.nUnits, S.nSlabs, S.nSplit, h->stream, h->ev, (h->opt.flags & YCNR_FLAG_LDS_SOLVER) != 0);
   }
-  if (rc) return rc;
+  StepArgs<double> a{S.dUnits, S.dSplit, R.dIndx, (const double *)R.dVals, (const double *)h->factors[1 - side],
+                     (const double *)h->dZeros, (double *)h->factors[side], (double *)S.dSlabs, h->dErr, lambda, h->opt.factorsCount, 0, 0, 0u};
+  return launch_step<double>(a, S.nUnits, S.nSlabs, S.nSplit, h->stream, part.ev, (h->opt.flags & YCNR_FLAG_LDS_SOLVER) != 0);
+}
+
+// row ranges of piece c of every rank (sharded upload)
+static void part_ranges(const ycnr_als *h, int side, int c, std::vector<int64_t> &begin, std::vector<int64_t> &end) {
+  const int world = h->comm.world, np = (int)h->parts[side].size();
+  begin.resize((size_t)world);
+  end.resize((size_t)world);
+  for (int r = 0; r < world; ++r) {
+    begin[(size_t)r] = h->bounds[side][(size_t)r * (np + 1) + c];
+    end[(size_t)r] = h->bounds[side][(size_t)r * (np + 1) + c + 1];
+  }
+}
+
+int ycnr_als_step_async(ycnr_als *h, int side) {
+  if (!h) return fail(YCNR_ERR_INVALID, "null handle");
+  if (side != YCNR_BY_USER && side != YCNR_BY_ITEM) return fail(YCNR_ERR_INVALID, "bad side %d", side);
+  std::vector<Part> &parts = h->parts[side];
+  if (parts.empty()) return fail(YCNR_ERR_STATE, "step: set_ratings was not called for this side");
+  HIP_TRY(hipSetDevice(h->opt.device));
+  HIP_TRY(hipMemsetAsync(h->dErr, 0, sizeof(ErrInfo), h->stream));
+  // With a communicator and a sharded upload the half-step includes its exchange: the rows of piece
+  // c travel (on the communicator's stream) while piece c + 1 is being solved, and the step's
+  // stream waits for the last piece to land -- the next half-step reads the whole matrix.
+  const bool exchange = h->comm.active() && !h->bounds[side].empty();
+  h->exchangedInStep = exchange;
   memset(&h->info, 0, sizeof h->info);
+  std::vector<int64_t> xb, xe;
+  for (size_t c = 0; c < parts.size(); ++c) {
+    int rc = launch_part(h, side, parts[c]);
+    if (rc) return rc;
+    if (exchange) {
+      part_ranges(h, side, (int)c, xb, xe);
+      rc = comm_exchange(h->comm, h->factors[side], h->opt.factorsCount, h->ts(), xb.data(), xe.data(), h->stream, parts[c].ready,
+                         parts[c].x0, parts[c].x1, &h->info.exchangeBytes);
+      if (rc) return rc;
+    }
+  }
+  if (exchange) {
+    HIP_TRY(hipEventRecord(h->evComputeEnd, h->stream));
+    if (h->comm.transport == YCNR_COMM_RCCL) HIP_TRY(hipStreamWaitEvent(h->stream, parts.back().x1, 0));
+  }
   h->info.struct_size = (int32_t)sizeof(ycnr_als_step_info);
   h->info.side = side;
-  h->info.rows = S.solvedRows;
-  h->info.ratings = R.nnz;
-  h->info.units = S.nUnits;
-  h->info.splitRows = S.nSplit;
-  h->info.fusedRows = S.solvedRows - S.nSplit;
-  h->info.fusedRatings = S.fusedRatings;
-  if (h->opt.dtype == YCNR_F32 && dual_max_ratings(h->opt) > 0) {
-    h->info.dualRows = S.dualRows;
-    h->info.dualRatings = S.dualRatings;
-    h->info.dualOverlapped = S.dualRows >= kMinOverlapDualRows && h->opt.factorsCount <= kMaxFactors && !(h->opt.flags & YCNR_FLAG_NO_OVERLAP) &&
-                             !env_flags().noOverlap;
+  h->info.parts = (int32_t)parts.size();
+  const bool dual = h->opt.dtype == YCNR_F32 && dual_max_ratings(h->opt) > 0;
+  for (const Part &p : parts) {
+    const Schedule &S = p.S;
+    h->info.rows += S.solvedRows;
+    h->info.ratings += p.R.nnz;
+    h->info.units += S.nUnits;
+    h->info.splitRows += S.nSplit;
+    h->info.fusedRows += S.solvedRows - S.nSplit;
+    h->info.fusedRatings += S.fusedRatings;
+    if (dual) {
+      h->info.dualRows += S.dualRows;
+      h->info.dualRatings += S.dualRatings;
+      h->info.dualFlops += S.dualFlops;
+      if (S.dualRows >= kMinOverlapDualRows && h->opt.factorsCount <= kMaxFactors && !(h->opt.flags & YCNR_FLAG_NO_OVERLAP) &&
+          !env_flags().noOverlap)
+        h->info.dualOverlapped = 1;
+    }
   }
   h->infoPending = true;
-  h->infoHasSplit = S.nSplit > 0;
+  h->infoSide = side;
   return YCNR_OK;
 }
 
@@ -1330,17 +1446,37 @@ int ycnr_als_sync(ycnr_als *h) {
   HIP_TRY(hipStreamSynchronize(h->stream));
   if (h->infoPending) {
     h->infoPending = false;
+    const std::vector<Part> &parts = h->parts[h->infoSide];
     float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
-    h->info.gramSlabMs = ms;
-    HIP_TRY(hipEventElapsedTime(&ms, h->ev[1], h->ev[2]));
-    h->info.gramSolveMs = ms;
-    HIP_TRY(hipEventElapsedTime(&ms, h->ev[2], h->ev[3]));
-    h->info.dualSolveMs = ms;
-    HIP_TRY(hipEventElapsedTime(&ms, h->ev[3], h->ev[4]));
-    h->info.reduceSolveMs = ms;
-    HIP_TRY(hipEventElapsedTime(&ms, h->ev[0], h->ev[4]));
-    h->info.totalMs = ms;
+    for (const Part &p : parts) {
+      HIP_TRY(hipEventElapsedTime(&ms, p.ev[0], p.ev[1]));
+      h->info.gramSlabMs += ms;
+      HIP_TRY(hipEventElapsedTime(&ms, p.ev[1], p.ev[2]));
+      h->info.gramSolveMs += ms;
+      HIP_TRY(hipEventElapsedTime(&ms, p.ev[2], p.ev[3]));
+      h->info.dualSolveMs += ms;
+      HIP_TRY(hipEventElapsedTime(&ms, p.ev[3], p.ev[4]));
+      h->info.reduceSolveMs += ms;
+      if (h->exchangedInStep) {
+        HIP_TRY(hipEventElapsedTime(&ms, p.x0, p.x1));
+        h->info.exchangeMs += ms;
+      }
+    }
+    if (!parts.empty()) {
+      HIP_TRY(hipEventElapsedTime(&ms, parts.front().ev[0], parts.back().ev[4]));
+      h->info.totalMs = ms;
+      if (h->exchangedInStep) {
+        if (h->comm.transport == YCNR_COMM_RCCL) {
+          // what the step's stream still had to wait for after its own last kernel
+          HIP_TRY(hipEventElapsedTime(&ms, h->evComputeEnd, parts.back().x1));
+          h->info.exposedExchangeMs = ms > 0 ? ms : 0;
+        } else {
+          h->info.exposedExchangeMs = h->info.exchangeMs;  // the staged stand-in blocks the stream
+          HIP_TRY(hipEventElapsedTime(&ms, parts.back().x0, parts.back().x1));
+          h->info.totalMs -= h->info.exchangeMs - ms;  // kernels only (the last exchange lies behind the last kernel)
+        }
+      }
+    }
     ErrInfo ei{};
     HIP_TRY(hipMemcpy(&ei, h->dErr, sizeof ei, hipMemcpyDeviceToHost));
     h->info.numericErrors = ei.count;
@@ -1435,6 +1571,118 @@ int ycnr_als_rmse(ycnr_als *h, int which, double shift, int nPortions, const int
   if (dEnds) (void)hipFree(dEnds);
   if (dOut) (void)hipFree(dOut);
   if (e != hipSuccess) return fail(YCNR_ERR_HIP, "rmse: %s", hipGetErrorString(e));
+  return YCNR_OK;
+}
+
+// ---- multi-GPU exchange (comm_impl.hip.h) ----
+
+int ycnr_comm_unique_id(int transport, void *id) {
+  if (!id) return fail(YCNR_ERR_INVALID, "ycnr_comm_unique_id: null id");
+  memset(id, 0, YCNR_COMM_ID_BYTES);
+  if (transport == YCNR_COMM_RCCL) {
+    const RcclApi *api = nullptr;
+    int rc = rccl_api(&api);
+    if (rc) return rc;
+    ncclUniqueId uid;
+    NCCL_TRY(api, api->GetUniqueId(&uid));
+    memcpy(id, &uid, sizeof uid);
+    return YCNR_OK;
+  }
+  if (transport == YCNR_COMM_SHM) {
+    FILE *f = fopen("/dev/urandom", "rb");
+    if (!f || fread(id, 1, 16, f) != 16) {
+      if (f) fclose(f);
+      return fail(YCNR_ERR_HIP, "ycnr_comm_unique_id: cannot read /dev/urandom");
+    }
+    fclose(f);
+    return YCNR_OK;
+  }
+  return fail(YCNR_ERR_INVALID, "ycnr_comm_unique_id: unknown transport %d", transport);
+}
+
+int ycnr_als_comm_init(ycnr_als *h, int transport, const void *id, int rank, int world) {
+  if (!h) return fail(YCNR_ERR_INVALID, "null handle");
+  if (h->comm.transport != YCNR_COMM_NONE) return fail(YCNR_ERR_STATE, "comm_init: the handle already has a communicator");
+  HIP_TRY(hipSetDevice(h->opt.device));
+  // the staged stand-in needs room for the larger matrix (an exchange never stages more than one side)
+  const size_t big = (size_t)std::max(h->opt.totalUsersCount, h->opt.totalItemsCount) * h->opt.factorsCount * h->ts();
+  int rc = comm_setup(h->comm, id, transport, rank, world, std::max<size_t>(big, (size_t)1 << 20));
+  if (rc) comm_release(h->comm);
+  return rc;
+}
+
+int ycnr_als_comm_destroy(ycnr_als *h) {
+  if (!h) return fail(YCNR_ERR_INVALID, "null handle");
+  (void)hipSetDevice(h->opt.device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  comm_release(h->comm);
+  return YCNR_OK;
+}
+
+int ycnr_als_exchange(ycnr_als *h, int side) {
+  if (!h) return fail(YCNR_ERR_INVALID, "null handle");
+  if (side != 0 && side != 1) return fail(YCNR_ERR_INVALID, "bad side %d", side);
+  if (!h->comm.active()) return YCNR_OK;
+  if (h->bounds[side].empty() || h->parts[side].empty()) return fail(YCNR_ERR_STATE, "exchange: no sharded upload for this side");
+  HIP_TRY(hipSetDevice(h->opt.device));
+  const int world = h->comm.world, np = (int)h->parts[side].size();
+  std::vector<int64_t> b((size_t)world), e((size_t)world);
+  for (int r = 0; r < world; ++r) {
+    b[(size_t)r] = h->bounds[side][(size_t)r * (np + 1)];
+    e[(size_t)r] = h->bounds[side][(size_t)r * (np + 1) + np];
+  }
+  Part &p0 = h->parts[side][0];
+  int rc = comm_exchange(h->comm, h->factors[side], h->opt.factorsCount, h->ts(), b.data(), e.data(), h->stream, p0.ready, p0.x0, p0.x1, nullptr);
+  if (rc) return rc;
+  if (h->comm.transport == YCNR_COMM_RCCL) HIP_TRY(hipStreamSynchronize(h->comm.stream));
+  return YCNR_OK;
+}
+
+int ycnr_als_allreduce_sum(ycnr_als *h, double *vals, int64_t n) {
+  if (!h || (n > 0 && !vals)) return fail(YCNR_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(h->opt.device));
+  return comm_allreduce_sum(h->comm, vals, n);
+}
+
+int ycnr_als_broadcast_factors(ycnr_als *h, int side, int root) {
+  if (!h) return fail(YCNR_ERR_INVALID, "null handle");
+  if (side != 0 && side != 1) return fail(YCNR_ERR_INVALID, "bad side %d", side);
+  HIP_TRY(hipSetDevice(h->opt.device));
+  return comm_broadcast(h->comm, h->factors[side], (size_t)h->rows(side) * h->opt.factorsCount * h->ts(), root, h->stream);
+}
+
+// One self-addressed send / receive pair and one all-reduce through the handle's communicator:
+// lets a single-GPU box prove that the RCCL calls of the exchange run (tests/test_gpu_comm.py).
+int ycnr_als_comm_selftest(ycnr_als *h, int64_t nFloats) {
+  if (!h) return fail(YCNR_ERR_INVALID, "null handle");
+  if (h->comm.transport == YCNR_COMM_NONE) return fail(YCNR_ERR_STATE, "comm_selftest: no communicator");
+  if (nFloats < 1) return fail(YCNR_ERR_INVALID, "comm_selftest: nFloats < 1");
+  HIP_TRY(hipSetDevice(h->opt.device));
+  Comm &c = h->comm;
+  std::vector<float> src((size_t)nFloats), got((size_t)nFloats);
+  for (int64_t i = 0; i < nFloats; ++i) src[(size_t)i] = (float)((i * 2654435761u) % 65521) + 0.25f * (float)c.rank;
+  double sum[3] = {1.0 + c.rank, 2.0, -0.5 * c.rank};
+  if (c.transport == YCNR_COMM_RCCL) {
+    DevBuf a, b;
+    HIP_TRY(hipMalloc(&a.p, sizeof(float) * (size_t)nFloats));
+    HIP_TRY(hipMalloc(&b.p, sizeof(float) * (size_t)nFloats));
+    HIP_TRY(hipMemcpy(a.p, src.data(), sizeof(float) * (size_t)nFloats, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(b.p, 0, sizeof(float) * (size_t)nFloats));
+    NCCL_TRY(c.api, c.api->GroupStart());
+    NCCL_TRY(c.api, c.api->Send(a.p, (size_t)nFloats, ncclFloat, c.rank, c.nccl, c.stream));
+    NCCL_TRY(c.api, c.api->Recv(b.p, (size_t)nFloats, ncclFloat, c.rank, c.nccl, c.stream));
+    NCCL_TRY(c.api, c.api->GroupEnd());
+    HIP_TRY(hipStreamSynchronize(c.stream));
+    HIP_TRY(hipMemcpy(got.data(), b.p, sizeof(float) * (size_t)nFloats, hipMemcpyDeviceToHost));
+    if (memcmp(got.data(), src.data(), sizeof(float) * (size_t)nFloats) != 0)
+      return fail(YCNR_ERR_STATE, "comm_selftest: the self-addressed ncclSend / ncclRecv pair did not return the bytes sent");
+  }
+  int rc = comm_allreduce_sum(c, sum, 3);
+  if (rc) return rc;
+  const double w = c.world;
+  const double want[3] = {w + w * (w - 1) / 2, 2.0 * w, -0.5 * w * (w - 1) / 2};
+  for (int i = 0; i < 3; ++i)
+    if (!(fabs(sum[i] - want[i]) <= 1e-12 * (1 + fabs(want[i])))) return fail(YCNR_ERR_STATE, "comm_selftest: all-reduce gave %g, expected %g", sum[i], want[i]);
   return YCNR_OK;
 }
 

@@ -30,7 +30,12 @@ EXPORTS = [
     "ycnr_als_last_step_info", "ycnr_als_rmse",
     "ycnr_split_to_sets", "ycnr_rating_stats", "ycnr_csr_from_triplets", "ycnr_csr_transpose",
     "ycnr_recommend_items",
+    "ycnr_comm_unique_id", "ycnr_als_comm_init", "ycnr_als_comm_destroy", "ycnr_als_set_ratings_sharded",
+    "ycnr_als_exchange", "ycnr_als_broadcast_factors", "ycnr_als_allreduce_sum", "ycnr_als_comm_selftest",
 ]
+COMM_NONE, COMM_RCCL, COMM_SHM = 0, 1, 2
+COMM_ID_BYTES = 128
+ABI_VERSION = 2
 
 
 class YcnrError(RuntimeError):
@@ -52,7 +57,9 @@ class StepInfo(C.Structure):
                 ("fusedRatings", C.c_int64), ("dualRows", C.c_int64), ("dualRatings", C.c_int64),
                 ("gramSlabMs", C.c_float), ("gramSolveMs", C.c_float), ("dualSolveMs", C.c_float),
                 ("reduceSolveMs", C.c_float), ("totalMs", C.c_float), ("numericErrors", C.c_int32),
-                ("dualOverlapped", C.c_int32)]
+                ("dualOverlapped", C.c_int32), ("parts", C.c_int32), ("reserved0", C.c_int32),
+                ("exchangeBytes", C.c_int64), ("exchangeMs", C.c_float), ("exposedExchangeMs", C.c_float),
+                ("dualFlops", C.c_double)]
 
 
 _lib = None
@@ -126,6 +133,22 @@ def load():
     L.ycnr_recommend_items.argtypes = [i32, i32, i64, vp, i64, vp, vp, vp, dbl, dbl, i32, vp, vp, vp, C.POINTER(dbl)]
     L.ycnr_csr_transpose.restype = i32
     L.ycnr_csr_transpose.argtypes = [i32, i64, i64, vp, vp, vp, vp, vp, vp, C.POINTER(dbl)]
+    L.ycnr_comm_unique_id.restype = i32
+    L.ycnr_comm_unique_id.argtypes = [i32, vp]
+    L.ycnr_als_comm_init.restype = i32
+    L.ycnr_als_comm_init.argtypes = [vp, i32, vp, i32, i32]
+    L.ycnr_als_comm_destroy.restype = i32
+    L.ycnr_als_comm_destroy.argtypes = [vp]
+    L.ycnr_als_set_ratings_sharded.restype = i32
+    L.ycnr_als_set_ratings_sharded.argtypes = [vp, i32, vp, vp, vp, i32, i32, vp]
+    L.ycnr_als_exchange.restype = i32
+    L.ycnr_als_exchange.argtypes = [vp, i32]
+    L.ycnr_als_broadcast_factors.restype = i32
+    L.ycnr_als_broadcast_factors.argtypes = [vp, i32, i32]
+    L.ycnr_als_allreduce_sum.restype = i32
+    L.ycnr_als_allreduce_sum.argtypes = [vp, vp, i64]
+    L.ycnr_als_comm_selftest.restype = i32
+    L.ycnr_als_comm_selftest.argtypes = [vp, i64]
     _lib = L
     return L
 

@@ -42,9 +42,12 @@ def default_options():
         "dataDir": "data",
         # ratings per wave-level work unit on the GPU (0 = library default)
         "chunkRatings": 0,
-        # multi-GPU only: the user shard is solved in this many chunks so that the all-gather of
-        # one chunk overlaps with the solve of the next (1 = solve, then exchange)
+        # multi-GPU only: a side whose matrix is large is solved in this many pieces per rank, so that
+        # the exchange of one piece overlaps with the solve of the next (1 = solve, then exchange)
         "exchangeChunks": 4,
+        # multi-GPU only: "rccl" (the product path) or "shm" (functional stand-in: ranks of one node,
+        # possibly sharing one GPU, stage rows through POSIX shared memory)
+        "commTransport": "rccl",
     }
 
 
@@ -103,11 +106,31 @@ def split_to_portions(cnt_per_row, rows_cnt, ratings_in_portion, num_threads, pc
     return np.asarray(row_id_to, np.int64), ratings_in_portion, max_rows
 
 
-def shard_ranges(counts, world):
-    """Contiguous, nnz-balanced row ranges for `world` ranks: the greedy cumulative cut of
-    splitToPortions (EmfLord.js:571-592) with one portion per GPU.  Returns int64[world+1]."""
+def row_cost(counts, k, double=False):
+    """Modelled cost (SIMD-cycles) of re-solving one row with `counts` ratings in a half-step, used
+    to cut shards that finish together.  A rating costs the Gramian update of a k x k matrix, a row
+    costs its solve whatever its length, and rows with fewer ratings than factors take the cheaper
+    dual (n x n) form; constants from the per-kernel times of the MAL-scale run at k = 100
+    (170 cycles per rating and 25 K per solve in the row kernel; 3.6 K ... 41 K per row
+    for the dual classes of 16 ... 96 ratings).  Balancing ratings alone (what the reference's
+    splitToPortions does, lib/emf/EmfLord.js:571-592) gives the shard with many short rows more
+    work per rating."""
+    n = np.asarray(counts, np.float64)
+    nb = (k + 15) // 16
+    dual_max = 0 if (double or k % 4) else 16 * min(10 if k > 128 else 6, nb - 1)
+    primal = n * (1.7 * k) + 0.025 * float(k) ** 3
+    dual = 3600.0 * np.ceil(n / 16.0) ** 1.36 * (k / 100.0)
+    c = np.where(n <= dual_max, dual, primal)
+    return np.where(n > 0, c, 0.0)
+
+
+def shard_ranges(counts, world, k=None, double=False):
+    """Contiguous row ranges for `world` ranks with equal modelled cost (row_cost; plain rating
+    counts when k is None): the greedy cumulative cut of splitToPortions (EmfLord.js:571-592) with
+    one portion per GPU.  Returns int64[world+1]."""
     counts = np.asarray(counts, np.int64)
-    cum = np.concatenate([[0], np.cumsum(counts)])
+    w = counts.astype(np.float64) if k is None else row_cost(counts, k, double)
+    cum = np.concatenate([[0.0], np.cumsum(w)])
     total = cum[-1]
     b = [0]
     for r in range(1, world):
@@ -136,14 +159,14 @@ class Dataset:
 
 
 class HipBackend:
-    """The product compute backend: libycnr_als.so on cuda:<device>.  Factor matrices are
-    torch CUDA tensors bound into the handle(s) so collectives run on them in place.
+    """The product compute backend: libycnr_als.so on cuda:<device>.  Factor matrices are torch
+    CUDA tensors bound into the handle (torch is the allocator; nothing computes in torch).
 
-    With several ranks the local shard of a side can be cut into `chunks` row ranges, each
-    with its own native handle (same bound matrices): chunk c's solved rows are exchanged
-    while chunk c + 1 is being solved.  All work is enqueued on torch's current stream, so a
-    collective issued after step_chunk_async(c) is ordered behind that chunk's kernels and
-    overlaps with the next chunk's."""
+    With several ranks the library itself exchanges the solved rows (ycnr_als_comm_init +
+    ycnr_als_set_ratings_sharded, RCCL point-to-point over xGMI): step() returns when every replica
+    holds every solved row."""
+
+    native_exchange = True
 
     def __init__(self, opts, users, items, device=0):
         import torch
@@ -157,17 +180,28 @@ class HipBackend:
         k = opts["factorsCount"]
         self.fac = [torch.zeros(users, k, dtype=tdt, device=self.device),
                     torch.zeros(items, k, dtype=tdt, device=self.device)]
-        self.dev = self._new_handle()
-        self.chunk_devs = {0: [], 1: []}  # side -> [(AlsDevice, rowBegin, rowEnd)]
-
-    def _new_handle(self):
         o = self.opts
-        d = AlsDevice(o["factorsCount"], self.users, self.items, o["useDoublePrecision"], o["als"]["userFactReg"],
-                      o["als"]["itemFactReg"], device=self.devno, chunkRatings=o.get("chunkRatings", 0))
-        d.bind_factors(0, self.fac[0])
-        d.bind_factors(1, self.fac[1])
-        return d
+        self.dev = AlsDevice(o["factorsCount"], self.users, self.items, o["useDoublePrecision"], o["als"]["userFactReg"],
+                             o["als"]["itemFactReg"], device=self.devno, chunkRatings=o.get("chunkRatings", 0))
+        self.dev.bind_factors(0, self.fac[0])
+        self.dev.bind_factors(1, self.fac[1])
+        self.world = 1
 
+    # -- communicator ---------------------------------------------------------------------
+    def comm_unique_id(self, transport):
+        return AlsDevice.comm_unique_id(transport)
+
+    def comm_init(self, unique_id, rank, world, transport):
+        self.dev.comm_init(unique_id, rank, world, transport)
+        self.world = world
+
+    def allreduce_sum(self, arr):
+        return self.dev.allreduce_sum(arr)
+
+    def broadcast_factors(self, side, root=0):
+        self.dev.broadcast_factors(side, root)
+
+    # -- data ------------------------------------------------------------------------------
     def factors(self, side):
         return self.fac[side]
 
@@ -181,19 +215,12 @@ class HipBackend:
     def _vals(self, csr):
         return csr.astype(self.dtype_np)
 
-    def set_ratings(self, side, csr, rb, re, chunk_bounds=None):
-        """chunk_bounds: ascending row ids [rb, ..., re] cutting the shard into pipelined chunks."""
+    def set_ratings(self, side, csr, rb, re, bounds=None):
+        """bounds: per rank the ascending row ids [begin, cut, ..., end] of its pieces (sharded
+        upload for all ranks); None: the plain shard [rb, re) of a single process."""
         c = self._vals(csr)
-        for d, _, _ in self.chunk_devs[side]:
-            d.destroy()
-        self.chunk_devs[side] = []
-        if chunk_bounds is not None and len(chunk_bounds) > 2:
-            stream = self.torch.cuda.current_stream(self.device).cuda_stream
-            for lo, hi in zip(chunk_bounds[:-1], chunk_bounds[1:]):
-                d = self._new_handle()
-                d.set_stream(stream)
-                d.set_ratings(side, c.rowPtr, c.indx, c.vals, int(lo), int(hi))
-                self.chunk_devs[side].append((d, int(lo), int(hi)))
+        if bounds is not None:
+            self.dev.set_ratings_sharded(side, c.rowPtr, c.indx, c.vals, bounds)
         else:
             self.dev.set_ratings(side, c.rowPtr, c.indx, c.vals, rb, re)
 
@@ -201,41 +228,15 @@ class HipBackend:
         c = self._vals(csr)
         self.dev.set_rmse_ratings(which, c.rowPtr, c.indx, c.vals, rb, re)
 
-    def nchunks(self, side):
-        return len(self.chunk_devs[side])
-
     def step(self, side):
-        self.torch.cuda.synchronize(self.device)  # collectives on torch's stream are done
+        self.torch.cuda.synchronize(self.device)  # anything the host enqueued through torch is done
         return self.dev.step(side)
 
-    def step_chunk_async(self, side, c):
-        self.chunk_devs[side][c][0].step_async(side)
-
-    def sync_chunks(self, side):
-        """Wait for all chunk kernels; returns one merged StepInfo-like object."""
-        infos = []
-        for d, _, _ in self.chunk_devs[side]:
-            d.sync()
-            infos.append(d.last_step_info())
-        m = infos[0]
-        for i in infos[1:]:
-            for f in ("rows", "ratings", "units", "splitRows", "fusedRows", "fusedRatings", "dualRows", "dualRatings",
-                      "gramSlabMs", "gramSolveMs", "dualSolveMs", "reduceSolveMs", "totalMs", "numericErrors"):
-                setattr(m, f, getattr(m, f) + getattr(i, f))
-            m.dualOverlapped = max(m.dualOverlapped, i.dualOverlapped)
-        return m
-
     def rmse(self, which, shift, portion_row_end):
-        # the exchange of the last half-step runs on torch's streams, the RMSE kernel on the handle's
-        # own (non-blocking) stream: nothing else orders the two
         self.torch.cuda.synchronize(self.device)
         return self.dev.rmse(which, shift, portion_row_end)
 
     def destroy(self):
-        for side in (0, 1):
-            for d, _, _ in self.chunk_devs[side]:
-                d.destroy()
-            self.chunk_devs[side] = []
         self.dev.destroy()
 
 
@@ -298,21 +299,53 @@ class EmfLord:
         cu = _to_np(ds.train_by_user.counts())
         ci = _to_np(ds.train_by_item.counts())
         self.ratingsCntPerUser, self.ratingsCntPerItem = cu, ci
-        self.shards = {0: shard_ranges(cu, self.world), 1: shard_ranges(ci, self.world)}
+        k, dbl = self.factorsCount, self.options["useDoublePrecision"]
+        self.shards = {0: shard_ranges(cu, self.world, k, dbl), 1: shard_ranges(ci, self.world, k, dbl)}
         self.backend = self._backend_factory(self.options, self.totalUsersCount, self.totalItemsCount, device)
         ub, ue = self.shards[0][self.rank], self.shards[0][self.rank + 1]
         ib, ie = self.shards[1][self.rank], self.shards[1][self.rank + 1]
-        # pipelined exchange of the big (user) side: every rank's shard is cut into the same number
-        # of nnz-balanced chunks; chunkBounds[side][r] = row ids [begin, ..., end] of rank r
-        self.chunkBounds = {}
-        nch = int(self.options.get("exchangeChunks", 4)) if self.world > 1 else 1
-        if nch > 1 and hasattr(self.backend, "step_chunk_async"):
-            b = self.shards[0]
-            self.chunkBounds[0] = [b[r] + shard_ranges(cu[b[r]:b[r + 1]], nch) for r in range(self.world)]
-            self.backend.set_ratings(0, ds.train_by_user, int(ub), int(ue), chunk_bounds=self.chunkBounds[0][self.rank])
+        self.native_exchange = self.world > 1 and getattr(self.backend, "native_exchange", False)
+        if self.native_exchange:
+            # the communicator's id travels over the host's control plane (here torch.distributed's
+            # store; in the NodeJS host the Lord's process.send), the rows over the library's transport
+            transport = self.options.get("commTransport", "rccl")
+            ok, why = 1, ""
+            try:
+                box = [self.backend.comm_unique_id(transport) if self.rank == 0 else None]
+            except Exception as e:  # noqa: BLE001 -- reported below, collectively
+                box, ok, why = [None], 0, str(e)
+            self._dist.broadcast_object_list(box, src=0)
+            if box[0] is not None:
+                try:
+                    self.backend.comm_init(box[0], self.rank, self.world, transport)
+                except Exception as e:  # noqa: BLE001
+                    ok, why = 0, str(e)
+            else:
+                ok = 0
+            # all ranks must agree on the path: one failed rank sends everybody to torch.distributed
+            flags = [None] * self.world
+            self._dist.all_gather_object(flags, (ok, why))
+            if not all(f[0] for f in flags):
+                import warnings
+                warnings.warn("native exchange unavailable (%s); using torch.distributed all-gather"
+                              % "; ".join(f[1] for f in flags if not f[0]))
+                self.native_exchange = False
+        self.exchangePath = ("libycnr_als:" + self.options.get("commTransport", "rccl")) if self.native_exchange else \
+            ("torch.distributed" if self.world > 1 else "none")
+        if self.native_exchange:
+            # pieces per rank: a side whose shard is large is pipelined against its own exchange
+            s = 8 if dbl else 4
+            self.pieceBounds = {}
+            for side, cnt, rows in ((0, cu, self.totalUsersCount), (1, ci, self.totalItemsCount)):
+                nch = int(self.options.get("exchangeChunks", 4)) if rows * k * s / self.world >= (8 << 20) else 1
+                b = self.shards[side]
+                self.pieceBounds[side] = np.stack([b[r] + shard_ranges(cnt[b[r]:b[r + 1]], max(nch, 1), k, dbl)
+                                                   for r in range(self.world)])
+            self.backend.set_ratings(0, ds.train_by_user, int(ub), int(ue), bounds=self.pieceBounds[0])
+            self.backend.set_ratings(1, ds.train_by_item, int(ib), int(ie), bounds=self.pieceBounds[1])
         else:
             self.backend.set_ratings(0, ds.train_by_user, int(ub), int(ue))
-        self.backend.set_ratings(1, ds.train_by_item, int(ib), int(ie))
+            self.backend.set_ratings(1, ds.train_by_item, int(ib), int(ie))
         self.trainRatingsCount = int(cu.sum())
         # portions of the RMSE passes (EmfLord.js:523-598); kept as exclusive 0-based row ends
         self.portionsRowIdTo = {}
@@ -419,50 +452,16 @@ class EmfLord:
         has been re-solved everywhere, i.e. after the local step AND the exchange."""
         side = self.STEP_SIDE[stepType]
         t0 = time.perf_counter()
-        if side in self.chunkBounds:
-            info = self._step_pipelined(side)
-        else:
-            info = self.backend.step(side)
+        info = self.backend.step(side)  # with a native communicator this includes the exchange
+        if self.world > 1 and not self.native_exchange:
             self._exchange(side)
         self.stepTimes.append({"stepType": stepType, "iter": self.trainIter, "info": info,
                                "wall": time.perf_counter() - t0})
         return info
 
-    def _step_pipelined(self, side):
-        """Solve the local shard chunk by chunk; the all-gather of chunk c runs (on the
-        collective's own stream) while chunk c + 1 is being solved.  Same results as
-        step + _exchange: rows are independent within a half-step."""
-        dist, torch = self._dist, _torch()
-        bounds = self.chunkBounds[side]  # per rank: row ids [b0, b1, ..., bn]
-        nch = len(bounds[0]) - 1
-        fac = self.backend.factors(side)
-        k = fac.shape[1]
-        if not hasattr(self, "_cbuf"):
-            self._cbuf = {}
-        works = []
-        torch.cuda.synchronize()
-        for c in range(nch):
-            self.backend.step_chunk_async(side, c)
-            sizes = [int(bounds[r][c + 1] - bounds[r][c]) for r in range(self.world)]
-            mx = max(max(sizes), 1)
-            key = (side, c)
-            if key not in self._cbuf or self._cbuf[key].shape[1] != mx:
-                self._cbuf[key] = torch.zeros(self.world, mx, k, dtype=fac.dtype, device=fac.device)
-            buf = self._cbuf[key]
-            lo = int(bounds[self.rank][c])
-            buf[self.rank, : sizes[self.rank]].copy_(fac[lo:lo + sizes[self.rank]])
-            works.append((dist.all_gather_into_tensor(buf.view(-1), buf[self.rank].reshape(-1), async_op=True), buf, sizes, c))
-        for w, buf, sizes, c in works:
-            w.wait()
-            for r in range(self.world):
-                if r != self.rank and sizes[r] > 0:
-                    lo = int(bounds[r][c])
-                    fac[lo:lo + sizes[r]].copy_(buf[r, : sizes[r]])
-        torch.cuda.synchronize()
-        return self.backend.sync_chunks(side)
-
     def _exchange(self, side):
-        """All-gather of the freshly solved shard into every rank's replica of the matrix."""
+        """Exchange for backends WITHOUT a native one (the CPU oracle behind the gloo tests): a padded
+        all-gather through torch.distributed.  The product backend exchanges inside the library."""
         if self.world == 1:
             return
         dist = self._dist
@@ -501,7 +500,9 @@ class EmfLord:
         if calcGlobalAvgShift:
             self.globalAvgShift = 0
         parts = self.backend.rmse(stepType, self.globalAvgShift, self.portionsRowIdTo[stepType])
-        if self.world > 1:
+        if self.world > 1 and self.native_exchange:
+            parts = self.backend.allreduce_sum(parts.reshape(-1)).reshape(parts.shape)  # 'rmseSaveCalcs', EmfMaster.js:726-736
+        elif self.world > 1:
             torch = _torch()
             t = torch.from_numpy(parts).to(self.backend.factors(0).device)
             self._dist.all_reduce(t)

@@ -11,6 +11,7 @@ from . import _lib
 from ._lib import BY_ITEM, BY_USER, F32, F64, MEM_DEVICE, MEM_HOST, RMSE_TEST, RMSE_VALIDATE, check
 
 SIDES = {"byUser": BY_USER, "byItem": BY_ITEM, BY_USER: BY_USER, BY_ITEM: BY_ITEM}
+TRANSPORTS = {"rccl": _lib.COMM_RCCL, "shm": _lib.COMM_SHM, _lib.COMM_RCCL: _lib.COMM_RCCL, _lib.COMM_SHM: _lib.COMM_SHM}
 RMSE_SETS = {"rmseValidate": RMSE_VALIDATE, "rmseTest": RMSE_TEST, RMSE_VALIDATE: RMSE_VALIDATE,
              RMSE_TEST: RMSE_TEST}
 
@@ -190,6 +191,52 @@ class AlsDevice:
 
     def set_ratings(self, side, rowPtr, indx, vals, rowBegin=0, rowEnd=None):
         self._upload(self._L.ycnr_als_set_ratings, SIDES[side], rowPtr, indx, vals, rowBegin, rowEnd)
+
+    def set_ratings_sharded(self, side, rowPtr, indx, vals, bounds, nChunks=None):
+        """Sharded upload for every rank of the communicator: bounds[r] = ascending row ids
+        [begin, cut, ..., end] of rank r (all ranks the same number of pieces).  Afterwards step(side)
+        includes the exchange of the solved rows (ycnr_als_set_ratings_sharded)."""
+        b = np.ascontiguousarray(bounds, np.int64)
+        if b.ndim != 2:
+            raise ValueError("bounds must be [world, nChunks + 1]")
+        p0, k0 = _ptr_kind(rowPtr, np.int64)
+        p1, k1 = _ptr_kind(indx, np.int32)
+        p2, k2 = _ptr_kind(vals, self.dtype)
+        if not (k0 == k1 == k2):
+            raise ValueError("rowPtr, indx and vals must live in the same kind of memory")
+        check(self._L.ycnr_als_set_ratings_sharded(self._h, SIDES[side], p0, p1, p2, k0, b.shape[1] - 1, b.ctypes.data))
+
+    # -- multi-GPU exchange -----------------------------------------------------------
+    @staticmethod
+    def comm_unique_id(transport="rccl"):
+        """128 bytes made by ONE rank; every rank passes the same bytes to comm_init."""
+        L = _lib.load()
+        buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
+        check(L.ycnr_comm_unique_id(TRANSPORTS[transport], buf))
+        return buf.raw
+
+    def comm_init(self, unique_id, rank, world, transport="rccl"):
+        if len(unique_id) != _lib.COMM_ID_BYTES:
+            raise ValueError("unique id must be 128 bytes")
+        check(self._L.ycnr_als_comm_init(self._h, TRANSPORTS[transport], C.c_char_p(bytes(unique_id)), int(rank), int(world)))
+
+    def comm_destroy(self):
+        check(self._L.ycnr_als_comm_destroy(self._h))
+
+    def exchange(self, side):
+        check(self._L.ycnr_als_exchange(self._h, SIDES[side]))
+
+    def broadcast_factors(self, side, root=0):
+        check(self._L.ycnr_als_broadcast_factors(self._h, SIDES[side], int(root)))
+
+    def allreduce_sum(self, arr):
+        """In-place sum over ranks of a float64 numpy array."""
+        a = np.ascontiguousarray(arr, np.float64)
+        check(self._L.ycnr_als_allreduce_sum(self._h, a.ctypes.data, a.size))
+        return a
+
+    def comm_selftest(self, nFloats=1 << 20):
+        check(self._L.ycnr_als_comm_selftest(self._h, int(nFloats)))
 
     def set_rmse_ratings(self, which, rowPtr, indx, vals, rowBegin=0, rowEnd=None):
         self._upload(self._L.ycnr_als_set_rmse_ratings, RMSE_SETS[which], rowPtr, indx, vals, rowBegin, rowEnd)
