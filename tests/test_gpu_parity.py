@@ -365,8 +365,8 @@ def test_float64_solvers_agree(als, k):
 
 
 def test_big_k_split_rows_and_batches(als):
-    """k = 256 through the 4-wave kernels: rows of many chunks, a row longer than 64 chunks, and
-    both half-steps; checked against float64."""
+    """k = 256 through the workgroup-per-row kernels: rows cut into many chunks (slabs + reduce), a row
+    longer than 64 chunks, whole rows; checked against float64."""
     k, users, items = 256, 40, 3000
     rng = np.random.default_rng(3)
     lens = [0, 1, 50, 96, 97, 130, 500, 1024, 1025, 2500, 2999] + list(rng.integers(100, 400, 29))
@@ -377,17 +377,57 @@ def test_big_k_split_rows_and_batches(als):
     bu = Csr(users, items, rowPtr, indx, vals)
     U = (rng.standard_normal((users, k)) / k).astype(np.float32)
     V = (rng.standard_normal((items, k)) / np.sqrt(k)).astype(np.float32)
-    dev = als.AlsDevice(k, users, items, chunkRatings=32)  # 2999 ratings -> 64 chunks of 48
-    dev.set_ratings("byUser", bu.rowPtr, bu.indx, bu.vals)
-    dev.set_factors("byUser", U)
-    dev.set_factors("byItem", V)
-    info = dev.step("byUser")
-    assert info.numericErrors == 0 and info.rows == users - 1
-    got = dev.get_factors("byUser")
     want, conds = numpy_step(0.05, k, bu, V, U)
-    check_rows(got, want, conds, np.float32)
-    assert np.array_equal(got[0], U[0])
-    dev.destroy()
+    for chunk in (32, 0):   # 32: 2999 ratings -> 64 chunks of 48; 0: the library's own (whole rows here)
+        dev = als.AlsDevice(k, users, items, chunkRatings=chunk)
+        dev.set_ratings("byUser", bu.rowPtr, bu.indx, bu.vals)
+        dev.set_factors("byUser", U)
+        dev.set_factors("byItem", V)
+        info = dev.step("byUser")
+        assert info.numericErrors == 0 and info.rows == users - 1
+        assert (info.splitRows > 20) == (chunk == 32)
+        got = dev.get_factors("byUser")
+        check_rows(got, want, conds, np.float32)
+        assert np.array_equal(got[0], U[0])
+        dev.destroy()
+
+
+@pytest.mark.parametrize("k", [132, 144, 160, 176, 192, 208, 224, 240, 256])
+def test_workgroup_path_every_block_count(als, k):
+    """128 < k <= 256 (als_wg_kernels.hip.h) at every tile count NB = 9..16: more rows than CUs (the
+    persistent loop and its prefetch of the next row), rows of 1..70 steps of 32 ratings including exact
+    multiples, split rows, both against float64; a second run must reproduce the first bit for bit."""
+    from ycnr_als import _lib
+    items = 2600
+    rng = np.random.default_rng(k)
+    lens = [161, 162, 191, 192, 193, 223, 224, 225, 256, 320, 321, 1000, 2240, 2241] + list(rng.integers(161, 420, 700)) + [0, 3, 160]
+    rowPtr = np.zeros(len(lens) + 1, np.int64)
+    rowPtr[1:] = np.cumsum(lens)
+    indx = np.concatenate([np.sort(rng.choice(items, n, replace=False)) for n in lens]).astype(np.int32)
+    vals = rng.integers(1, 11, rowPtr[-1]).astype(np.float32)
+    bu = Csr(len(lens), items, rowPtr, indx, vals)
+    U = (rng.standard_normal((len(lens), k)) / k).astype(np.float32)
+    V = (rng.standard_normal((items, k)) / np.sqrt(k)).astype(np.float32)
+    rows = np.r_[0:40, len(lens) - 60:len(lens)]      # float64 check on a subset (numpy at k = 256 is slow)
+    sub = Csr(len(rows), items, np.concatenate([[0], np.cumsum(np.asarray(lens)[rows])]),
+              np.concatenate([indx[rowPtr[r]:rowPtr[r + 1]] for r in rows]), np.concatenate([vals[rowPtr[r]:rowPtr[r + 1]] for r in rows]))
+    want, conds = numpy_step(0.05, k, sub, V, U[rows])
+    res = []
+    for chunk, flags in ((0, _lib.FLAG_NO_DUAL), (0, _lib.FLAG_NO_DUAL), (96, 0)):
+        dev = als.AlsDevice(k, len(lens), items, chunkRatings=chunk, flags=flags)
+        dev.set_ratings("byUser", bu.rowPtr, bu.indx, bu.vals)
+        dev.set_factors("byUser", U)
+        dev.set_factors("byItem", V)
+        info = dev.step("byUser")
+        assert info.numericErrors == 0
+        got = dev.get_factors("byUser")
+        check_rows(got[rows], want, conds, np.float32)
+        assert np.array_equal(got[len(lens) - 3], U[len(lens) - 3])
+        res.append(got)
+        dev.destroy()
+    assert np.array_equal(res[0], res[1])
+    err = row_rel_err(res[0], res[2])
+    assert err.max() < 2e-4, err.max()   # whole rows vs chunks + reduce: same error class
 
 
 def test_sharded_rows_equal_unsharded(als):

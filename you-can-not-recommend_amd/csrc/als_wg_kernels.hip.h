@@ -1,0 +1,625 @@
+// als_wg_kernels.hip.h -- the float32 path for 128 < factorsCount <= 256: one 512-thread workgroup
+// (8 waves, two per SIMD) per row, one workgroup per CU, persistent over the rows of a launch.
+//
+// At k = 256 the upper triangle of A = Y^T Y is 136 tiles of 16 x 16: 544 accumulator registers per
+// lane, more than a wave owns, and a 136 KB image, most of a CU's LDS.  So a row belongs to a whole
+// workgroup:
+//
+//  Gramian (WgGram).  Wave w owns the tiles of block rows w and NB-1-w (NB + 1 tiles: 68
+//    registers).  Products run on the bf16 matrix pipe with float32-equivalent results: every
+//    gathered float is split exactly into three bf16 terms and six of the nine products are
+//    accumulated (the exact scheme of GramX6D, als_kernels.hip.h).  A step is 32 ratings:
+//      * every thread loads 4 x 16 bytes of ONE gathered row (thread t: rating t >> 4 of the step,
+//        columns 64 j + 4 (t & 15) .. +3) with plain 16-byte global loads, two steps ahead of their
+//        use -- each gathered row crosses L2 -> CU once per workgroup, 16 bytes per lane;
+//      * it splits its 16 values in registers and writes the three bf16 planes to LDS as
+//        [rating][column] rows of 4 columns = 8 bytes (ds_write_b64), into one of two plane buffers;
+//      * the MFMA operand of block b -- lane (g, c): ratings 8g .. 8g+7 of column 16 b + c -- comes
+//        back with two ds_read_b64_tr_b16 per plane (the transposing LDS read of gfx950): no
+//        shuffles, no second image.  Inside a block's 1 KB region the 8-byte chunk of (rating rho,
+//        column quad p) sits at  p + 4 (rho & 3) + 16 ((rho >> 3) & 1) + 32 ((rho >> 2) & 1) + 64 (rho >> 4):
+//        a transposed read touches 32 consecutive chunks (conflict-free) and consecutive blocks are
+//        32 bytes further apart than 1 KB, which spreads the 16 writers of a rating over all banks.
+//    One workgroup barrier per step; b = Y^T r is accumulated on the VALU from the unsplit values.
+//
+//  Solve (WgSolve).  The tiles go from the accumulators to an LDS image ([col][row] per tile with a
+//    16-byte XOR swizzle: every operand and every tile is ONE conflict-free ds_read_b128 /
+//    ds_write_b128 at the same per-lane offset) and a right-looking block Cholesky A = U^T U runs on
+//    it with float32 MFMAs, all eight waves working:
+//      for J:  panel  U[J][bj] = W_J T[J][bj]            (tiles dealt over the waves)
+//              update T[bi][bj] -= U[J][bi]^T U[J][bj]   wave 0 takes tile (J+1, J+1) FIRST and
+//                     factors + inverts it (16 sequential pivots) while the other seven waves do the
+//                     rest of the trailing update: the next diagonal tile is ready when they are
+//                     (look-ahead), two barriers per block step;
+//      the right-hand side rides along (z_J = W_J b_J in the panel phase, b_bj -= U[J][bj]^T z_J in
+//      the update phase, one wave per block column), and the back substitution is right-looking
+//      too: after x_J every wave updates the block rows it owns, one barrier per block.
+//
+//  Rows longer than a launch wants in one workgroup are cut into chunks whose tiles go to a slab in
+//  global memory in image layout (als_wg_gram_slab_kernel) and are summed in slab order before the
+//  same solve (als_wg_reduce_solve_kernel).  Rows of <= 160 ratings never come here: they take the
+//  dual form (als_dual_solve_kernel).
+#pragma once
+#include "als_kernels.hip.h"
+
+namespace ycnr {
+
+constexpr int kWgWaves = 8;
+constexpr int kWgThreads = kWgWaves * 64;
+
+typedef float wg_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned wg_u32x2 __attribute__((ext_vector_type(2)));
+typedef short wg_s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int NB>
+struct WgCfg {
+  static constexpr int NT = tile_count(NB);
+  static constexpr int REGION = 1024 + 32;  // bytes of one (plane, block): 32 ratings x 16 columns of bf16, + bank rotation
+  static constexpr int PLANE = NB * REGION;
+  static constexpr int BUF = 3 * PLANE;
+  static constexpr int GRAM_BYTES = 2 * BUF;
+  static constexpr int IMG_BYTES = NT * 1024;
+  static constexpr int BPART_OFF = IMG_BYTES > GRAM_BYTES ? IMG_BYTES : GRAM_BYTES;
+  static constexpr int BPART_BYTES = kWgWaves * NB * 16 * 4;
+  static constexpr int VEC_OFF = BPART_OFF + BPART_BYTES;  // bvec, zvec, xvec: NB * 16 floats each
+  static constexpr int DT_OFF = VEC_OFF + 3 * NB * 64;
+  static constexpr int LDW = 20;
+  static constexpr int FLAG_OFF = DT_OFF + 16 * LDW * 4;
+  static constexpr int LDS_BYTES = FLAG_OFF + 64;
+  // elements of one slab in global memory: the image + b
+  static constexpr int64_t SLAB_FLOATS = (int64_t)NT * 256 + NB * 16;
+};
+__host__ __device__ constexpr int64_t wg_slab_floats(int nb) { return (int64_t)tile_count(nb) * 256 + nb * 16; }
+
+// byte offset of a lane's 16 bytes in a tile of the image: element (row r, col c) of the tile lives
+// at float c * 16 + 4 ((r >> 2) ^ ((c >> 1) & 3)) + (r & 3); lane (g, c) owns rows 4g .. 4g+3 of column c
+__device__ __forceinline__ int wg_tile_lane_off(int lane) {
+  const int g = lane >> 4, c = lane & 15;
+  return (c * 16 + 4 * (g ^ ((c >> 1) & 3))) * 4;
+}
+
+// block rows of wave W: r0 = W, r1 = NB-1-W (one row when they coincide, none when W > NB-1-W)
+template <int NB, int W>
+struct WgRows {
+  static constexpr int r0 = W, r1 = NB - 1 - W;
+  static constexpr bool any = r0 <= r1, two = r0 < r1;
+  static constexpr int n0 = any ? NB - r0 : 0;          // tiles of row r0: bj = r0 .. NB-1
+  static constexpr int n1 = two ? NB - r1 : 0;          // tiles of row r1
+};
+
+template <int NB>
+struct WgGram {
+  using C = WgCfg<NB>;
+  using acc_t = typename MfmaTraits<float>::acc_t;
+  static constexpr int NACC = NB + 1;
+
+  struct Stage {  // one step's gathered values of this thread, and its rating
+    wg_f32x4 x[4];
+    float r;
+  };
+
+  // ids and ratings are read one step ahead of the rows they address
+  struct Meta {
+    int32_t id;
+    float r;
+    bool valid;
+  };
+  static __device__ __forceinline__ Meta load_meta(const StepArgs<float> &a, int64_t beg, int64_t n, int64_t s, int rho) {
+    const int64_t q = (s << 5) + rho;
+    Meta m;
+    m.valid = q < n;
+    const int64_t qc = beg + (m.valid ? q : n - 1);
+    m.id = a.indx[qc];
+    m.r = a.vals[qc];
+    return m;
+  }
+  static __device__ __forceinline__ void load_rows(Stage &st, const StepArgs<float> &a, const Meta &m, int l16) {
+    const float *row = m.valid ? a.fixed + (int64_t)m.id * a.k : a.zeros;
+    st.r = m.valid ? m.r : 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = 64 * j + 4 * l16;
+      if (64 * j < NB * 16) {  // static: loads a block of this NB can need
+        const float *p = col < a.k ? row + col : a.zeros;
+        st.x[j] = *reinterpret_cast<const wg_f32x4 *>(p);
+      }
+    }
+  }
+
+  // split + plane writes of one stage into plane buffer `buf` (byte address of the buffer in LDS)
+  static __device__ __forceinline__ void split_store(const Stage &st, float (&bacc)[4][4], unsigned char *buf, int wofs, int l16) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (64 * j >= NB * 16) continue;
+      if (4 * j + (l16 >> 2) >= NB) continue;  // a block beyond the padded matrix (columns >= 16 NB)
+      unsigned h[2], m[2], l[2];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bacc[j][e] = fmaf(st.x[j][e], st.r, bacc[j][e]);
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const float x0 = st.x[j][2 * jj], x1 = st.x[j][2 * jj + 1];
+        const unsigned u0 = __builtin_bit_cast(unsigned, x0), u1 = __builtin_bit_cast(unsigned, x1);
+        h[jj] = __builtin_amdgcn_perm(u1, u0, 0x07060302);
+        const float s0 = x0 - __builtin_bit_cast(float, u0 & 0xFFFF0000u);
+        const float s1 = x1 - __builtin_bit_cast(float, u1 & 0xFFFF0000u);
+        const unsigned v0 = __builtin_bit_cast(unsigned, s0), v1 = __builtin_bit_cast(unsigned, s1);
+        m[jj] = __builtin_amdgcn_perm(v1, v0, 0x07060302);
+        const float t0 = s0 - __builtin_bit_cast(float, v0 & 0xFFFF0000u);
+        const float t1 = s1 - __builtin_bit_cast(float, v1 & 0xFFFF0000u);
+        l[jj] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, t1), __builtin_bit_cast(unsigned, t0), 0x07060302);
+      }
+      unsigned char *p = buf + wofs + 4 * j * C::REGION;
+      *reinterpret_cast<wg_u32x2 *>(p) = wg_u32x2{h[0], h[1]};
+      *reinterpret_cast<wg_u32x2 *>(p + C::PLANE) = wg_u32x2{m[0], m[1]};
+      *reinterpret_cast<wg_u32x2 *>(p + 2 * C::PLANE) = wg_u32x2{l[0], l[1]};
+    }
+  }
+
+  struct Op {  // the three bf16 planes of one block in MFMA operand layout
+    wg_bf16x8 p[3];
+  };
+  static __device__ __forceinline__ Op read_op(const unsigned char *buf, int block, int rofs) {
+    Op o;
+    typedef __attribute__((address_space(3))) wg_s16x4 *lds_s16x4_ptr;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      const unsigned char *p = buf + pl * C::PLANE + block * C::REGION + rofs;
+      const wg_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p));
+      const wg_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p + 256));
+      typedef short s16x8 __attribute__((ext_vector_type(8)));
+      const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      o.p[pl] = __builtin_bit_cast(wg_bf16x8, v);
+    }
+    return o;
+  }
+  // acc += A^T B with float32-equivalent products: the six significant bf16 products, smallest first
+  static __device__ __forceinline__ acc_t mma6(const Op &A, const Op &B, acc_t acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A.p[1], B.p[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A.p[0], B.p[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A.p[2], B.p[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A.p[0], B.p[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A.p[1], B.p[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A.p[0], B.p[0], acc, 0, 0, 0);
+    return acc;
+  }
+
+  // the products of one step for wave W: tiles (r0, r0..NB-1) in acc[0 .. n0), (r1, r1..NB-1) behind them
+  template <int W>
+  static __device__ __forceinline__ void mma_step(acc_t (&acc)[NACC], const unsigned char *buf, int rofs) {
+    using R = WgRows<NB, W>;
+    if constexpr (R::any) {
+      // B operands one block ahead of their products, and no further: the compiler would otherwise
+      // hoist every read of the row to the top (12 registers per block) and spill the accumulators
+      const Op A0 = read_op(buf, R::r0, rofs);
+      Op A1 = A0, B = A0;
+#pragma unroll
+      for (int bj = R::r0; bj < NB; ++bj) {
+        Op Bn = B;
+        if (bj + 1 < NB) Bn = read_op(buf, bj + 1, rofs);
+        asm volatile("" ::: "memory");
+        if (R::two && bj == R::r1) A1 = B;
+        acc[bj - R::r0] = mma6(A0, B, acc[bj - R::r0]);
+        if (R::two && bj >= R::r1) acc[R::n0 + bj - R::r1] = mma6(A1, B, acc[R::n0 + bj - R::r1]);
+        B = Bn;
+      }
+    }
+  }
+  static __device__ __forceinline__ void mma_step_w(int wave, acc_t (&acc)[NACC], const unsigned char *buf, int rofs) {
+    switch (wave) {
+      case 0: mma_step<0>(acc, buf, rofs); break;
+      case 1: mma_step<1>(acc, buf, rofs); break;
+      case 2: mma_step<2>(acc, buf, rofs); break;
+      case 3: mma_step<3>(acc, buf, rofs); break;
+      case 4: mma_step<4>(acc, buf, rofs); break;
+      case 5: mma_step<5>(acc, buf, rofs); break;
+      case 6: mma_step<6>(acc, buf, rofs); break;
+      default: mma_step<7>(acc, buf, rofs); break;
+    }
+  }
+
+  // accumulator tiles of wave W -> image layout at `img` (LDS or a slab in global memory), float units
+  template <int W, typename P>
+  static __device__ __forceinline__ void store_tiles(const acc_t (&acc)[NACC], P img, int lane) {
+    using R = WgRows<NB, W>;
+    const int off = wg_tile_lane_off(lane) >> 2;
+    if constexpr (R::any) {
+#pragma unroll
+      for (int bj = R::r0; bj < NB; ++bj) *reinterpret_cast<wg_f32x4 *>(&img[tile_index(R::r0, bj, NB) * 256 + off]) = acc[bj - R::r0];
+      if constexpr (R::two) {
+#pragma unroll
+        for (int bj = R::r1; bj < NB; ++bj)
+          *reinterpret_cast<wg_f32x4 *>(&img[tile_index(R::r1, bj, NB) * 256 + off]) = acc[R::n0 + bj - R::r1];
+      }
+    }
+  }
+  template <typename P>
+  static __device__ __forceinline__ void store_tiles_w(int wave, const acc_t (&acc)[NACC], P img, int lane) {
+    switch (wave) {
+      case 0: store_tiles<0>(acc, img, lane); break;
+      case 1: store_tiles<1>(acc, img, lane); break;
+      case 2: store_tiles<2>(acc, img, lane); break;
+      case 3: store_tiles<3>(acc, img, lane); break;
+      case 4: store_tiles<4>(acc, img, lane); break;
+      case 5: store_tiles<5>(acc, img, lane); break;
+      case 6: store_tiles<6>(acc, img, lane); break;
+      default: store_tiles<7>(acc, img, lane); break;
+    }
+  }
+
+  // Gramian of ratings [beg, beg + n): on return the workgroup's accumulators hold the tiles, bacc
+  // this thread's partial sums of b, and all waves have passed the last barrier (LDS is free).
+  // pre0 / pre1 / m2: steps 0 and 1 already requested by the caller (prefetch during the previous
+  // row's solve) and the ids of step 2.
+  static __device__ __forceinline__ void run(const StepArgs<float> &a, int64_t beg, int64_t n, unsigned char *smem, acc_t (&acc)[NACC],
+                                             float (&bacc)[4][4], Stage &s0, Stage &s1, Meta &m2) {
+    const int tid = threadIdx.x, lane = tid & 63, l16 = tid & 15, rho = tid >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t nsteps = (n + 31) >> 5;
+    // writer: chunk of (rho, p = l16 & 3) in the region of block (l16 >> 2) [+ 4 j]
+    const int wofs = (l16 >> 2) * C::REGION +
+                     8 * ((l16 & 3) + 4 * (rho & 3) + 16 * ((rho >> 3) & 1) + 32 * ((rho >> 2) & 1) + 64 * (rho >> 4));
+    // reader: lane 4q + p of a 16-lane group supplies row q, column quad p; group g reads ratings 8g .. 8g+3 (+4)
+    const int rofs = 8 * (lane & 31) + 512 * (lane >> 5);
+#pragma unroll
+    for (int t = 0; t < NACC; ++t) acc[t] = acc_t{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bacc[j][e] = 0.0f;
+    unsigned char *buf0 = smem, *buf1 = smem + C::BUF;
+    // phase -1: planes of step 0; rows of step 2; ids of step 3
+    split_store(s0, bacc, buf0, wofs, l16);
+    load_rows(s0, a, m2, l16);
+    Meta m3 = load_meta(a, beg, n, 3, rho);
+    __syncthreads();
+    for (int64_t s = 0; s < nsteps; s += 2) {
+      // phase s: planes of step s + 1 (always written: zeros past the end), products of step s
+      split_store(s1, bacc, buf1, wofs, l16);
+      load_rows(s1, a, m3, l16);                        // step s + 3
+      Meta m4 = load_meta(a, beg, n, s + 4, rho);
+      mma_step_w(wave, acc, buf0, rofs);
+      __syncthreads();
+      if (s + 1 >= nsteps) break;
+      // phase s + 1
+      split_store(s0, bacc, buf0, wofs, l16);           // step s + 2
+      load_rows(s0, a, m4, l16);                        // step s + 4
+      m3 = load_meta(a, beg, n, s + 5, rho);
+      mma_step_w(wave, acc, buf1, rofs);
+      __syncthreads();
+    }
+  }
+
+  // this thread's b partials -> bvec (NB * 16 floats in LDS); ends with a barrier
+  static __device__ __forceinline__ void reduce_b(float (&bacc)[4][4], unsigned char *smem) {
+    const int tid = threadIdx.x, lane = tid & 63, l16 = tid & 15;
+    const int wave = tid >> 6;
+    float *bpart = reinterpret_cast<float *>(smem + C::BPART_OFF);
+    float *bvec = reinterpret_cast<float *>(smem + C::VEC_OFF);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (64 * j >= NB * 16) continue;
+      wg_f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float t = bacc[j][e];
+        t += __shfl_xor(t, 16, 64);
+        t += __shfl_xor(t, 32, 64);
+        v[e] = t;
+      }
+      const int col = 64 * j + 4 * l16;
+      if (lane < 16 && col < NB * 16) *reinterpret_cast<wg_f32x4 *>(bpart + wave * (NB * 16) + col) = v;
+    }
+    __syncthreads();
+    if (tid < NB * 16) {
+      float t = 0.0f;
+#pragma unroll
+      for (int w = 0; w < kWgWaves; ++w) t += bpart[w * (NB * 16) + tid];
+      bvec[tid] = t;
+    }
+    __syncthreads();
+  }
+};
+
+// Block Cholesky + substitutions on the LDS image.  In: tiles (upper triangle, image layout) at smem,
+// bvec; lam I not yet added.  Out: x written to a.solved[row].  All 512 threads call it.
+template <int NB>
+struct WgSolve {
+  using C = WgCfg<NB>;
+  using Tr = MfmaTraits<float>;
+  using acc_t = typename Tr::acc_t;
+  using Sm = SolveMfmaF32<1>;
+
+  static __device__ __forceinline__ float *tile(float *S, int bi, int bj) { return S + tile_index(bi, bj, NB) * 256; }
+  static __device__ __forceinline__ acc_t ld(const float *T, int off) { return *reinterpret_cast<const acc_t *>(T + off); }
+  static __device__ __forceinline__ void st(float *T, int off, const acc_t &v) { *reinterpret_cast<acc_t *>(T + off) = v; }
+
+  // y[c] = sum_r M[r][c] v[r] for the tile in registers (lane (g, c): M[4g+t][c]), v given per row
+  // (vrow[t] = v[4g + t]); result in every lane group
+  static __device__ __forceinline__ float matvec_t(const acc_t &m, const acc_t &vrow) {
+    float s = m[0] * vrow[0];
+    s = fmaf(m[1], vrow[1], s);
+    s = fmaf(m[2], vrow[2], s);
+    s = fmaf(m[3], vrow[3], s);
+    return Sm::group_sum(s);
+  }
+  // y[4g+t] = sum_c M[4g+t][c] v[c], v given per column (vc = v[c]); result in every lane of group g
+  static __device__ __forceinline__ acc_t matvec_n(const acc_t &m, float vc) {
+    acc_t y;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) y[t] = Sm::row_sum(m[t] * vc);
+    return y;
+  }
+
+  // wave 0: factor the diagonal tile (J, J) in place: on return it holds V = U_JJ^-1 (upper triangular,
+  // image layout), i.e. image[c][r] = W[c][r] with W = L^-1.  Returns true when a real pivot was not positive.
+  static __device__ __forceinline__ bool factor_diag(float *S, float *Dt, int J, int k, int lane) {
+    const int g = lane >> 4, c = lane & 15;
+    float *T = tile(S, J, J);
+    // lane c of groups 0 / 2: row c of D (= column c, D is symmetric); groups 1 / 3: row c of the identity
+    float R[16];
+    {
+      const bool xlane = (g & 1) != 0;
+      const int sw = (c >> 1) & 3;
+#pragma unroll
+      for (int m4 = 0; m4 < 4; ++m4) {
+        const acc_t v = *reinterpret_cast<const acc_t *>(T + c * 16 + 4 * (m4 ^ sw));
+#pragma unroll
+        for (int t = 0; t < 4; ++t) R[4 * m4 + t] = xlane ? (c == 4 * m4 + t ? 1.0f : 0.0f) : v[t];
+      }
+    }
+    float dmin = 3.0e38f;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+      if (J == NB - 1 && J * 16 + p >= k) break;  // padded pivots are rows of the identity
+      const float d = Sm::readlane(R[p], p);
+      dmin = fminf(dmin, d);
+      const float rs = __builtin_amdgcn_rsqf(d);
+      R[p] *= rs;
+      float mult[16];
+#pragma unroll
+      for (int j = p + 1; j < 16; ++j) mult[j] = Sm::readlane(R[p], j);
+#pragma unroll
+      for (int j = p + 1; j < 16; ++j) R[j] = fmaf(-R[p], mult[j], R[j]);
+    }
+    // lane (1, c) holds R[j] = L^-T[c][j] = W[j][c]: image[j][r = c]
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // the tile reads above have returned before the tile is overwritten
+    if (g == 1) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) T[j * 16 + 4 * ((c >> 2) ^ ((j >> 1) & 3)) + (c & 3)] = R[j];
+    }
+    (void)Dt;
+    return !(dmin > 0.0f);
+  }
+
+  static __device__ void run(const StepArgs<float> &a, int32_t row, int64_t nRatings, unsigned char *smem) {
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int k = a.k;
+    float *S = reinterpret_cast<float *>(smem);
+    float *bvec = reinterpret_cast<float *>(smem + C::VEC_OFF), *zvec = bvec + NB * 16, *xvec = zvec + NB * 16;
+    float *Dt = reinterpret_cast<float *>(smem + C::DT_OFF);
+    int *flag = reinterpret_cast<int *>(smem + C::FLAG_OFF);
+    const float lam = (float)(a.lambda * (double)nRatings);
+    const int off = wg_tile_lane_off(lane) >> 2;
+    // diagonal: + lam on real indices, 1 on padded ones
+    for (int i = tid; i < NB * 16; i += kWgThreads) {
+      const int r = i & 15;
+      tile(S, i >> 4, i >> 4)[r * 16 + 4 * ((r >> 2) ^ ((r >> 1) & 3)) + (r & 3)] += (i < k) ? lam : 1.0f;
+    }
+    if (tid == 0) *flag = 0;
+    __syncthreads();
+    bool bad = false;
+    if (wave == 0) bad = factor_diag(S, Dt, 0, k, lane);
+    __syncthreads();
+    for (int J = 0; J < NB; ++J) {
+      // ---- panel: U[J][bj] = W T[J][bj]; wave 7 also z_J = W b_J = V^T b_J
+      {
+        const acc_t Wop = ld(tile(S, J, J), off);  // A operand: W[c][4g + q]
+        for (int bj = J + 1 + wave; bj < NB; bj += kWgWaves) {
+          float *T = tile(S, J, bj);
+          const acc_t B = ld(T, off);             // B operand: T[4g + q][c]
+          acc_t P = acc_t{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) P = Tr::mma(Wop[q], B[q], P);
+          st(T, off, P);
+        }
+        if (wave == kWgWaves - 1) {
+          const acc_t brow = *reinterpret_cast<const acc_t *>(bvec + J * 16 + 4 * g);
+          const float z = matvec_t(Wop, brow);  // V = W^T in (row, col) terms: lane (g, c) holds V[4g+t][c]
+          if (g == 0) zvec[J * 16 + c] = z;
+        }
+      }
+      __syncthreads();
+      if (J + 1 == NB) break;
+      // ---- trailing update with look-ahead; rhs update by the waves 1..7
+      if (wave == 0) {
+        float *T = tile(S, J + 1, J + 1);
+        const acc_t Pi = ld(tile(S, J, J + 1), off);
+        acc_t t = ld(T, off);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t = Tr::mma(-Pi[q], Pi[q], t);
+        st(T, off, t);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        bad = factor_diag(S, Dt, J + 1, k, lane) || bad;
+      } else {
+        int e = 0;
+        for (int bi = J + 1; bi < NB; ++bi) {
+          acc_t Pi = acc_t{0.0f, 0.0f, 0.0f, 0.0f};
+          bool have = false;
+          for (int bj = bi; bj < NB; ++bj) {
+            if (bi == J + 1 && bj == J + 1) continue;  // wave 0's
+            if ((e++ % (kWgWaves - 1)) != wave - 1) continue;
+            if (!have) {
+              Pi = ld(tile(S, J, bi), off);
+              have = true;
+            }
+            const acc_t Pj = ld(tile(S, J, bj), off);
+            float *T = tile(S, bi, bj);
+            acc_t t = ld(T, off);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t = Tr::mma(-Pi[q], Pj[q], t);
+            st(T, off, t);
+          }
+        }
+        // b_bj -= U[J][bj]^T z_J
+        const acc_t zrow = *reinterpret_cast<const acc_t *>(zvec + J * 16 + 4 * g);
+        for (int bj = J + 1 + (wave - 1); bj < NB; bj += kWgWaves - 1) {
+          const acc_t U = ld(tile(S, J, bj), off);
+          const float d = matvec_t(U, zrow);
+          if (g == 0) bvec[bj * 16 + c] -= d;
+        }
+      }
+      __syncthreads();
+    }
+    // ---- back substitution, right-looking: x_J = V_J z_J; z_bi -= U[bi][J] x_J for bi < J
+    for (int J = NB - 1; J >= 0; --J) {
+      if (wave == 0) {
+        const acc_t V = ld(tile(S, J, J), off);
+        const acc_t x = matvec_n(V, zvec[J * 16 + c]);
+        if (c == 0) *reinterpret_cast<acc_t *>(xvec + J * 16 + 4 * g) = x;
+      }
+      __syncthreads();
+      if (J == 0) break;
+      {
+        const float xc = xvec[J * 16 + c];
+        for (int bi = wave; bi < J; bi += kWgWaves) {
+          const acc_t U = ld(tile(S, bi, J), off);
+          const acc_t d = matvec_n(U, xc);
+          if (c == 0) {
+            acc_t z = *reinterpret_cast<acc_t *>(zvec + bi * 16 + 4 * g);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) z[t] -= d[t];
+            *reinterpret_cast<acc_t *>(zvec + bi * 16 + 4 * g) = z;
+          }
+        }
+      }
+      __syncthreads();
+    }
+    float *out = a.solved + (int64_t)row * k;
+    float chk = 0.0f;
+    for (int i = tid; i < k; i += kWgThreads) {
+      const float x = xvec[i];
+      out[i] = x;
+      chk = fmaf(x, 0.0f, chk);
+    }
+    if (!(chk == 0.0f)) atomicOr(flag, 1);  // NaN / Inf in the input ends up in x
+    if (bad && lane == 0) atomicOr(flag, 1);
+    __syncthreads();
+    if (tid == 0 && *flag) {
+      atomicAdd(&a.err->count, 1);
+      a.err->firstRow = row;
+    }
+  }
+};
+
+// whole rows: Gramian + solve, persistent over units [firstFused + blockIdx.x, firstFused + count) by gridDim.x
+template <int NB>
+__global__ __launch_bounds__(kWgThreads, 2) void als_wg_gram_solve_kernel(StepArgs<float> a, int32_t count) {
+  using G = WgGram<NB>;
+  using C = WgCfg<NB>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, l16 = tid & 15, rho = tid >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  typename G::Stage s0, s1;
+  typename G::Meta m2;
+  int32_t ui = blockIdx.x;
+  if (ui >= count) return;
+  Unit u = a.units[a.firstFused + ui];
+  auto prefetch = [&](const Unit &v) {
+    const int64_t n = v.end - v.beg;
+    const typename G::Meta m0 = G::load_meta(a, v.beg, n, 0, rho), m1 = G::load_meta(a, v.beg, n, 1, rho);
+    m2 = G::load_meta(a, v.beg, n, 2, rho);
+    G::load_rows(s0, a, m0, l16);
+    G::load_rows(s1, a, m1, l16);
+  };
+  prefetch(u);
+  while (true) {
+    typename G::acc_t acc[G::NACC];
+    float bacc[4][4];
+    G::run(a, u.beg, u.end - u.beg, smem, acc, bacc, s0, s1, m2);
+    G::store_tiles_w(wave, acc, reinterpret_cast<float *>(smem), lane);
+    G::reduce_b(bacc, smem);
+    const int32_t row = u.row;
+    const int64_t n = u.end - u.beg;
+    ui += gridDim.x;
+    const bool more = ui < count;
+    if (more) {
+      u = a.units[a.firstFused + ui];
+      prefetch(u);  // the next row's first steps land during this row's solve
+    }
+    WgSolve<NB>::run(a, row, n, smem);
+    if (!more) break;
+    __syncthreads();  // the image is dead: the next row's planes may overwrite it
+  }
+  (void)sizeof(C);
+}
+
+// chunks of heavy rows: Gramian -> slab (image layout + b), persistent over units [0, count)
+template <int NB>
+__global__ __launch_bounds__(kWgThreads, 2) void als_wg_gram_slab_kernel(StepArgs<float> a, int32_t count) {
+  using G = WgGram<NB>;
+  using C = WgCfg<NB>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, l16 = tid & 15, rho = tid >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int32_t ui = blockIdx.x; ui < count; ui += gridDim.x) {
+    const Unit u = a.units[ui];
+    const int64_t n = u.end - u.beg;
+    typename G::Stage s0, s1;
+    const typename G::Meta m0 = G::load_meta(a, u.beg, n, 0, rho), m1 = G::load_meta(a, u.beg, n, 1, rho);
+    typename G::Meta m2 = G::load_meta(a, u.beg, n, 2, rho);
+    G::load_rows(s0, a, m0, l16);
+    G::load_rows(s1, a, m1, l16);
+    typename G::acc_t acc[G::NACC];
+    float bacc[4][4];
+    G::run(a, u.beg, n, smem, acc, bacc, s0, s1, m2);
+    float *slab = a.slabs + (int64_t)u.slab * C::SLAB_FLOATS;
+    G::store_tiles_w(wave, acc, slab, lane);
+    G::reduce_b(bacc, smem);
+    if (tid < NB * 16) slab[(int64_t)C::NT * 256 + tid] = reinterpret_cast<const float *>(smem + C::VEC_OFF)[tid];
+    __syncthreads();
+  }
+}
+
+// split rows: slabs summed in slab order -> image -> solve, persistent over split rows [0, count)
+template <int NB>
+__global__ __launch_bounds__(kWgThreads, 2) void als_wg_reduce_solve_kernel(StepArgs<float> a, int32_t count) {
+  using C = WgCfg<NB>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  float *S = reinterpret_cast<float *>(smem);
+  float *bvec = reinterpret_cast<float *>(smem + C::VEC_OFF);
+  for (int32_t si = blockIdx.x; si < count; si += gridDim.x) {
+    const SplitRow sr = a.split[si];
+    constexpr int NQ = C::NT * 64;  // float4s of the image
+    for (int q0 = tid; q0 < NQ; q0 += 4 * kWgThreads) {
+      wg_f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = wg_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      for (int sl = 0; sl < sr.nslabs; ++sl) {
+        const wg_f32x4 *src = reinterpret_cast<const wg_f32x4 *>(a.slabs + (int64_t)(sr.slab0 + sl) * C::SLAB_FLOATS);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int q = q0 + u * kWgThreads;
+          if (q < NQ) v[u] += src[q];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int q = q0 + u * kWgThreads;
+        if (q < NQ) reinterpret_cast<wg_f32x4 *>(S)[q] = v[u];
+      }
+    }
+    if (tid < NB * 16) {
+      float t = 0.0f;
+      for (int sl = 0; sl < sr.nslabs; ++sl) t += a.slabs[(int64_t)(sr.slab0 + sl) * C::SLAB_FLOATS + (int64_t)C::NT * 256 + tid];
+      bvec[tid] = t;
+    }
+    __syncthreads();
+    WgSolve<NB>::run(a, sr.row, sr.n, smem);
+    __syncthreads();
+  }
+}
+
+}  // namespace ycnr

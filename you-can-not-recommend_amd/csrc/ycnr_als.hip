@@ -6,7 +6,7 @@
 // a HIP device every entry point fails with YCNR_ERR_HIP.
 #include "../../include/ycnr_als.h"
 #include "als_kernels.hip.h"
-#include "als_big_kernels.hip.h"
+#include "als_wg_kernels.hip.h"
 #include "prep_kernels.hip.h"
 #include <hipcub/hipcub.hpp>
 #include "prep_kernels.hip.h"
@@ -49,8 +49,9 @@ int fail(int code, const char *fmt, ...) {
   } while (0)
 
 constexpr int kMaxFactors = 128;     // float64, and the one-wave-per-row float32 kernels
-constexpr int kMaxFactorsBig = 256;  // float32 through the 4-wave kernels of als_big_kernels.hip.h
-constexpr size_t kBigArenaBytes = (size_t)16 << 30;  // slabs of the big path are produced and consumed in batches
+constexpr int kMaxFactorsBig = 256;  // float32 through the workgroup-per-row kernels of als_wg_kernels.hip.h
+constexpr int kWgChunk = 8192;       // ratings per chunk of a row that is split over workgroups (k > 128)
+constexpr int kWgFusedMax = 16384;   // longest row one workgroup takes whole (k > 128)
 constexpr int kDefaultChunk = 1024;  // ratings per split unit (and the largest fused row)
 constexpr int kMaxSlabsPerRow = 64;  // heavier rows get proportionally longer chunks
 constexpr int64_t kBandBytes = (int64_t)96 << 20;  // slice of the fixed matrix one band of chunks gathers from (cache-sized)
@@ -87,13 +88,7 @@ struct Schedule {
   int64_t nPrimal = 0, dualFirst[kMaxDualBlocks + 1] = {}, dualCount[kMaxDualBlocks + 1] = {};
   int64_t dualRows = 0, dualRatings = 0;
   double dualFlops = 0;  // flops the dual form executes for those rows: G = Y Y^T (symmetric), Cholesky, x = Y^T w
-  // big path (k > 128): consecutive rows whose slabs fit the arena together
-  struct Batch {
-    int64_t unitFirst, unitCount, splitFirst, splitCount;
-  };
-  std::vector<Batch> batches;
   void release() {
-    batches.clear();
     if (dUnits) (void)hipFree(dUnits);
     if (dSplit) (void)hipFree(dSplit);
     if (dSlabs) (void)hipFree(dSlabs);
@@ -167,13 +162,11 @@ void build_schedule(const int64_t *rowPtr, int64_t rowBegin, int64_t nRows, int 
 struct EnvFlags {
   bool noDualX6, noX6d, noFusedX6d, noOverlap, ignoreNumeric;
   size_t k1LdsPad;
-  int bandMb;  // < 0: default
 };
 const EnvFlags &env_flags() {
   static const EnvFlags f = {getenv("YCNR_NO_DUAL_X6") != nullptr, getenv("YCNR_NO_X6D") != nullptr, getenv("YCNR_NO_FUSED_X6D") != nullptr,
                              getenv("YCNR_NO_OVERLAP") != nullptr, getenv("YCNR_IGNORE_NUMERIC") != nullptr,
-                             getenv("YCNR_K1_LDSPAD") ? (size_t)atoi(getenv("YCNR_K1_LDSPAD")) : 0,
-                             getenv("YCNR_BAND_MB") ? atoi(getenv("YCNR_BAND_MB")) : -1};
+                             getenv("YCNR_K1_LDSPAD") ? (size_t)atoi(getenv("YCNR_K1_LDSPAD")) : 0};
   return f;
 }
 
@@ -333,53 +326,76 @@ int launch_nb(const StepArgs<T> &args, int64_t nUnits, int64_t nSplitUnits, int6
   return launch_nbe<T, NB, LDS_SOLVER, false, false>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp);
 }
 
-template <int NB>
-int launch_big_nb(StepArgs<float> args, const std::vector<Schedule::Batch> &batches, hipStream_t stream) {
-  auto kg = als_gram_big_kernel<NB>;
-  auto ks = als_solve_big_kernel<NB>;
-  const size_t lds = SolveBig<NB>::lds_bytes();
-  if (int rcl = set_max_lds(reinterpret_cast<const void *>(ks), lds)) return rcl;
-  for (const Schedule::Batch &b : batches) {
-    if (b.unitCount == 0) continue;
-    args.firstFused = (int32_t)b.unitFirst;
-    args.firstDual = (int32_t)b.splitFirst;
-    hipLaunchKernelGGL(kg, dim3((unsigned)b.unitCount), dim3(256), 0, stream, args);
-    HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(ks, dim3((unsigned)b.splitCount), dim3(256), lds, stream, args);
-    HIP_TRY(hipGetLastError());
-  }
-  return YCNR_OK;
+int device_cus() {
+  static std::mutex mu;
+  static std::map<int, int> cus;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = cus.find(dev);
+  if (it != cus.end()) return it->second;
+  int n = 0;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+  cus[dev] = n;
+  return n;
 }
 
-// 128 < k <= 256, float32: [big batches: Gramian slabs + LDS block Cholesky] then the dual classes
-int launch_step_big(const StepArgs<float> &args, const std::vector<Schedule::Batch> &batches, hipStream_t stream,
-                    hipEvent_t *ev, const DualPlan &dp) {
-  const int nb = (args.k + 15) / 16;
+// 128 < k <= 256, float32 (als_wg_kernels.hip.h): one 512-thread workgroup per row or chunk, one
+// workgroup per CU, persistent over its share of the units:
+//   [chunks of heavy rows -> slabs] [whole rows: Gramian + solve] [dual classes] [slabs -> solve]
+template <int NB>
+int launch_wg_nb(StepArgs<float> args, int64_t nSplitUnits, int64_t nPrimal, int64_t nSplit, hipStream_t stream, hipEvent_t *ev,
+                 const DualPlan &dp) {
+  auto k0 = als_wg_gram_slab_kernel<NB>;
+  auto k1 = als_wg_gram_solve_kernel<NB>;
+  auto k2 = als_wg_reduce_solve_kernel<NB>;
+  const size_t lds = WgCfg<NB>::LDS_BYTES;
+  if (int rc = set_max_lds(reinterpret_cast<const void *>(k0), lds)) return rc;
+  if (int rc = set_max_lds(reinterpret_cast<const void *>(k1), lds)) return rc;
+  if (int rc = set_max_lds(reinterpret_cast<const void *>(k2), lds)) return rc;
+  const int64_t cus = device_cus();
+  args.firstFused = (int32_t)nSplitUnits;
   if (ev) HIP_TRY(hipEventRecord(ev[0], stream));
-  int rc;
-  switch (nb) {
-    case 9: rc = launch_big_nb<9>(args, batches, stream); break;
-    case 10: rc = launch_big_nb<10>(args, batches, stream); break;
-    case 11: rc = launch_big_nb<11>(args, batches, stream); break;
-    case 12: rc = launch_big_nb<12>(args, batches, stream); break;
-    case 13: rc = launch_big_nb<13>(args, batches, stream); break;
-    case 14: rc = launch_big_nb<14>(args, batches, stream); break;
-    case 15: rc = launch_big_nb<15>(args, batches, stream); break;
-    case 16: rc = launch_big_nb<16>(args, batches, stream); break;
-    default: return fail(YCNR_ERR_UNSUPPORTED, "factorsCount %d is outside the big path", args.k);
+  if (nSplitUnits > 0) {
+    hipLaunchKernelGGL(k0, dim3((unsigned)std::min(nSplitUnits, cus)), dim3(kWgThreads), lds, stream, args, (int32_t)nSplitUnits);
+    HIP_TRY(hipGetLastError());
   }
-  if (rc) return rc;
   if (ev) HIP_TRY(hipEventRecord(ev[1], stream));
+  if (nPrimal > 0) {
+    hipLaunchKernelGGL(k1, dim3((unsigned)std::min(nPrimal, cus)), dim3(kWgThreads), lds, stream, args, (int32_t)nPrimal);
+    HIP_TRY(hipGetLastError());
+  }
   if (ev) HIP_TRY(hipEventRecord(ev[2], stream));
   if (dp.nPrimal >= 0) {
-    DualPlan serial = dp;  // this path keeps its kernels in stream order
+    DualPlan serial = dp;  // these kernels fill the register file: the dual classes follow in stream order
     serial.nSide = 0;
-    rc = launch_duals<float>(args, serial, stream);
+    int rc = launch_duals<float>(args, serial, stream);
     if (rc) return rc;
   }
   if (ev) HIP_TRY(hipEventRecord(ev[3], stream));
+  if (nSplit > 0) {
+    hipLaunchKernelGGL(k2, dim3((unsigned)std::min(nSplit, cus)), dim3(kWgThreads), lds, stream, args, (int32_t)nSplit);
+    HIP_TRY(hipGetLastError());
+  }
   if (ev) HIP_TRY(hipEventRecord(ev[4], stream));
   return YCNR_OK;
+}
+
+int launch_step_big(const StepArgs<float> &args, int64_t nUnits, int64_t nSplitUnits, int64_t nSplit, hipStream_t stream,
+                    hipEvent_t *ev, const DualPlan &dp) {
+  if (nUnits > 0x7fffffffLL) return fail(YCNR_ERR_UNSUPPORTED, "too many work units for one launch (%lld)", (long long)nUnits);
+  const int64_t nPrimal = dp.nPrimal >= 0 ? dp.nPrimal : nUnits - nSplitUnits;
+  switch ((args.k + 15) / 16) {
+    case 9: return launch_wg_nb<9>(args, nSplitUnits, nPrimal, nSplit, stream, ev, dp);
+    case 10: return launch_wg_nb<10>(args, nSplitUnits, nPrimal, nSplit, stream, ev, dp);
+    case 11: return launch_wg_nb<11>(args, nSplitUnits, nPrimal, nSplit, stream, ev, dp);
+    case 12: return launch_wg_nb<12>(args, nSplitUnits, nPrimal, nSplit, stream, ev, dp);
+    case 13: return launch_wg_nb<13>(args, nSplitUnits, nPrimal, nSplit, stream, ev, dp);
+    case 14: return launch_wg_nb<14>(args, nSplitUnits, nPrimal, nSplit, stream, ev, dp);
+    case 15: return launch_wg_nb<15>(args, nSplitUnits, nPrimal, nSplit, stream, ev, dp);
+    case 16: return launch_wg_nb<16>(args, nSplitUnits, nPrimal, nSplit, stream, ev, dp);
+    default: return fail(YCNR_ERR_UNSUPPORTED, "factorsCount %d is outside the workgroup-per-row path", args.k);
+  }
 }
 
 template <typename T>
@@ -1064,35 +1080,12 @@ static int build_part(ycnr_als *h, int side, const int64_t *rowPtr, const int32_
   std::vector<SplitRow> split;
   int64_t nSlabs = 0, solved = 0;
   const bool big = h->opt.factorsCount > kMaxFactors;
-  const int chunkRatings = h->autoChunk && !big ? auto_chunk(hp[rowEnd - rowBegin] - hp[0]) : h->opt.chunkRatings;
-  build_schedule(hp.data(), rowBegin, rowEnd - rowBegin, chunkRatings, units, split, nSlabs, solved,
-                 big ? dual_max_ratings(h->opt) : -1, std::min(chunkRatings, h->opt.chunkRatings));
-  std::vector<Schedule::Batch> batches;
+  // k > 128: a unit is a whole workgroup's work, so chunks are long (a slab is 140 KB at k = 256)
+  // (an explicit options.chunkRatings is honoured there too: tests cut short rows into chunks with it)
+  const int chunkRatings = h->autoChunk ? (big ? kWgChunk : auto_chunk(hp[rowEnd - rowBegin] - hp[0])) : h->opt.chunkRatings;
+  build_schedule(hp.data(), rowBegin, rowEnd - rowBegin, chunkRatings, units, split, nSlabs, solved, -1,
+                 big && h->autoChunk ? kWgFusedMax : std::min(chunkRatings, h->opt.chunkRatings));
   int64_t arenaSlabs = nSlabs;
-  if (big && nSlabs > 0) {
-    // cut the split rows into batches whose slabs fit the arena; slab numbers restart per batch
-    const int64_t slabBytes = slab_elems(slab_nb(h->opt.factorsCount)) * (int64_t)sizeof(float);
-    int64_t cap = std::max<int64_t>(1, (int64_t)(kBigArenaBytes / slabBytes));
-    for (const SplitRow &sr : split) cap = std::max<int64_t>(cap, sr.nslabs);
-    Schedule::Batch cur{0, 0, 0, 0};
-    int64_t used = 0, unitPos = 0;
-    arenaSlabs = 0;
-    for (size_t r = 0; r < split.size(); ++r) {
-      if (used + split[r].nslabs > cap) {
-        batches.push_back(cur);
-        cur = Schedule::Batch{unitPos, 0, (int64_t)r, 0};
-        used = 0;
-      }
-      split[r].slab0 = (int32_t)used;
-      for (int p = 0; p < split[r].nslabs; ++p) units[unitPos + p].slab = (int32_t)(used + p);
-      used += split[r].nslabs;
-      unitPos += split[r].nslabs;
-      cur.unitCount += split[r].nslabs;
-      cur.splitCount += 1;
-      arenaSlabs = std::max(arenaSlabs, used);
-    }
-    batches.push_back(cur);
-  }
   // Band-major chunks (unless YCNR_FLAG_NO_BANDS): when the fixed matrix is far larger than the
   // last-level cache, cut every split row at the same column-id boundaries ("bands" of
   // kBandBytes of the fixed matrix) instead of every `chunk` ratings, and run the chunks band
@@ -1103,7 +1096,7 @@ static int build_part(ycnr_als *h, int side, const int64_t *rowPtr, const int32_
     const int64_t fixedRows = h->rows(1 - side);
     const int64_t rowBytes = (int64_t)h->opt.factorsCount * (int64_t)h->ts();
     int64_t bandBytes = kBandBytes;
-    if (env_flags().bandMb >= 0) bandBytes = (int64_t)env_flags().bandMb << 20;
+    if (const char *e = getenv("YCNR_BAND_MB")) bandBytes = (int64_t)atoi(e) << 20;  // per upload, not per half-step: read live (tests set it)
     if (!big && nSlabs > 1 && !(h->opt.flags & YCNR_FLAG_NO_BANDS) && bandBytes > 0 && fixedRows * rowBytes > 2 * bandBytes) {
       // at most kMaxSlabsPerRow / 2 bands, so that a row present in every band still has chunks to
       // spare (very large fixed matrices get wider bands instead of a failed upload)
@@ -1177,7 +1170,6 @@ static int build_part(ycnr_als *h, int side, const int64_t *rowPtr, const int32_
   S.nSplit = (int64_t)split.size();
   S.nSlabs = nSlabs;
   S.solvedRows = solved;
-  S.batches = batches;
   S.fusedRatings = 0;
   for (size_t i = (size_t)nSlabs; i < units.size(); ++i) S.fusedRatings += units[i].end - units[i].beg;
   // whole rows are sorted by descending length: rows short enough for the dual form are the
@@ -1205,7 +1197,8 @@ static int build_part(ycnr_als *h, int side, const int64_t *rowPtr, const int32_
   if (S.nSplit) {
     HIP_TRY(hipMalloc(&S.dSplit, sizeof(SplitRow) * split.size()));
     HIP_TRY(hipMemcpy(S.dSplit, split.data(), sizeof(SplitRow) * split.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipMalloc(&S.dSlabs, (size_t)arenaSlabs * slab_regs(h->opt, side) * 64 * h->ts()));
+    const size_t slabElems = big ? (size_t)wg_slab_floats(slab_nb(h->opt.factorsCount)) : (size_t)slab_regs(h->opt, side) * 64;
+    HIP_TRY(hipMalloc(&S.dSlabs, (size_t)arenaSlabs * slabElems * h->ts()));
   }
   return YCNR_OK;
 }
@@ -1366,7 +1359,7 @@ static int launch_part(ycnr_als *h, int side, Part &part) {
         }
       }
     }
-    if (h->opt.factorsCount > kMaxFactors) return launch_step_big(a, S.batches, h->stream, part.ev, dp);
+    if (h->opt.factorsCount > kMaxFactors) return launch_step_big(a, S.nUnits, S.nSlabs, S.nSplit, h->stream, part.ev, dp);
     return launch_step<float>(a, S.nUnits, S.nSlabs, S.nSplit, h->stream, part.ev, (h->opt.flags & YCNR_FLAG_LDS_SOLVER) != 0, dp,
                               use_valu_edge(h->opt), use_slab_x6(h->opt, side));
   }
