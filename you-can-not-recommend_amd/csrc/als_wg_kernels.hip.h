@@ -52,6 +52,19 @@ typedef unsigned wg_u32x2 __attribute__((ext_vector_type(2)));
 typedef short wg_s16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
 
+// In-kernel stamps (diagnostic builds only, -DYCNR_WG_STAMPS): lane 0 of waves 0 and 1 of workgroup 0
+// writes the shader clock at phase boundaries of the FIRST row it solves into the words behind
+// ErrInfo (the host allocates 64 KB there); ycnr_als_sync dumps them when YCNR_DUMP_STAMPS names a file.
+#ifdef YCNR_WG_STAMPS
+#define YCNR_STAMP(a, slot)                                                                                   \
+  do {                                                                                                        \
+    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 2 && (slot) < 250)                 \
+      reinterpret_cast<unsigned long long *>((a).err)[8 + (threadIdx.x >> 6) * 256 + (slot)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define YCNR_STAMP(a, slot) do { } while (0)
+#endif
+
 template <int NB>
 struct WgCfg {
   static constexpr int NT = tile_count(NB);
@@ -129,13 +142,21 @@ struct WgGram {
 
   // split + plane writes of one stage into plane buffer `buf` (byte address of the buffer in LDS)
   static __device__ __forceinline__ void split_store(const Stage &st, float (&bacc)[4][4], unsigned char *buf, int wofs, int l16) {
+#ifdef YCNR_WG_ABLATE_SPLIT  // timing experiments only: loads stay alive, nothing split or stored
+#pragma unroll
+    for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(st.x[j]));
+    return;
+#endif
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       if (64 * j >= NB * 16) continue;
       if (4 * j + (l16 >> 2) >= NB) continue;  // a block beyond the padded matrix (columns >= 16 NB)
       unsigned h[2], m[2], l[2];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) bacc[j][e] = fmaf(st.x[j][e], st.r, bacc[j][e]);
+      for (int e = 0; e < 4; ++e) {
+        bacc[j][e] = fmaf(st.x[j][e], st.r, bacc[j][e]);
+        asm volatile("" : "+v"(bacc[j][e]));  // no v_pk_fma_f32: packed float32 beside MFMAs is slower than two v_fma
+      }
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
         const float x0 = st.x[j][2 * jj], x1 = st.x[j][2 * jj + 1];
@@ -175,6 +196,10 @@ struct WgGram {
   }
   // acc += A^T B with float32-equivalent products: the six significant bf16 products, smallest first
   static __device__ __forceinline__ acc_t mma6(const Op &A, const Op &B, acc_t acc) {
+#ifdef YCNR_WG_ABLATE_MFMA  // timing experiments only: operands stay alive, no products
+    asm volatile("" ::"v"(A.p[0]), "v"(A.p[1]), "v"(A.p[2]), "v"(B.p[0]), "v"(B.p[1]), "v"(B.p[2]));
+    return acc;
+#endif
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A.p[1], B.p[1], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A.p[0], B.p[2], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A.p[2], B.p[0], acc, 0, 0, 0);
@@ -196,7 +221,7 @@ struct WgGram {
 #pragma unroll
       for (int bj = R::r0; bj < NB; ++bj) {
         Op Bn = B;
-        if (bj + 1 < NB) Bn = read_op(buf, bj + 1, rofs);
+        if (bj + 1 < NB) Bn = read_op(buf, bj + 1, rofs);  // (two blocks ahead bought nothing: the step is bound by the matrix pipe)
         asm volatile("" ::: "memory");
         if (R::two && bj == R::r1) A1 = B;
         acc[bj - R::r0] = mma6(A0, B, acc[bj - R::r0]);
@@ -206,6 +231,9 @@ struct WgGram {
     }
   }
   static __device__ __forceinline__ void mma_step_w(int wave, acc_t (&acc)[NACC], const unsigned char *buf, int rofs) {
+#ifdef YCNR_WG_ABLATE_MMASTEP  // timing experiments only
+    return;
+#endif
     switch (wave) {
       case 0: mma_step<0>(acc, buf, rofs); break;
       case 1: mma_step<1>(acc, buf, rofs); break;
@@ -273,19 +301,36 @@ struct WgGram {
     load_rows(s0, a, m2, l16);
     Meta m3 = load_meta(a, beg, n, 3, rho);
     __syncthreads();
+    // Within a phase a wave writes one plane buffer and reads the other, in either order.  Waves 0-3
+    // split first and multiply second, waves 4-7 the other way round: the two waves of a SIMD (w and
+    // w + 4) then keep its vector ALU and its matrix pipe busy at the same time instead of both
+    // splitting (matrix pipe idle) and then both multiplying.
+    const bool splitFirst = wave < 4;
     for (int64_t s = 0; s < nsteps; s += 2) {
       // phase s: planes of step s + 1 (always written: zeros past the end), products of step s
-      split_store(s1, bacc, buf1, wofs, l16);
-      load_rows(s1, a, m3, l16);                        // step s + 3
+      if (splitFirst) {
+        split_store(s1, bacc, buf1, wofs, l16);
+        load_rows(s1, a, m3, l16);                      // step s + 3
+      }
       Meta m4 = load_meta(a, beg, n, s + 4, rho);
       mma_step_w(wave, acc, buf0, rofs);
+      if (!splitFirst) {
+        split_store(s1, bacc, buf1, wofs, l16);
+        load_rows(s1, a, m3, l16);
+      }
       __syncthreads();
       if (s + 1 >= nsteps) break;
       // phase s + 1
-      split_store(s0, bacc, buf0, wofs, l16);           // step s + 2
-      load_rows(s0, a, m4, l16);                        // step s + 4
+      if (splitFirst) {
+        split_store(s0, bacc, buf0, wofs, l16);         // step s + 2
+        load_rows(s0, a, m4, l16);                      // step s + 4
+      }
       m3 = load_meta(a, beg, n, s + 5, rho);
       mma_step_w(wave, acc, buf1, rofs);
+      if (!splitFirst) {
+        split_store(s0, bacc, buf0, wofs, l16);
+        load_rows(s0, a, m4, l16);
+      }
       __syncthreads();
     }
   }
@@ -351,43 +396,67 @@ struct WgSolve {
     return y;
   }
 
+  // value of lane N of the caller's 16-lane row, in every lane of the row (DPP row_newbcast)
+  template <int N>
+  static __device__ __forceinline__ float row_bcast(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + N, 0xF, 0xF, true));
+  }
+  template <int P, int Jn>
+  struct Pivot {
+    static __device__ __forceinline__ void updates(float (&R)[16], float (&X)[16]) {
+      if constexpr (Jn < 16) {
+        const float m = row_bcast<Jn>(R[P]);  // L[Jn][P]
+        R[Jn] = fmaf(-R[P], m, R[Jn]);
+        X[Jn] = fmaf(-X[P], m, X[Jn]);
+        Pivot<P, Jn + 1>::updates(R, X);
+      }
+    }
+  };
+  template <int P>
+  static __device__ __forceinline__ void pivot(float (&R)[16], float (&X)[16], float &dmin) {
+    const float d = row_bcast<P>(R[P]);  // D[P][P] after the updates of the pivots before it
+    dmin = fminf(dmin, d);
+    const float rs = __builtin_amdgcn_rsqf(d);
+    R[P] *= rs;  // column P of L (lane i: L[i][P])
+    X[P] *= rs;
+    Pivot<P, P + 1>::updates(R, X);
+  }
+
   // wave 0: factor the diagonal tile (J, J) in place: on return it holds V = U_JJ^-1 (upper triangular,
   // image layout), i.e. image[c][r] = W[c][r] with W = L^-1.  Returns true when a real pivot was not positive.
+  // Lane (g, i) holds row i of D in R (every 16-lane row carries a copy) and row i of the identity
+  // in X; the column operations that turn D into L turn the identity into L^-T.  The multipliers
+  // L[j][p] come from lane j of the lane's own row by DPP (row_newbcast): no v_readlane, no SGPR hops.
   static __device__ __forceinline__ bool factor_diag(float *S, float *Dt, int J, int k, int lane) {
     const int g = lane >> 4, c = lane & 15;
     float *T = tile(S, J, J);
-    // lane c of groups 0 / 2: row c of D (= column c, D is symmetric); groups 1 / 3: row c of the identity
-    float R[16];
+    float R[16], X[16];
     {
-      const bool xlane = (g & 1) != 0;
       const int sw = (c >> 1) & 3;
 #pragma unroll
       for (int m4 = 0; m4 < 4; ++m4) {
-        const acc_t v = *reinterpret_cast<const acc_t *>(T + c * 16 + 4 * (m4 ^ sw));
+        const acc_t v = *reinterpret_cast<const acc_t *>(T + c * 16 + 4 * (m4 ^ sw));  // row c = column c (D is symmetric)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) R[4 * m4 + t] = xlane ? (c == 4 * m4 + t ? 1.0f : 0.0f) : v[t];
+        for (int t = 0; t < 4; ++t) {
+          R[4 * m4 + t] = v[t];
+          X[4 * m4 + t] = c == 4 * m4 + t ? 1.0f : 0.0f;
+        }
       }
     }
     float dmin = 3.0e38f;
-#pragma unroll
-    for (int p = 0; p < 16; ++p) {
-      if (J == NB - 1 && J * 16 + p >= k) break;  // padded pivots are rows of the identity
-      const float d = Sm::readlane(R[p], p);
-      dmin = fminf(dmin, d);
-      const float rs = __builtin_amdgcn_rsqf(d);
-      R[p] *= rs;
-      float mult[16];
-#pragma unroll
-      for (int j = p + 1; j < 16; ++j) mult[j] = Sm::readlane(R[p], j);
-#pragma unroll
-      for (int j = p + 1; j < 16; ++j) R[j] = fmaf(-R[p], mult[j], R[j]);
-    }
-    // lane (1, c) holds R[j] = L^-T[c][j] = W[j][c]: image[j][r = c]
+    // padded pivots (index >= k; only the last tile has any) are rows of the identity (diagonal 1, nothing
+    // else): their scale is 1 and their multipliers 0, so running them is exact, and 16 unconditional
+    // pivots keep R and X in fixed registers (a guard per pivot made the compiler copy and spill them)
+    pivot<0>(R, X, dmin);  pivot<1>(R, X, dmin);  pivot<2>(R, X, dmin);  pivot<3>(R, X, dmin);
+    pivot<4>(R, X, dmin);  pivot<5>(R, X, dmin);  pivot<6>(R, X, dmin);  pivot<7>(R, X, dmin);
+    pivot<8>(R, X, dmin);  pivot<9>(R, X, dmin);  pivot<10>(R, X, dmin); pivot<11>(R, X, dmin);
+    pivot<12>(R, X, dmin); pivot<13>(R, X, dmin); pivot<14>(R, X, dmin); pivot<15>(R, X, dmin);
+    (void)k;
+    // X[j] = L^-T[c][j] = W[j][c] = element (row c, col j) of the tile; lane group g writes columns 4g .. 4g+3
     __builtin_amdgcn_s_waitcnt(0xc07f);  // the tile reads above have returned before the tile is overwritten
-    if (g == 1) {
 #pragma unroll
-      for (int j = 0; j < 16; ++j) T[j * 16 + 4 * ((c >> 2) ^ ((j >> 1) & 3)) + (c & 3)] = R[j];
-    }
+    for (int j = 0; j < 16; ++j)
+      if ((j >> 2) == g) T[j * 16 + 4 * ((c >> 2) ^ ((j >> 1) & 3)) + (c & 3)] = X[j];
     (void)Dt;
     return !(dmin > 0.0f);
   }
@@ -399,7 +468,7 @@ struct WgSolve {
     float *S = reinterpret_cast<float *>(smem);
     float *bvec = reinterpret_cast<float *>(smem + C::VEC_OFF), *zvec = bvec + NB * 16, *xvec = zvec + NB * 16;
     float *Dt = reinterpret_cast<float *>(smem + C::DT_OFF);
-    int *flag = reinterpret_cast<int *>(smem + C::FLAG_OFF);
+    int *flag = reinterpret_cast<int *>(smem + C::FLAG_OFF), *rowCounter = flag + 1;
     const float lam = (float)(a.lambda * (double)nRatings);
     const int off = wg_tile_lane_off(lane) >> 2;
     // diagonal: + lam on real indices, 1 on padded ones
@@ -408,31 +477,60 @@ struct WgSolve {
       tile(S, i >> 4, i >> 4)[r * 16 + 4 * ((r >> 2) ^ ((r >> 1) & 3)) + (r & 3)] += (i < k) ? lam : 1.0f;
     }
     if (tid == 0) *flag = 0;
+    YCNR_STAMP(a, 0);
     __syncthreads();
+    YCNR_STAMP(a, 1);
     bool bad = false;
+#ifndef YCNR_WG_ABLATE_FACTOR  // timing experiments only
     if (wave == 0) bad = factor_diag(S, Dt, 0, k, lane);
+#endif
+    YCNR_STAMP(a, 2);
     __syncthreads();
+    YCNR_STAMP(a, 3);
+    // The right-hand side is block column NB of the matrix: "tile" (bi, NB) is the 16 x 16 matrix with
+    // b_bi in column 0, kept as 16 floats (lanes c == 0 carry it, the others zeros), so that
+    // z_J = W b_J is one more panel tile and b_bi -= U[J][bi]^T z_J one more trailing update --
+    // MFMAs like the rest, no cross-lane sums.
+    const bool c0 = c == 0;
+    auto ld_rhs = [&](const float *vec, int blk) {
+      const acc_t v = *reinterpret_cast<const acc_t *>(vec + blk * 16 + 4 * g);
+      return c0 ? v : acc_t{0.0f, 0.0f, 0.0f, 0.0f};
+    };
     for (int J = 0; J < NB; ++J) {
-      // ---- panel: U[J][bj] = W T[J][bj]; wave 7 also z_J = W b_J = V^T b_J
+      // ---- panel: U[J][bj] = W T[J][bj] for bj = J+1 .. NB-1, and z_J = W b_J (bj = NB)
+      if (tid == 0) *rowCounter = J + 1;  // rows of the trailing update that follows (read after the barrier)
       {
         const acc_t Wop = ld(tile(S, J, J), off);  // A operand: W[c][4g + q]
-        for (int bj = J + 1 + wave; bj < NB; bj += kWgWaves) {
-          float *T = tile(S, J, bj);
-          const acc_t B = ld(T, off);             // B operand: T[4g + q][c]
-          acc_t P = acc_t{0.0f, 0.0f, 0.0f, 0.0f};
+        // items bj = J+1 .. NB (NB: the right-hand side), at most two per wave (NB <= 16): both at once
+        const int bjA = J + 1 + wave, bjB = bjA + kWgWaves;
+        if (bjA <= NB) {
+          const bool rA = bjA == NB, hasB = bjB <= NB, rB = bjB == NB;
+          float *TA = tile(S, J, rA ? J : bjA), *TB = tile(S, J, (rB || !hasB) ? J : bjB);
+          const acc_t BA = rA ? ld_rhs(bvec, J) : ld(TA, off);  // B operand: T[4g + q][c]
+          const acc_t BB = rB ? ld_rhs(bvec, J) : ld(TB, off);
+          acc_t PA = acc_t{0.0f, 0.0f, 0.0f, 0.0f}, PB = PA;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) P = Tr::mma(Wop[q], B[q], P);
-          st(T, off, P);
-        }
-        if (wave == kWgWaves - 1) {
-          const acc_t brow = *reinterpret_cast<const acc_t *>(bvec + J * 16 + 4 * g);
-          const float z = matvec_t(Wop, brow);  // V = W^T in (row, col) terms: lane (g, c) holds V[4g+t][c]
-          if (g == 0) zvec[J * 16 + c] = z;
+          for (int q = 0; q < 4; ++q) {
+            PA = Tr::mma(Wop[q], BA[q], PA);
+            PB = Tr::mma(Wop[q], BB[q], PB);
+          }
+          if (!rA) st(TA, off, PA);
+          else if (c0) *reinterpret_cast<acc_t *>(zvec + J * 16 + 4 * g) = PA;
+          if (hasB) {
+            if (!rB) st(TB, off, PB);
+            else if (c0) *reinterpret_cast<acc_t *>(zvec + J * 16 + 4 * g) = PB;
+          }
         }
       }
+      YCNR_STAMP(a, 4 + 4 * J);
       __syncthreads();
+      YCNR_STAMP(a, 5 + 4 * J);
       if (J + 1 == NB) break;
-      // ---- trailing update with look-ahead; rhs update by the waves 1..7
+      // ---- trailing update with look-ahead.  Wave 0 updates tile (J+1, J+1) FIRST and factors it; block
+      // rows bi = J+1 .. NB-1 of the update (items bj = bi .. NB, bj = NB: the right-hand side) are
+      // handed out by a counter in LDS, longest first, to whichever wave is free -- wave 0 joins when
+      // its factorization is done.  A row's panel operand is loaded once, its items go two at a time
+      // so that their LDS round trips and dependent MFMA chains overlap.
       if (wave == 0) {
         float *T = tile(S, J + 1, J + 1);
         const acc_t Pi = ld(tile(S, J, J + 1), off);
@@ -441,39 +539,66 @@ struct WgSolve {
         for (int q = 0; q < 4; ++q) t = Tr::mma(-Pi[q], Pi[q], t);
         st(T, off, t);
         __builtin_amdgcn_s_waitcnt(0xc07f);
+#ifndef YCNR_WG_ABLATE_FACTOR
         bad = factor_diag(S, Dt, J + 1, k, lane) || bad;
-      } else {
-        int e = 0;
-        for (int bi = J + 1; bi < NB; ++bi) {
-          acc_t Pi = acc_t{0.0f, 0.0f, 0.0f, 0.0f};
-          bool have = false;
-          for (int bj = bi; bj < NB; ++bj) {
-            if (bi == J + 1 && bj == J + 1) continue;  // wave 0's
-            if ((e++ % (kWgWaves - 1)) != wave - 1) continue;
-            if (!have) {
-              Pi = ld(tile(S, J, bi), off);
-              have = true;
-            }
-            const acc_t Pj = ld(tile(S, J, bj), off);
-            float *T = tile(S, bi, bj);
-            acc_t t = ld(T, off);
+#endif
+      }
+#ifndef YCNR_WG_ABLATE_TRAIL
+      {
+        auto next_row = [&]() {
+          int r = 0;
+          if (lane == 0) r = __hip_atomic_fetch_add(rowCounter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          return __builtin_amdgcn_readfirstlane(r);
+        };
+        const acc_t Zop = ld_rhs(zvec, J);
+        int bi = next_row();
+        while (bi < NB) {
+          const int nxt = next_row();  // in flight while this row is worked on
+          acc_t nPi = ld(tile(S, J, bi), off);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) t = Tr::mma(-Pi[q], Pj[q], t);
-            st(T, off, t);
+          for (int q = 0; q < 4; ++q) nPi[q] = -nPi[q];
+          // tiles (bi, b0 .. NB-1) lie 1 KB apart in the image, and so do the panel tiles (J, b0 .. NB-1):
+          // four at a time off two address registers with immediate offsets.  Past the end of the row
+          // the loads run into the next tiles (valid LDS; the products are dropped).
+          const int b0 = bi == J + 1 ? bi + 1 : bi, nt = NB - b0;
+          const float *Pp = tile(S, J, b0) + off;
+          float *Tp = tile(S, bi, b0) + off;
+          for (int i = 0; i < nt; i += 4) {
+            acc_t Pj[4], t[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              Pj[u] = *reinterpret_cast<const acc_t *>(Pp + 256 * (i + u));
+              t[u] = *reinterpret_cast<const acc_t *>(Tp + 256 * (i + u));
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+              for (int u = 0; u < 4; ++u) t[u] = Tr::mma(nPi[q], Pj[u][q], t[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              if (i + u < nt) *reinterpret_cast<acc_t *>(Tp + 256 * (i + u)) = t[u];
           }
-        }
-        // b_bj -= U[J][bj]^T z_J
-        const acc_t zrow = *reinterpret_cast<const acc_t *>(zvec + J * 16 + 4 * g);
-        for (int bj = J + 1 + (wave - 1); bj < NB; bj += kWgWaves - 1) {
-          const acc_t U = ld(tile(S, J, bj), off);
-          const float d = matvec_t(U, zrow);
-          if (g == 0) bvec[bj * 16 + c] -= d;
+          {  // the right-hand side: b_bi -= U[J][bi]^T z_J
+            acc_t t = ld_rhs(bvec, bi);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t = Tr::mma(nPi[q], Zop[q], t);
+            if (c0) *reinterpret_cast<acc_t *>(bvec + bi * 16 + 4 * g) = t;
+          }
+          bi = nxt;
         }
       }
+#endif
+      YCNR_STAMP(a, 6 + 4 * J);
       __syncthreads();
+      YCNR_STAMP(a, 7 + 4 * J);
     }
+    YCNR_STAMP(a, 80);
     // ---- back substitution, right-looking: x_J = V_J z_J; z_bi -= U[bi][J] x_J for bi < J
+#ifdef YCNR_WG_ABLATE_BACK
+    for (int J = -1; J >= 0; --J) {
+#else
     for (int J = NB - 1; J >= 0; --J) {
+#endif
       if (wave == 0) {
         const acc_t V = ld(tile(S, J, J), off);
         const acc_t x = matvec_n(V, zvec[J * 16 + c]);
@@ -496,6 +621,7 @@ struct WgSolve {
       }
       __syncthreads();
     }
+    YCNR_STAMP(a, 81);
     float *out = a.solved + (int64_t)row * k;
     float chk = 0.0f;
     for (int i = tid; i < k; i += kWgThreads) {

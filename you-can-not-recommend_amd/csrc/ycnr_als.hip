@@ -55,6 +55,7 @@ constexpr int kWgFusedMax = 16384;   // longest row one workgroup takes whole (k
 constexpr int kDefaultChunk = 1024;  // ratings per split unit (and the largest fused row)
 constexpr int kMaxSlabsPerRow = 64;  // heavier rows get proportionally longer chunks
 constexpr int64_t kBandBytes = (int64_t)96 << 20;  // slice of the fixed matrix one band of chunks gathers from (cache-sized)
+constexpr size_t kErrBytes = 65536;
 constexpr size_t kZeroRowBytes = 2048;  // >= kMaxFactors doubles
 constexpr int kMaxDualBlocks = 10;       // dual-form kernels exist for 1..10 blocks of 16 ratings
 constexpr int kMaxDualBlocksSmallK = 6;  // k <= 128: beyond 96 ratings the row kernel (k x k) is as cheap
@@ -973,8 +974,8 @@ int ycnr_als_create(const ycnr_als_options *o, ycnr_als **out) {
       e = hipMemsetAsync(h->factors[s], 0, (size_t)h->rows(s) * o->factorsCount * h->ts(), h->ownStream);
     }
   }
-  if (e == hipSuccess) e = hipMalloc(&h->dErr, sizeof(ErrInfo));
-  if (e == hipSuccess) e = hipMemsetAsync(h->dErr, 0, sizeof(ErrInfo), h->ownStream);
+  if (e == hipSuccess) e = hipMalloc(&h->dErr, kErrBytes);  // ErrInfo + room for in-kernel stamps of diagnostic builds
+  if (e == hipSuccess) e = hipMemsetAsync(h->dErr, 0, kErrBytes, h->ownStream);
   if (e == hipSuccess) e = hipMalloc(&h->dZeros, kZeroRowBytes);
   if (e == hipSuccess) e = hipMemsetAsync(h->dZeros, 0, kZeroRowBytes, h->ownStream);
   if (e == hipSuccess) e = hipStreamSynchronize(h->ownStream);
@@ -1473,6 +1474,16 @@ int ycnr_als_sync(ycnr_als *h) {
     ErrInfo ei{};
     HIP_TRY(hipMemcpy(&ei, h->dErr, sizeof ei, hipMemcpyDeviceToHost));
     h->info.numericErrors = ei.count;
+#ifdef YCNR_WG_STAMPS
+    if (const char *path = getenv("YCNR_DUMP_STAMPS")) {
+      std::vector<unsigned char> buf(kErrBytes);
+      HIP_TRY(hipMemcpy(buf.data(), h->dErr, kErrBytes, hipMemcpyDeviceToHost));
+      if (FILE *f = fopen(path, "wb")) {
+        fwrite(buf.data(), 1, buf.size(), f);
+        fclose(f);
+      }
+    }
+#endif
     if (ei.count > 0 && !env_flags().ignoreNumeric)  // the env var exists for timing experiments with ablated kernels
       return fail(YCNR_ERR_NUMERIC, "%d row(s) had a normal matrix that is not positive definite (e.g. row %d)",
                   ei.count, ei.firstRow);
