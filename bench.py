@@ -299,9 +299,10 @@ def main():
     if args.dump_factors and rank == 0:
         np.savez(args.dump_factors, U=lord.backend.get_factors(0), V=lord.backend.get_factors(1), rmse=rmse)
 
-    cpu = None
+    cpu = cpu_blas = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(lord, by_user, by_item, k, args)
+        cpu_blas = cpu_baseline_blas(lord, by_user, by_item, k, args)
 
     if rank == 0:
         out = {
@@ -312,7 +313,7 @@ def main():
             "config": {"workload": desc, "users": users, "items": items, "nnz": nnz, "factorsCount": k,
                        "lambda": 0.05, "parallelism": f"row-shard x{world} + direct all-gather ({lord.exchangePath})" if world > 1 else "1 GPU"},
             "rmse_in_sample_after_iters": rmse, "iters_run": args.steps + args.warmup,
-            "roofline": roofline, "exchange": exchange, "cpu_baseline": cpu,
+            "roofline": roofline, "exchange": exchange, "cpu_baseline": cpu, "cpu_baseline_blas": cpu_blas,
             "setup_s": {"generate": round(t_gen, 2), "prepare": round(t_prep, 2)},
         }
         print(json.dumps(out), flush=True)
@@ -388,6 +389,60 @@ def cpu_baseline(lord, by_user, by_item, k, args):
             "sample": f"first {ru} user rows ({nu} ratings, {tu:.1f} s) + first {ri} item rows ({ni} ratings, {ti:.1f} s) "
                       f"of the same workload, OpenMP over rows with {cores} threads (affinity mask capped by the cgroup CPU quota; "
                       f"os.cpu_count() = {os.cpu_count()}); extrapolated to a full iteration",
+            "rate_byUser": rate_u, "rate_byItem": rate_i}
+
+
+def cpu_baseline_blas(lord, by_user, by_item, k, args):
+    """The same bounded sample idea through BLAS / LAPACK (kind 'blas'): the reference's per-row gemm +
+    gesv structure in PyTorch's CPU BLAS (MKL), one single-threaded worker process per host core like
+    the reference's worker processes (oracle/blas_baseline.py, run as a child process so that no
+    process forks after it has touched the GPU).  Stands in for the reference's nblas / LAPACK path,
+    which cannot run here.  About half the CPU budget of the port sample."""
+    import subprocess
+    import tempfile
+    cores = host_cpus()
+    dt = np.float64 if args.double else np.float32
+    U = lord.backend.get_factors(0)
+    V = lord.backend.get_factors(1)
+    helper = os.path.join(ROOT, "oracle", "blas_baseline.py")
+
+    def run(csr, rp, rows, fixed):
+        e = int(rp[rows])
+        indx = csr.indx[:e].cpu().numpy()
+        uniq, inv = np.unique(indx, return_inverse=True)   # only the fixed rows the sample touches travel to the workers
+        with tempfile.TemporaryDirectory() as tmp:
+            path = os.path.join(tmp, "sample.npz")
+            np.savez(path, k=k, lam=0.05, rowPtr=np.ascontiguousarray(rp[:rows + 1]), indx=inv.astype(np.int32),
+                     vals=csr.vals[:e].cpu().numpy().astype(dt), fixed=np.ascontiguousarray(fixed[uniq]))
+            out = subprocess.run([sys.executable, helper, path, str(cores)], capture_output=True, text=True, timeout=600)
+        if out.returncode != 0:
+            raise RuntimeError("blas baseline failed: " + out.stderr[-400:])
+        j = json.loads(out.stdout.strip().splitlines()[-1])
+        return j["ratings"], j["busy_seconds_max"]
+
+    def sample(csr, fixed):
+        rp = csr.rowPtr.cpu().numpy()
+        # probe ~200 K ratings, then a prefix sized for about cpu_seconds / 4 per side
+        probe_rows = max(1, min(csr.rows, int(np.searchsorted(rp, 200_000)) + 1))
+        n, t = run(csr, rp, probe_rows, fixed)
+        rate = n / max(t, 1e-3)
+        rows = max(1, min(csr.rows, int(np.searchsorted(rp, rate * args.cpu_seconds * 0.25)) + 1))
+        if rows <= probe_rows:
+            return n, t, probe_rows
+        n, t = run(csr, rp, rows, fixed)
+        return n, t, rows
+
+    try:
+        nu, tu, ru = sample(by_user, V)
+        ni, ti, ri = sample(by_item, U)
+    except Exception as e:  # noqa: BLE001 -- a reported baseline must not take the bench line down
+        return {"kind": "blas", "error": str(e)[:300]}
+    rate_u, rate_i = nu / tu, ni / ti
+    import torch as _t
+    return {"value": 1.0 / (1.0 / rate_u + 1.0 / rate_i), "unit": "ratings/s", "cores": cores, "kind": "blas",
+            "blas": "PyTorch CPU (" + ("MKL" if _t.backends.mkl.is_available() else "default BLAS") + "): gemm + LAPACK gesv per row",
+            "sample": f"first {ru} user rows ({nu} ratings, {tu:.1f} s) + first {ri} item rows ({ni} ratings, {ti:.1f} s) of the same "
+                      f"workload, {cores} single-threaded worker processes; extrapolated to a full iteration",
             "rate_byUser": rate_u, "rate_byItem": rate_i}
 
 

@@ -1,5 +1,7 @@
 // Many short units at once (8 blocks per CU): als_gram_slab_x6d_kernel against the float32-MFMA
-// slab kernel, unit by unit.  x6many <nb:4|7> <k> <n> <units>
+// slab kernel, unit by unit.  x6many <nb:1..7> <k> <n> <units>     (exit code 1: some unit differs)
+// tests/test_gpu_hazard.py runs the shipped build of it over every block count and both forms of
+// the right-hand side (k = 16 nb: VALU accumulators, k < 16 nb: the padded Gramian column).
 // Built with -DYCNR_X6D_ALLOW_PK (the right-hand side's multiply-adds packed across blocks) the
 // k % 16 == 0 form fails for a few per cent of the units at 8 workgroups per CU.
 #include "../als_kernels.hip.h"
@@ -58,7 +60,10 @@ int run(int k, int n, int units, int items) {
 int main(int argc, char **argv) {
   const int nb = atoi(argv[1]), k = atoi(argv[2]), n = atoi(argv[3]), units = atoi(argv[4]);
   int bad = 0;
-  if (nb == 4) bad = k < 64 ? run<4, true>(k, n, units, 20000) : run<4, false>(k, n, units, 20000);
-  if (nb == 7) bad = k < 112 ? run<7, true>(k, n, units, 20000) : run<7, false>(k, n, units, 20000);
+  const int items = 20000;
+#define YCNR_NB(NBV) \
+  if (nb == NBV) bad = k < 16 * NBV ? run<NBV, true>(k, n, units, items) : run<NBV, false>(k, n, units, items);
+  YCNR_NB(1) YCNR_NB(2) YCNR_NB(3) YCNR_NB(4) YCNR_NB(5) YCNR_NB(6) YCNR_NB(7)
+#undef YCNR_NB
   return bad != 0;
 }
