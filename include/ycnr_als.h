@@ -34,7 +34,7 @@ extern "C" {
 #define YCNR_ERR_INVALID (-1)     /* bad argument: null pointer, k out of range, index >= rows ... */
 #define YCNR_ERR_HIP (-2)         /* a HIP runtime call failed (message carries hipGetErrorString) */
 #define YCNR_ERR_NOMEM (-3)       /* host or device allocation failed */
-#define YCNR_ERR_UNSUPPORTED (-4) /* valid request this build cannot serve (e.g. factorsCount > 128) */
+#define YCNR_ERR_UNSUPPORTED (-4) /* valid request this build cannot serve (e.g. factorsCount > 256) */
 #define YCNR_ERR_NUMERIC (-5)     /* a row's normal matrix was not positive definite (NaN/Inf input) */
 #define YCNR_ERR_STATE (-6)       /* call order violated (e.g. step before set_ratings) */
 
@@ -83,6 +83,18 @@ int64_t ycnr_dAlsCalcPortion(double lambda, int k, const int32_t *alsRows, const
                              const double *alsVals, const double *fixedFactors, int64_t fixedRows,
                              double *solvedFactors, int64_t solvedRows);
 
+/* Optional, once per half-step: keep the step's fixed factor matrix resident on the device for the
+ * portion calls that follow on this thread (call it where the worker handles 'startTrainStep',
+ * lib/emf/EmfWorker.js:43-51 / EmfMaster._startAlsTrainStep, lib/emf/EmfMaster.js:364-383).  A later
+ * ycnr_{s,d}AlsCalcPortion whose fixedFactors / fixedRows / k are the pinned ones skips the per-portion
+ * gather + upload of the rows it refers to -- the replacement of the per-rating BLAS.BufCopy of
+ * EmfBase.copySubFixedFactors (lib/emf/EmfBase.js:537-555).  The host must pin again after it has
+ * changed the matrix (every half-step does).  Stream and device buffers of the portion ops are
+ * cached per thread either way; ycnr_AlsReleasePortionState frees them. */
+int ycnr_sAlsPinFixedFactors(const float *fixedFactors, int64_t fixedRows, int k);
+int ycnr_dAlsPinFixedFactors(const double *fixedFactors, int64_t fixedRows, int k);
+int ycnr_AlsReleasePortionState(void);
+
 /* ycnr_{s,d}RmsePortion replaces EmfWorker.mw_calcRmsePortion, lib/emf/EmfWorker.js:266-315:
  * pred = userFactors[u] . itemFactors[i] + globalAvgShift (EmfBase._alsPredict, EmfBase.js:825-827);
  * out = {rSumDiff2, rCnt, rSum} accumulated in double (EmfWorker.js:297-299). */
@@ -103,7 +115,8 @@ typedef struct ycnr_als_options {
   int32_t struct_size;     /* = sizeof(ycnr_als_options) */
   int32_t device;          /* HIP device ordinal (one process per GPU: LOCAL_RANK) */
   int32_t dtype;           /* YCNR_F32 | YCNR_F64 = options.useDoublePrecision */
-  int32_t factorsCount;    /* options.factorsCount, 1..128 in this build */
+  int32_t factorsCount;    /* options.factorsCount: float32 1..128 and the multiples of 4 up to 256
+                            * (other values in 129..256 through a zero-padded copy), float64 1..128 */
   int64_t totalUsersCount; /* stats.totalUsersCount = max user id (EmfLord.js:81) */
   int64_t totalItemsCount; /* stats.totalItemsCount = max item id (EmfLord.js:82) */
   double userFactReg;      /* options.als.userFactReg (EmfBase.js:67) */

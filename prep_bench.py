@@ -66,6 +66,36 @@ def main():
         oid, opr = orc.recommend(Uf[uu], Vf, sk[sp[uu]:sp[uu + 1]], 6.4, 7.0, 20)
         assert len(oid) == rec_cnt[uu] and np.allclose(opr, rec_pred[uu, :len(oid)], atol=1e-4)
     cpu_rec_s = (time.perf_counter() - t0r) / 64
+    # Level 1: the portion op as a maintainer of the reference would call it from EmfWorker.mw_calcTrainAlsPortion
+    # (host buffers in, host rows out), 10 000-rating portions of the byUser step (EmfBase.js:99-103), k = 100:
+    # unpinned (per-portion gather + upload of the referenced fixed rows) and with the step's fixed
+    # matrix pinned on the device once (ycnr_sAlsPinFixedFactors)
+    from ycnr_als.data import csr_to_portion
+    a_np = by_user.numpy()
+    Uf0 = np.zeros((by_user.rows, kf), np.float32)
+    portion_rows = []
+    lo = 0
+    while len(portion_rows) < 64:
+        hi = int(np.searchsorted(rp_u, rp_u[lo] + 10_000, side="right")) - 1
+        hi = max(hi, lo + 1)
+        portion_rows.append((lo, hi))
+        lo = hi
+    portions = [csr_to_portion(a_np, lo_, hi_) for lo_, hi_ in portion_rows]
+    level1 = {}
+    for name in ("unpinned", "pinned"):
+        if name == "pinned":
+            t0p = time.perf_counter()
+            ycnr_als.pin_fixed_factors(Vf, kf)
+            level1["pin_ms"] = round((time.perf_counter() - t0p) * 1e3, 3)
+        ycnr_als.als_calc_portion(0.05, kf, *portions[0], Vf, Uf0)  # warm-up
+        t0p = time.perf_counter()
+        n1 = 0
+        for rows_, indx_, vals_ in portions:
+            n1 += ycnr_als.als_calc_portion(0.05, kf, rows_, indx_, vals_, Vf, Uf0)
+        dt1 = time.perf_counter() - t0p
+        level1[name] = {"portions_per_s": round(len(portions) / dt1, 1), "ratings_per_s": round(n1 / dt1), "ms_per_portion": round(dt1 / len(portions) * 1e3, 3)}
+    ycnr_als.release_portion_state()
+    level1["portion"] = "10 000 ratings of consecutive users (byUser step), k = 100, float32, host buffers in and out"
     # algorithmic bytes: the split reads and writes one byte per rating (+ row pointers); the
     # statistics read a rating and a type per rating and write 12 bytes per row
     b_split = 2 * nnz + 8 * (len(rp_u) - 1)
@@ -101,6 +131,7 @@ def main():
                       "algorithmic_GBs": round(nrec * by_user.cols * (kf * 4 + 16) / (ms_rec * 1e-3) / 1e9, 1),
                       "mean_recommended": float(rec_cnt.mean()), "cpu_oracle_s_per_user": round(cpu_rec_s, 5),
                       "checked": "64 users against the oracle"},
+        "level1_portion_op": level1,
         "sets": {"train": int(tot[1]), "validate": int(tot[2]), "test": int(tot[3])},
         "maxRatingsPerUser": int(cnt_u.max()), "maxRatingsPerItem": int(cnt_i.max()),
         "totalRatingsAvg": float(sum_u.sum() / cnt_u.sum()),

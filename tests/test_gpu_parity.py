@@ -66,6 +66,42 @@ def test_golden_portion(als, oracle, name):
     assert np.allclose(out, z["rmse_out"], rtol=1e-6 if dt == np.float32 else 1e-12)
 
 
+@pytest.mark.parametrize("k,dt", [(20, np.float32), (100, np.float32), (100, np.float64), (200, np.float32)])
+def test_portion_ops_keep_state_and_pinned_matrix(als, k, dt):
+    """Level 1 as the reference would drive it: many portions per half-step on one thread (stream and
+    device buffers are reused), with and without the step's fixed matrix pinned on the device
+    (ycnr_{s,d}AlsPinFixedFactors) -- bit-identical results either way, against float64, including
+    k > 128 through the workgroup-per-row kernels; a changed matrix must be pinned again."""
+    import ycnr_als
+    users, items = 600, 900
+    bu, _, U, V = make_problem(users, items, k, density=0.06, seed=5 + k, dtype=dt, empty_rows=(7,))
+    want, conds = numpy_step(0.05, k, bu, V, U)
+    cuts = [0, 50, 51, 200, 430, users]
+    outs = []
+    for pin in (False, True):
+        solved = U.copy()
+        if pin:
+            ycnr_als.pin_fixed_factors(V, k)
+        total = 0
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            rows, indx, vals = csr_to_portion(bu, lo, hi)
+            total += als.als_calc_portion(0.05, k, rows, indx, vals, V, solved)
+        assert total == bu.nnz
+        check_rows(solved, want, conds, dt)
+        assert np.array_equal(solved[7], U[7])
+        outs.append(solved)
+    assert np.array_equal(outs[0], outs[1])
+    # the pinned copy is a snapshot: after the host changes the matrix it must pin again
+    V2 = (V * dt(0.5)).astype(dt)
+    ycnr_als.pin_fixed_factors(V2, k)
+    rows, indx, vals = csr_to_portion(bu, 0, 50)
+    s2 = U.copy()
+    als.als_calc_portion(0.05, k, rows, indx, vals, V2, s2)
+    w2, c2 = numpy_step(0.05, k, Csr(50, items, bu.rowPtr[:51].copy(), bu.indx[:bu.rowPtr[50]], bu.vals[:bu.rowPtr[50]]), V2, U[:50])
+    check_rows(s2[:50], w2, c2, dt)
+    ycnr_als.release_portion_state()
+
+
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
 @pytest.mark.parametrize("k", [1, 7, 16, 20, 33, 36, 64, 100, 116, 128])
 def test_half_steps_all_k(als, oracle, k, dt):
@@ -136,7 +172,7 @@ def test_split_rows_and_chunk_edges(als, dt):
     dev2.destroy()
 
 
-@pytest.mark.parametrize("k", [20, 64, 100, 128, 132, 200, 256])
+@pytest.mark.parametrize("k", [20, 64, 100, 128, 129, 132, 150, 200, 201, 255, 256])
 def test_every_row_length_class(als, k):
     """Rows of 1..130 ratings at one k: short rows take the dual (n x n) form, grouped by their
     number of 16-rating blocks, longer ones the primal form; all against float64, and the three
@@ -488,9 +524,6 @@ def test_errors_are_reported_not_fatal(als):
     assert e.value.code == _lib.ERR_UNSUPPORTED
     with pytest.raises(YcnrError) as e:
         als.AlsDevice(129, 10, 10, useDoublePrecision=True)  # float64 stops at 128
-    assert e.value.code == _lib.ERR_UNSUPPORTED
-    with pytest.raises(YcnrError) as e:
-        als.AlsDevice(130, 10, 10)  # the 4-wave path needs 16-byte rows
     assert e.value.code == _lib.ERR_UNSUPPORTED
     dev = als.AlsDevice(8, 4, 5)
     with pytest.raises(YcnrError) as e:

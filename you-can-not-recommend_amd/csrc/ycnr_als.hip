@@ -327,6 +327,24 @@ int launch_nb(const StepArgs<T> &args, int64_t nUnits, int64_t nSplitUnits, int6
   return launch_nbe<T, NB, LDS_SOLVER, false, false>(args, nUnits, nSplitUnits, nSplit, stream, ev, dp);
 }
 
+// k > 128 with k % 4 != 0: the kernels of that path need 16-byte rows, so the half-step runs on copies of
+// both matrices with the rows padded to kp = 4 ceil(k / 4) zero columns.  A zero column adds nothing
+// to the Gramian or to b, its diagonal entry is lambda n and its solution component exactly 0.
+__global__ void pad_rows_kernel(const float *src, float *dst, int64_t rows, int k, int kp) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * kp) return;
+  const int64_t r = i / kp;
+  const int c = (int)(i - r * kp);
+  dst[i] = c < k ? src[r * k + c] : 0.0f;
+}
+__global__ void unpad_rows_kernel(const float *src, float *dst, int64_t rowBegin, int64_t rows, int k, int kp) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * k) return;
+  const int64_t r = rowBegin + i / k;
+  const int c = (int)(i % k);
+  dst[r * k + c] = src[r * kp + c];
+}
+
 int device_cus() {
   static std::mutex mu;
   static std::map<int, int> cus;
@@ -457,7 +475,8 @@ int64_t slab_regs(const ycnr_als_options &o, int side) {
 // Longest row solved in dual form (0 = never): float32 MFMA solver only, rows of 16-byte
 // multiples, and strictly fewer 16-blocks than the primal form would use.
 int dual_max_ratings(const ycnr_als_options &o) {
-  if (o.dtype != YCNR_F32 || (o.flags & (YCNR_FLAG_LDS_SOLVER | YCNR_FLAG_NO_DUAL)) || o.factorsCount % 4 != 0) return 0;
+  // (k > 128 with k % 4 != 0 runs on rows padded to a multiple of 4: see kPad)
+  if (o.dtype != YCNR_F32 || (o.flags & (YCNR_FLAG_LDS_SOLVER | YCNR_FLAG_NO_DUAL)) || (o.factorsCount % 4 != 0 && o.factorsCount <= kMaxFactors)) return 0;
   const int nb = slab_nb(o.factorsCount);
   // k > 128: every row that is not dual goes through slabs and the 4-wave LDS solve, whose cost
   // grows with k^3; an n x n problem with n <= 160 still fits one wave's registers
@@ -575,6 +594,8 @@ struct ycnr_als {
   hipEvent_t evFork = nullptr, evJoin[kSideStreams] = {};
   void *factors[2] = {nullptr, nullptr};
   bool ownFactors[2] = {false, false};
+  int kPad = 0;                          // != 0: factorsCount padded to a multiple of 4 (k > 128, k % 4 != 0)
+  float *padded[2] = {nullptr, nullptr};  // [rows x kPad] copies the kernels of that case work on
   bool autoChunk = false;  // options.chunkRatings was 0: sized per upload (auto_chunk)
   std::vector<Part> parts[2];      // the side's local row shard, cut into pipelined pieces (usually one)
   std::vector<int64_t> bounds[2];   // sharded upload: row bounds of every rank's pieces, world x (nParts + 1)
@@ -941,8 +962,6 @@ int ycnr_als_create(const ycnr_als_options *o, ycnr_als **out) {
   if (o->factorsCount > (o->dtype == YCNR_F32 ? kMaxFactorsBig : kMaxFactors))
     return fail(YCNR_ERR_UNSUPPORTED, "factorsCount %d > %d is not supported by this build for %s", o->factorsCount,
                 o->dtype == YCNR_F32 ? kMaxFactorsBig : kMaxFactors, o->dtype == YCNR_F32 ? "float32" : "float64");
-  if (o->factorsCount > kMaxFactors && o->factorsCount % 4 != 0)
-    return fail(YCNR_ERR_UNSUPPORTED, "factorsCount %d > %d must be a multiple of 4", o->factorsCount, kMaxFactors);
   if (o->totalUsersCount < 1 || o->totalItemsCount < 1 || o->totalUsersCount > 0x7fffffffLL ||
       o->totalItemsCount > 0x7fffffffLL)
     return fail(YCNR_ERR_INVALID, "totalUsersCount / totalItemsCount must be in [1, 2^31)");
@@ -974,6 +993,10 @@ int ycnr_als_create(const ycnr_als_options *o, ycnr_als **out) {
       e = hipMemsetAsync(h->factors[s], 0, (size_t)h->rows(s) * o->factorsCount * h->ts(), h->ownStream);
     }
   }
+  if (o->factorsCount > kMaxFactors && o->factorsCount % 4 != 0) {
+    h->kPad = (o->factorsCount + 3) & ~3;
+    for (int s = 0; s < 2 && e == hipSuccess; ++s) e = hipMalloc(&h->padded[s], (size_t)h->rows(s) * h->kPad * sizeof(float));
+  }
   if (e == hipSuccess) e = hipMalloc(&h->dErr, kErrBytes);  // ErrInfo + room for in-kernel stamps of diagnostic builds
   if (e == hipSuccess) e = hipMemsetAsync(h->dErr, 0, kErrBytes, h->ownStream);
   if (e == hipSuccess) e = hipMalloc(&h->dZeros, kZeroRowBytes);
@@ -1000,6 +1023,7 @@ int ycnr_als_destroy(ycnr_als *h) {
     h->parts[s].clear();
     h->rmse[s].release();
     if (h->ownFactors[s] && h->factors[s]) (void)hipFree(h->factors[s]);
+    if (h->padded[s]) (void)hipFree(h->padded[s]);
   }
   if (h->dErr) (void)hipFree(h->dErr);
   if (h->dZeros) (void)hipFree(h->dZeros);
@@ -1340,8 +1364,11 @@ static int launch_part(ycnr_als *h, int side, Part &part) {
   const Schedule &S = part.S;
   const double lambda = side == YCNR_BY_USER ? h->opt.userFactReg : h->opt.itemFactReg;
   if (h->opt.dtype == YCNR_F32) {
-    StepArgs<float> a{S.dUnits, S.dSplit, R.dIndx, (const float *)R.dVals, (const float *)h->factors[1 - side],
-                      (const float *)h->dZeros, (float *)h->factors[side], (float *)S.dSlabs, h->dErr, lambda, h->opt.factorsCount, 0, 0,
+    const int kk = h->kPad ? h->kPad : h->opt.factorsCount;
+    const float *fixedM = h->kPad ? h->padded[1 - side] : (const float *)h->factors[1 - side];
+    float *solvedM = h->kPad ? h->padded[side] : (float *)h->factors[side];
+    StepArgs<float> a{S.dUnits, S.dSplit, R.dIndx, (const float *)R.dVals, fixedM,
+                      (const float *)h->dZeros, solvedM, (float *)S.dSlabs, h->dErr, lambda, kk, 0, 0,
                       use_slab_x6(h->opt, side) ? (uint32_t)(h->rows(1 - side) * h->opt.factorsCount * 4) : 0u};
     DualPlan dp;
     dp.noX6 = (h->opt.flags & YCNR_FLAG_NO_BF16X6) != 0;
@@ -1360,7 +1387,18 @@ static int launch_part(ycnr_als *h, int side, Part &part) {
         }
       }
     }
-    if (h->opt.factorsCount > kMaxFactors) return launch_step_big(a, S.nUnits, S.nSlabs, S.nSplit, h->stream, part.ev, dp);
+    if (h->opt.factorsCount > kMaxFactors) {
+      int rc = launch_step_big(a, S.nUnits, S.nSlabs, S.nSplit, h->stream, part.ev, dp);
+      if (rc || !h->kPad) return rc;
+      // the piece's solved rows back into the caller's matrix (before its exchange)
+      const int64_t nr = R.rowEnd - R.rowBegin, n = nr * h->opt.factorsCount;
+      if (n > 0) {
+        hipLaunchKernelGGL(unpad_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, (const float *)h->padded[side],
+                           (float *)h->factors[side], R.rowBegin, nr, h->opt.factorsCount, h->kPad);
+        HIP_TRY(hipGetLastError());
+      }
+      return YCNR_OK;
+    }
     return launch_step<float>(a, S.nUnits, S.nSlabs, S.nSplit, h->stream, part.ev, (h->opt.flags & YCNR_FLAG_LDS_SOLVER) != 0, dp,
                               use_valu_edge(h->opt), use_slab_x6(h->opt, side));
   }
@@ -1390,6 +1428,14 @@ int ycnr_als_step_async(ycnr_als *h, int side) {
   // With a communicator and a sharded upload the half-step includes its exchange: the rows of piece
   // c travel (on the communicator's stream) while piece c + 1 is being solved, and the step's
   // stream waits for the last piece to land -- the next half-step reads the whole matrix.
+  if (h->kPad) {
+    for (int s = 0; s < 2; ++s) {
+      const int64_t n = h->rows(s) * h->kPad;
+      hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, (const float *)h->factors[s],
+                         h->padded[s], h->rows(s), h->opt.factorsCount, h->kPad);
+      HIP_TRY(hipGetLastError());
+    }
+  }
   const bool exchange = h->comm.active() && !h->bounds[side].empty();
   h->exchangedInStep = exchange;
   memset(&h->info, 0, sizeof h->info);
@@ -1696,18 +1742,103 @@ int ycnr_als_comm_selftest(ycnr_als *h, int64_t nFloats) {
 
 namespace {
 
-// Shared body of ycnr_{s,d}AlsCalcPortion.  The portion only touches the fixed rows its
-// column ids name, so those rows are compacted on the host before upload (a 10 000-rating
-// portion never needs more than 10 000 of them) and the solved rows are scattered back.
+// Per-thread state of the level-1 portion ops: the reference calls mw_calcTrainAlsPortion ~11 500
+// times per MAL half-step (EmfBase.js:99-103: 10 000 ratings per portion), so stream, device
+// buffers and -- when the host pins it -- the fixed factor matrix stay alive between calls.
+struct DevArena {
+  void *p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    const size_t want = std::max<size_t>(bytes + bytes / 2, 4096);
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+struct L1Ctx {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  DevArena units, split, indx, vals, fixed, solved, slabs, misc;  // misc: ErrInfo + zero row
+  // fixed matrix pinned by ycnr_{s,d}AlsPinFixedFactors
+  const void *pinnedHost = nullptr;
+  int64_t pinnedRows = 0;
+  int pinnedK = 0, pinnedDtype = -1;
+  DevArena pinned;
+  void release() {
+    if (device >= 0) (void)hipSetDevice(device);
+    if (stream) {
+      (void)hipStreamSynchronize(stream);
+      (void)hipStreamDestroy(stream);
+    }
+    stream = nullptr;
+    for (DevArena *a : {&units, &split, &indx, &vals, &fixed, &solved, &slabs, &misc, &pinned}) a->release();
+    pinnedHost = nullptr;
+    device = -1;
+  }
+  ~L1Ctx() { release(); }
+};
+
+L1Ctx &l1ctx() {
+  static thread_local L1Ctx c;
+  return c;
+}
+
+// stream + the small fixed buffers, on the calling thread's current device
+int l1_prepare(L1Ctx &C) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (C.device != dev) {
+    C.release();
+    C.device = dev;
+  }
+  if (!C.stream) HIP_TRY(hipStreamCreateWithFlags(&C.stream, hipStreamNonBlocking));
+  if (!C.misc.p) {
+    HIP_TRY(C.misc.reserve(kErrBytes + kZeroRowBytes));
+    HIP_TRY(hipMemsetAsync(C.misc.p, 0, kErrBytes + kZeroRowBytes, C.stream));
+  }
+  return YCNR_OK;
+}
+
+template <typename T>
+int pin_fixed(const T *fixed, int64_t rows, int k, int dtype) {
+  if (!fixed || rows < 1 || k < 1) return fail(YCNR_ERR_INVALID, "AlsPinFixedFactors: bad argument");
+  L1Ctx &C = l1ctx();
+  int rc = l1_prepare(C);
+  if (rc) return rc;
+  const size_t bytes = (size_t)rows * k * sizeof(T);
+  HIP_TRY(C.pinned.reserve(bytes));
+  HIP_TRY(hipMemcpyAsync(C.pinned.p, fixed, bytes, hipMemcpyHostToDevice, C.stream));
+  HIP_TRY(hipStreamSynchronize(C.stream));
+  C.pinnedHost = fixed;
+  C.pinnedRows = rows;
+  C.pinnedK = k;
+  C.pinnedDtype = dtype;
+  return YCNR_OK;
+}
+
+// Shared body of ycnr_{s,d}AlsCalcPortion.  Unless the caller has pinned this fixed matrix, the portion's
+// column ids are compacted on the host (a 10 000-rating portion never needs more than 10 000 fixed
+// rows) and only those rows are uploaded; the solved rows are scattered back into the caller's matrix.
 template <typename T>
 int64_t als_calc_portion(double lambda, int k, const int32_t *alsRows, const int32_t *alsIndx, const T *alsVals,
                          const T *fixedFactors, int64_t fixedRows, T *solvedFactors, int64_t solvedRows, int dtype) {
   if (!alsRows || !alsIndx || !alsVals || !fixedFactors || !solvedFactors)
     return fail(YCNR_ERR_INVALID, "AlsCalcPortion: null argument");
   if (k < 1) return fail(YCNR_ERR_INVALID, "AlsCalcPortion: k < 1");
-  if (k > kMaxFactors)
-    return fail(YCNR_ERR_UNSUPPORTED, "factorsCount %d > %d: use the resident trainer (ycnr_als_*) for large factor counts", k,
-                kMaxFactors);
+  const bool big = k > kMaxFactors;
+  if (k > (dtype == YCNR_F32 ? kMaxFactorsBig : kMaxFactors) || (big && k % 4 != 0))
+    return fail(YCNR_ERR_UNSUPPORTED, "factorsCount %d is not supported for %s by this build (float32: <= %d, multiples of 4 above %d; float64: <= %d)",
+                k, dtype == YCNR_F32 ? "float32" : "float64", kMaxFactorsBig, kMaxFactors, kMaxFactors);
   if (!(lambda >= 0)) return fail(YCNR_ERR_INVALID, "AlsCalcPortion: negative lambda");
   const int nRows = alsRows[0];
   if (nRows < 0) return fail(YCNR_ERR_INVALID, "AlsCalcPortion: alsRows[0] < 0");
@@ -1721,89 +1852,80 @@ int64_t als_calc_portion(double lambda, int k, const int32_t *alsRows, const int
   }
   const int64_t total = rowPtr[nRows];
   if (total == 0) return 0;
-  // compact the referenced fixed rows
-  std::vector<int32_t> uniq(alsIndx, alsIndx + total);
-  std::sort(uniq.begin(), uniq.end());
-  uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
-  if (uniq.front() < 0 || uniq.back() >= fixedRows)
-    return fail(YCNR_ERR_INVALID, "AlsCalcPortion: column id out of range (min %d, max %d, fixedRows %lld)", uniq.front(),
-                uniq.back(), (long long)fixedRows);
-  std::vector<int32_t> cidx((size_t)total);
-  for (int64_t i = 0; i < total; ++i)
-    cidx[i] = (int32_t)(std::lower_bound(uniq.begin(), uniq.end(), alsIndx[i]) - uniq.begin());
-  std::vector<T> cfix(uniq.size() * (size_t)k);
-  for (size_t u = 0; u < uniq.size(); ++u) memcpy(&cfix[u * k], fixedFactors + (size_t)uniq[u] * k, sizeof(T) * k);
-
+  int32_t lo = alsIndx[0], hi = alsIndx[0];
+  for (int64_t i = 1; i < total; ++i) {
+    lo = std::min(lo, alsIndx[i]);
+    hi = std::max(hi, alsIndx[i]);
+  }
+  if (lo < 0 || hi >= fixedRows)
+    return fail(YCNR_ERR_INVALID, "AlsCalcPortion: column id out of range (min %d, max %d, fixedRows %lld)", lo, hi, (long long)fixedRows);
+  L1Ctx &C = l1ctx();
+  int rc = l1_prepare(C);
+  if (rc) return rc;
+  const bool pinned = C.pinnedHost == fixedFactors && C.pinnedRows == fixedRows && C.pinnedK == k && C.pinnedDtype == dtype;
+  // compact the referenced fixed rows unless the whole matrix is resident
+  std::vector<int32_t> uniq, cidx;
+  std::vector<T> cfix;
+  if (!pinned) {
+    uniq.assign(alsIndx, alsIndx + total);
+    std::sort(uniq.begin(), uniq.end());
+    uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+    cidx.resize((size_t)total);
+    for (int64_t i = 0; i < total; ++i)
+      cidx[i] = (int32_t)(std::lower_bound(uniq.begin(), uniq.end(), alsIndx[i]) - uniq.begin());
+    cfix.resize(uniq.size() * (size_t)k);
+    for (size_t u = 0; u < uniq.size(); ++u) memcpy(&cfix[u * k], fixedFactors + (size_t)uniq[u] * k, sizeof(T) * k);
+  }
   std::vector<Unit> units;
   std::vector<SplitRow> split;
   int64_t nSlabs = 0, solved = 0;
-  build_schedule(rowPtr.data(), 0, nRows, kDefaultChunk, units, split, nSlabs, solved);
+  build_schedule(rowPtr.data(), 0, nRows, big ? kWgChunk : kDefaultChunk, units, split, nSlabs, solved, -1, big ? kWgFusedMax : 0);
 
   const int nb = slab_nb(k);
-  Unit *dUnits = nullptr;
-  SplitRow *dSplit = nullptr;
-  int32_t *dIndx = nullptr;
-  T *dVals = nullptr, *dFixed = nullptr, *dSolved = nullptr, *dSlabs = nullptr, *dZeros = nullptr;
-  ErrInfo *dErr = nullptr;
-  hipStream_t stream = nullptr;
+  const size_t slabElems = big ? (size_t)wg_slab_floats(nb) : (size_t)slab_elems(nb);
   std::vector<T> hostSolved((size_t)nRows * k);
   ErrInfo ei{};
-  int rc = YCNR_OK;
-  auto cleanup = [&]() {
-    if (dUnits) (void)hipFree(dUnits);
-    if (dSplit) (void)hipFree(dSplit);
-    if (dIndx) (void)hipFree(dIndx);
-    if (dVals) (void)hipFree(dVals);
-    if (dFixed) (void)hipFree(dFixed);
-    if (dSolved) (void)hipFree(dSolved);
-    if (dSlabs) (void)hipFree(dSlabs);
-    if (dZeros) (void)hipFree(dZeros);
-    if (dErr) (void)hipFree(dErr);
-    if (stream) (void)hipStreamDestroy(stream);
-  };
 #define L1_TRY(expr)                                                                                  \
   do {                                                                                                \
     hipError_t e_ = (expr);                                                                           \
-    if (e_ != hipSuccess) {                                                                           \
-      rc = fail(e_ == hipErrorOutOfMemory ? YCNR_ERR_NOMEM : YCNR_ERR_HIP, "%s failed: %s", #expr,    \
-                hipGetErrorString(e_));                                                               \
-      cleanup();                                                                                      \
-      return rc;                                                                                      \
-    }                                                                                                 \
+    if (e_ != hipSuccess)                                                                             \
+      return fail(e_ == hipErrorOutOfMemory ? YCNR_ERR_NOMEM : YCNR_ERR_HIP, "%s failed: %s", #expr,  \
+                  hipGetErrorString(e_));                                                             \
   } while (0)
-  L1_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-  L1_TRY(hipMalloc(&dUnits, sizeof(Unit) * std::max<size_t>(1, units.size())));
-  L1_TRY(hipMalloc(&dSplit, sizeof(SplitRow) * std::max<size_t>(1, split.size())));
-  L1_TRY(hipMalloc(&dIndx, sizeof(int32_t) * (size_t)total));
-  L1_TRY(hipMalloc(&dVals, sizeof(T) * (size_t)total));
-  L1_TRY(hipMalloc(&dFixed, sizeof(T) * cfix.size()));
-  L1_TRY(hipMalloc(&dSolved, sizeof(T) * hostSolved.size()));
-  L1_TRY(hipMalloc(&dSlabs, sizeof(T) * std::max<size_t>(1, (size_t)nSlabs * slab_elems(nb))));
-  L1_TRY(hipMalloc(&dErr, sizeof(ErrInfo)));
-  L1_TRY(hipMalloc(&dZeros, kZeroRowBytes));
-  L1_TRY(hipMemsetAsync(dZeros, 0, kZeroRowBytes, stream));
+  L1_TRY(C.units.reserve(sizeof(Unit) * std::max<size_t>(1, units.size())));
+  L1_TRY(C.split.reserve(sizeof(SplitRow) * std::max<size_t>(1, split.size())));
+  L1_TRY(C.indx.reserve(sizeof(int32_t) * (size_t)total + 64));
+  L1_TRY(C.vals.reserve(sizeof(T) * (size_t)total + 64));
+  if (!pinned) L1_TRY(C.fixed.reserve(sizeof(T) * cfix.size()));
+  L1_TRY(C.solved.reserve(sizeof(T) * hostSolved.size()));
+  L1_TRY(C.slabs.reserve(sizeof(T) * std::max<size_t>(1, (size_t)nSlabs * slabElems)));
+  hipStream_t stream = C.stream;
+  ErrInfo *dErr = (ErrInfo *)C.misc.p;
+  T *dZeros = (T *)((char *)C.misc.p + kErrBytes);
   L1_TRY(hipMemsetAsync(dErr, 0, sizeof(ErrInfo), stream));
-  L1_TRY(hipMemsetAsync(dSolved, 0, sizeof(T) * hostSolved.size(), stream));
-  if (!units.empty()) L1_TRY(hipMemcpyAsync(dUnits, units.data(), sizeof(Unit) * units.size(), hipMemcpyHostToDevice, stream));
-  if (!split.empty()) L1_TRY(hipMemcpyAsync(dSplit, split.data(), sizeof(SplitRow) * split.size(), hipMemcpyHostToDevice, stream));
-  L1_TRY(hipMemcpyAsync(dIndx, cidx.data(), sizeof(int32_t) * (size_t)total, hipMemcpyHostToDevice, stream));
-  L1_TRY(hipMemcpyAsync(dVals, alsVals, sizeof(T) * (size_t)total, hipMemcpyHostToDevice, stream));
-  L1_TRY(hipMemcpyAsync(dFixed, cfix.data(), sizeof(T) * cfix.size(), hipMemcpyHostToDevice, stream));
+  L1_TRY(hipMemsetAsync(C.solved.p, 0, sizeof(T) * hostSolved.size(), stream));
+  if (!units.empty()) L1_TRY(hipMemcpyAsync(C.units.p, units.data(), sizeof(Unit) * units.size(), hipMemcpyHostToDevice, stream));
+  if (!split.empty()) L1_TRY(hipMemcpyAsync(C.split.p, split.data(), sizeof(SplitRow) * split.size(), hipMemcpyHostToDevice, stream));
+  L1_TRY(hipMemcpyAsync(C.indx.p, pinned ? alsIndx : cidx.data(), sizeof(int32_t) * (size_t)total, hipMemcpyHostToDevice, stream));
+  L1_TRY(hipMemcpyAsync(C.vals.p, alsVals, sizeof(T) * (size_t)total, hipMemcpyHostToDevice, stream));
+  if (!pinned) L1_TRY(hipMemcpyAsync(C.fixed.p, cfix.data(), sizeof(T) * cfix.size(), hipMemcpyHostToDevice, stream));
   {
     // rows are numbered 0..nRows-1 on the device and scattered to rowId on the host
-    StepArgs<T> a{dUnits, dSplit, dIndx, dVals, dFixed, dZeros, dSolved, dSlabs, dErr, lambda, k, 0, 0, 0u};
-    rc = launch_step<T>(a, (int64_t)units.size(), nSlabs, (int64_t)split.size(), stream, nullptr);
-    if (rc) {
-      cleanup();
-      return rc;
+    const T *dFixed = pinned ? (const T *)C.pinned.p : (const T *)C.fixed.p;
+    StepArgs<T> a{(const Unit *)C.units.p, (const SplitRow *)C.split.p, (const int32_t *)C.indx.p, (const T *)C.vals.p, dFixed, dZeros,
+                  (T *)C.solved.p, (T *)C.slabs.p, dErr, lambda, k, 0, 0, 0u};
+    if constexpr (std::is_same<T, float>::value) {
+      if (big) rc = launch_step_big(a, (int64_t)units.size(), nSlabs, (int64_t)split.size(), stream, nullptr, DualPlan());
+      else rc = launch_step<T>(a, (int64_t)units.size(), nSlabs, (int64_t)split.size(), stream, nullptr);
+    } else {
+      rc = launch_step<T>(a, (int64_t)units.size(), nSlabs, (int64_t)split.size(), stream, nullptr);
     }
+    if (rc) return rc;
   }
-  L1_TRY(hipMemcpyAsync(hostSolved.data(), dSolved, sizeof(T) * hostSolved.size(), hipMemcpyDeviceToHost, stream));
+  L1_TRY(hipMemcpyAsync(hostSolved.data(), C.solved.p, sizeof(T) * hostSolved.size(), hipMemcpyDeviceToHost, stream));
   L1_TRY(hipMemcpyAsync(&ei, dErr, sizeof ei, hipMemcpyDeviceToHost, stream));
   L1_TRY(hipStreamSynchronize(stream));
 #undef L1_TRY
-  cleanup();
-  (void)dtype;
   if (ei.count > 0)
     return fail(YCNR_ERR_NUMERIC, "%d row(s) of the portion had a normal matrix that is not positive definite", ei.count);
   for (int r = 0; r < nRows; ++r) {
@@ -1874,6 +1996,17 @@ int64_t ycnr_dAlsCalcPortion(double lambda, int k, const int32_t *alsRows, const
                              const double *fixedFactors, int64_t fixedRows, double *solvedFactors, int64_t solvedRows) {
   return als_calc_portion<double>(lambda, k, alsRows, alsIndx, alsVals, fixedFactors, fixedRows, solvedFactors,
                                   solvedRows, YCNR_F64);
+}
+
+int ycnr_sAlsPinFixedFactors(const float *fixedFactors, int64_t fixedRows, int k) {
+  return pin_fixed<float>(fixedFactors, fixedRows, k, YCNR_F32);
+}
+int ycnr_dAlsPinFixedFactors(const double *fixedFactors, int64_t fixedRows, int k) {
+  return pin_fixed<double>(fixedFactors, fixedRows, k, YCNR_F64);
+}
+int ycnr_AlsReleasePortionState(void) {
+  l1ctx().release();
+  return YCNR_OK;
 }
 
 int ycnr_sRmsePortion(int k, const int32_t *rmseRows, const int32_t *rmseIndx, const float *rmseVals,

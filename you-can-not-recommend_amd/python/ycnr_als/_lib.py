@@ -24,6 +24,7 @@ FLAG_NO_OVERLAP = 64
 EXPORTS = [
     "ycnr_last_error", "ycnr_version", "ycnr_device_count",
     "ycnr_sAlsCalcPortion", "ycnr_dAlsCalcPortion", "ycnr_sRmsePortion", "ycnr_dRmsePortion",
+    "ycnr_sAlsPinFixedFactors", "ycnr_dAlsPinFixedFactors", "ycnr_AlsReleasePortionState",
     "ycnr_als_create", "ycnr_als_destroy", "ycnr_als_set_stream", "ycnr_als_set_ratings",
     "ycnr_als_set_rmse_ratings", "ycnr_als_set_factors", "ycnr_als_get_factors", "ycnr_als_factors_ptr",
     "ycnr_als_bind_factors", "ycnr_als_step", "ycnr_als_step_async", "ycnr_als_sync",
@@ -95,6 +96,12 @@ def load():
         f = getattr(L, f"ycnr_{p}RmsePortion")
         f.restype = i32
         f.argtypes = [i32, vp, vp, vp, vp, i64, vp, i64, dbl, vp]
+    for p in "sd":
+        f = getattr(L, f"ycnr_{p}AlsPinFixedFactors")
+        f.restype = i32
+        f.argtypes = [vp, i64, i32]
+    L.ycnr_AlsReleasePortionState.restype = i32
+    L.ycnr_AlsReleasePortionState.argtypes = []
     L.ycnr_als_create.restype = i32
     L.ycnr_als_create.argtypes = [C.POINTER(Options), C.POINTER(vp)]
     L.ycnr_als_destroy.restype = i32

@@ -64,6 +64,20 @@ def als_calc_portion(lam, k, alsRows, alsIndx, alsVals, fixedFactors, solvedFact
                    solvedFactors.size // k))
 
 
+def pin_fixed_factors(fixedFactors, k):
+    """Level 1, once per half-step: keep the step's fixed factor matrix on the device for the portion
+    calls that follow (ycnr_{s,d}AlsPinFixedFactors)."""
+    L = _lib.load()
+    p = _portion_prefix(fixedFactors)
+    if not fixedFactors.flags["C_CONTIGUOUS"]:
+        raise TypeError("invalid type!")
+    check(getattr(L, f"ycnr_{p}AlsPinFixedFactors")(fixedFactors.ctypes.data, fixedFactors.size // k, int(k)))
+
+
+def release_portion_state():
+    check(_lib.load().ycnr_AlsReleasePortionState())
+
+
 def rmse_portion(k, rmseRows, rmseIndx, rmseVals, userFactors, itemFactors, globalAvgShift=0.0):
     """Level 1: drop-in for EmfWorker.mw_calcRmsePortion (EmfWorker.js:266-315).
     Returns np.array([rSumDiff2, rCnt, rSum])."""
