@@ -11,9 +11,14 @@ const { Dataset, rng } = require(path.join(root, 'lib', 'Dataset'));
 
 const n = als.native;
 for (const f of ['sAlsCalcPortion', 'dAlsCalcPortion', 'sRmsePortion', 'dRmsePortion', 'create', 'destroy', 'setRatings',
-  'setRmseRatings', 'setFactors', 'getFactors', 'step', 'rmse', 'deviceCount', 'lastError', 'version'])
+  'setRmseRatings', 'setFactors', 'getFactors', 'step', 'rmse', 'deviceCount', 'lastError', 'version',
+  'commUniqueId', 'commInit', 'setRatingsSharded', 'allreduceSum', 'broadcastFactors', 'exchange'])
   assert.strictEqual(typeof n[f], 'function', f);
-assert.strictEqual(n.version(), 1);
+assert.strictEqual(n.version(), 2);
+// the communicator id of the shared-memory stand-in needs no GPU: 128 bytes, not all zero, new every time
+const id1 = n.commUniqueId(als.COMM_SHM), id2 = n.commUniqueId(als.COMM_SHM);
+assert.strictEqual(id1.length, 128);
+assert.ok(id1.some((b) => b != 0) && Buffer.compare(Buffer.from(id1), Buffer.from(id2)) != 0);
 
 // s/d dispatch and Error('invalid type!') exactly like cpp_utils/cpp_utils.js:6-19
 assert.throws(() => als.alsCalcPortion(0.05, 4, new Int32Array([1, 0, 1]), new Int32Array([0]), new Int16Array([1]),
@@ -39,6 +44,11 @@ lord.getStats().then(() => lord.splitToPortions()).then(() => {
   out.trainNnz = ds.trainByUser.nnz;
   out.byItemIndxHead = Array.from(ds.trainByItem.indx.slice(0, 10));
   out.totalRatingsAvg = ds.totalRatingsAvg;
+  // cost-balanced shard cuts (checked against the Python mirror's shard_ranges)
+  const EmfMaster = require(path.join(root, 'lib', 'emf', 'EmfMaster'));
+  out.shards = {};
+  for (const [w, k] of [[2, 8], [3, 100], [8, 256]])
+    out.shards[w + '_' + k] = EmfMaster.shardRanges(ds.trainByUser.rowPtr, 0, ds.trainByUser.rows, w, k, false);
   let gpu = true;
   try { n.deviceCount(); } catch (e) { gpu = false; out.deviceCountError = e.message; }
   if (gpu) return;

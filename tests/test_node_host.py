@@ -47,6 +47,10 @@ def test_js_host_on_cpu(tmp_path):
         assert out["portionsRowIdTo"][step] == ends.tolist(), step
         assert out["maxRatingsInPortion"][step] == rip and out["maxRowsInPortion"][step] == mrows
     assert abs(out["totalRatingsAvg"] - float(bu.vals.mean())) < 1e-6
+    from ycnr_als.emf import shard_ranges
+    for key, got in out["shards"].items():
+        w, k = (int(x) for x in key.split("_"))
+        assert got == shard_ranges(cnt_u, w, k).tolist(), key
     if "prepareError" in out:  # no GPU here: loud failure, carrying the library's message
         assert "hip" in out["prepareError"].lower()
 
@@ -107,6 +111,36 @@ def test_js_train_matches_python_host(tmp_path, double):
     assert cj["calcCnt"] == 2 and cp["calcCnt"] == 1  # the JS run warm-started from a saved calc
     assert out["checkpoints"] == len(out["history"])    # one save per iteration: n - 1 checkpoints + the final one
     assert out["portionRatings"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("double", [False, True])
+def test_js_train_on_per_gpu_processes(tmp_path, double):
+    """The NodeJS Lord forks 2 and 3 per-GPU processes (here sharing cuda:0 through the shared-memory
+    transport): sharded upload, pipelined pieces, exchange and all-reduce through the addon.  Result files
+    and RMSE history must equal the single-process run's."""
+    dt = np.float64 if double else np.float32
+    bu, user, typ, U, V = problem(seed=9, users=120, items=70)
+    res = {}
+    for world in (1, 2, 3):
+        d = tmp_path / f"w{world}"
+        inp = {"dir": str(d), "k": 12, "iters": 3, "rip": 40, "threads": 2, "useDoublePrecision": double, "world": world,
+               "users": bu.rows, "items": bu.cols, "user": user.tolist(), "item": bu.indx.tolist(),
+               "rating": bu.vals.astype(dt).tolist(), "type": typ.tolist()}
+        (tmp_path / f"in{world}.json").write_text(json.dumps(inp))
+        r = subprocess.run(["node", os.path.join(HERE, "js", "train_gpu_ranks.js"), str(tmp_path / f"in{world}.json")],
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[world] = json.loads(r.stdout.strip().splitlines()[-1])
+    for world in (2, 3):
+        for name in ("user_factors", "item_factors"):
+            a = np.fromfile(tmp_path / "w1" / "ml_factors_ready" / name, dt)
+            b = np.fromfile(tmp_path / f"w{world}" / "ml_factors_ready" / name, dt)
+            assert a.size == (bu.rows if name[0] == "u" else bu.cols) * 12 and np.array_equal(a, b), (world, name)
+        for h1, hw in zip(res[1]["history"], res[world]["history"]):
+            for key in ("rmseValidate", "rmseTest", "rmseTestShifted", "globalAvgShift"):
+                assert abs(h1[key] - hw[key]) < 1e-12, (world, key)
+        assert res[world]["stepInfo"]["exchangeBytes"] > 0
 
 
 @pytest.mark.gpu

@@ -365,7 +365,99 @@ napi_value Step(napi_env env, napi_callback_info info) {
   set_num(env, o, "reduceSolveMs", si.reduceSolveMs);
   set_num(env, o, "dualOverlapped", (double)si.dualOverlapped);
   set_num(env, o, "time", si.totalMs);  // 'time' of 'completedPortion', EmfWorker.js:258
+  set_num(env, o, "parts", (double)si.parts);
+  set_num(env, o, "exchangeBytes", (double)si.exchangeBytes);
+  set_num(env, o, "exchangeMs", si.exchangeMs);
+  set_num(env, o, "exposedExchangeMs", si.exposedExchangeMs);
   return o;
+}
+
+// ---- multi-GPU exchange (include/ycnr_als.h "multi-GPU"): the Lord process creates the id and hands it to
+// the per-GPU processes it forks (process.send), replacing the TCP cluster of EmfLord.initClusterLord /
+// EmfChief.initClusterChief (lib/emf/EmfLord.js:668-747, lib/emf/EmfChief.js:87-231)
+
+// commUniqueId(transport) -> Uint8Array(128)
+napi_value CommUniqueId(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value a[1];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, a, nullptr, nullptr));
+  int64_t transport;
+  if (argc < 1 || !get_int(env, a[0], &transport)) return throw_msg(env, "commUniqueId(transport)");
+  napi_value ab, out;
+  void *buf = nullptr;
+  NAPI_OK(napi_create_arraybuffer(env, YCNR_COMM_ID_BYTES, &buf, &ab));
+  NAPI_OK(napi_create_typedarray(env, napi_uint8_array, YCNR_COMM_ID_BYTES, ab, 0, &out));
+  int rc = ycnr_comm_unique_id((int)transport, buf);
+  if (rc) return throw_last(env, "commUniqueId", rc);
+  return out;
+}
+
+// commInit(handle, transport, id: Uint8Array(128), rank, world)
+napi_value CommInit(napi_env env, napi_callback_info info) {
+  size_t argc = 5;
+  napi_value a[5];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, a, nullptr, nullptr));
+  Handle *hd = argc >= 5 ? handle_of(env, a[0]) : nullptr;
+  int64_t transport, rank, world;
+  if (!hd || !get_int(env, a[1], &transport) || !get_int(env, a[3], &rank) || !get_int(env, a[4], &world))
+    return throw_msg(env, "commInit(handle, transport, id, rank, world)");
+  View id = view_of(env, a[2]);
+  if (!id.ok || id.type != napi_uint8_array || id.length != YCNR_COMM_ID_BYTES) return throw_msg(env, "commInit: id must be a Uint8Array(128)");
+  int rc = ycnr_als_comm_init(hd->h, (int)transport, id.data, (int)rank, (int)world);
+  if (rc) return throw_last(env, "commInit", rc);
+  return nullptr;
+}
+
+// setRatingsSharded(handle, side, rowPtr, indx, vals, nChunks, bounds: Float64Array(world * (nChunks + 1)))
+napi_value SetRatingsSharded(napi_env env, napi_callback_info info) {
+  size_t argc = 7;
+  napi_value a[7];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, a, nullptr, nullptr));
+  if (argc < 7) return throw_msg(env, "setRatingsSharded(handle, side, rowPtr, indx, vals, nChunks, bounds)");
+  Handle *hd = handle_of(env, a[0]);
+  int64_t side, nChunks;
+  if (!hd || !get_int(env, a[1], &side) || !get_int(env, a[5], &nChunks) || (side != 0 && side != 1)) return throw_msg(env, "bad handle, side or nChunks");
+  View rp = view_of(env, a[2]), indx = view_of(env, a[3]), vals = view_of(env, a[4]), bv = view_of(env, a[6]);
+  const napi_typedarray_type ft = hd->dtype == YCNR_F64 ? napi_float64_array : napi_float32_array;
+  if (!rp.ok || !indx.ok || !vals.ok || !bv.ok || indx.type != napi_int32_array || vals.type != ft) return throw_msg(env, "invalid type!");
+  std::vector<int64_t> rowPtr, bounds;
+  if (!to_i64(rp, rowPtr) || rowPtr.empty() || !to_i64(bv, bounds)) return throw_msg(env, "invalid type!");
+  if ((int64_t)rowPtr.size() != hd->rows[side] + 1) return throw_msg(env, "rowPtr must have rows + 1 entries");
+  if (nChunks < 1 || bounds.empty() || bounds.size() % (size_t)(nChunks + 1) != 0) return throw_msg(env, "bounds must hold world * (nChunks + 1) row ids");
+  if (rowPtr.back() < 0 || (size_t)rowPtr.back() > indx.length || (size_t)rowPtr.back() > vals.length)
+    return throw_msg(env, "indx / vals shorter than rowPtr says");
+  int rc = ycnr_als_set_ratings_sharded(hd->h, (int)side, rowPtr.data(), static_cast<const int32_t *>(indx.data), vals.data, YCNR_MEM_HOST,
+                                        (int)nChunks, bounds.data());
+  if (rc) return throw_last(env, "setRatingsSharded", rc);
+  return nullptr;
+}
+
+// allreduceSum(handle, Float64Array) -> the same array, summed over the ranks in place
+napi_value AllreduceSum(napi_env env, napi_callback_info info) {
+  size_t argc = 2;
+  napi_value a[2];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, a, nullptr, nullptr));
+  Handle *hd = argc >= 2 ? handle_of(env, a[0]) : nullptr;
+  if (!hd) return throw_msg(env, "allreduceSum(handle, Float64Array)");
+  View v = view_of(env, a[1]);
+  if (!v.ok || v.type != napi_float64_array) return throw_msg(env, "invalid type!");
+  int rc = ycnr_als_allreduce_sum(hd->h, static_cast<double *>(v.data), (int64_t)v.length);
+  if (rc) return throw_last(env, "allreduceSum", rc);
+  return a[1];
+}
+
+// broadcastFactors(handle, side, root); exchange(handle, side)
+template <bool BCAST>
+napi_value CommSide(napi_env env, napi_callback_info info) {
+  size_t argc = 3;
+  napi_value a[3];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, a, nullptr, nullptr));
+  Handle *hd = argc >= 2 ? handle_of(env, a[0]) : nullptr;
+  int64_t side, root = 0;
+  if (!hd || !get_int(env, a[1], &side) || (BCAST && (argc < 3 || !get_int(env, a[2], &root)))) return throw_msg(env, BCAST ? "broadcastFactors(handle, side, root)" : "exchange(handle, side)");
+  int rc = BCAST ? ycnr_als_broadcast_factors(hd->h, (int)side, (int)root) : ycnr_als_exchange(hd->h, (int)side);
+  if (rc) return throw_last(env, BCAST ? "broadcastFactors" : "exchange", rc);
+  return nullptr;
 }
 
 // rmse(handle, which, globalAvgShift, portionRowEnd) -> Float64Array [rSumDiff2, rCnt, rSum] * nPortions
@@ -553,6 +645,12 @@ napi_value Init(napi_env env, napi_value exports) {
       {"csrFromTriplets", nullptr, CsrFromTriplets, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
       {"csrTranspose", nullptr, CsrTranspose, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
       {"recommendItems", nullptr, RecommendItems, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+      {"commUniqueId", nullptr, CommUniqueId, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+      {"commInit", nullptr, CommInit, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+      {"setRatingsSharded", nullptr, SetRatingsSharded, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+      {"allreduceSum", nullptr, AllreduceSum, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+      {"broadcastFactors", nullptr, CommSide<true>, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+      {"exchange", nullptr, CommSide<false>, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
   };
   napi_define_properties(env, exports, sizeof(props) / sizeof(props[0]), props);
   return exports;

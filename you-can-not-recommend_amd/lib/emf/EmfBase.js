@@ -60,6 +60,16 @@ class EmfBase extends EventEmitter {
       // (reference: <repo>/data), GPU work-unit size (0 = library default), seed of the
       // initial factors (reference: unseeded)
       device: 0,
+      // multi-GPU (not in the reference, whose cluster is TCP, lib/emf/EmfLord.js:668-747): `gpus` > 1 makes
+      // train() fork one process per GPU (EmfLord.trainOnGpus); inside such a process `rank` / `world` /
+      // `commId` / `commTransport` describe its place, and a large side is solved in `exchangeChunks`
+      // pieces so that the exchange of one piece overlaps with the solve of the next
+      gpus: 1,
+      rank: 0,
+      world: 1,
+      commId: null,
+      commTransport: 'rccl', // 'rccl' | 'shm' (functional stand-in: several ranks on one GPU)
+      exchangeChunks: 4,
       dataDir: path.join(__dirname, '..', '..', 'data'),
       chunkRatings: 0,
       seed: 1,

@@ -6,6 +6,9 @@
 'use strict';
 
 const EmfMaster = require('./EmfMaster');
+const { als } = require('./EmfBase');
+const child_process = require('child_process');
+const path = require('path');
 
 class EmfLord extends EmfMaster {
   /**
@@ -146,7 +149,7 @@ class EmfLord extends EmfMaster {
             this.trainIter++;
             // the reference's open todo "saveCalcResults every iter!" (lib/YcnrController.js:288): a
             // checkpoint the next train() warm-starts from (_loadSharedFactorsForTrain)
-            if (this.options.saveCalcResultsEveryIter && this.trainIter < this.options.trainIters)
+            if (this.options.saveCalcResultsEveryIter && this.trainIter < this.options.trainIters && this.options.rank == 0)
               return Promise.resolve(this.saveCalcResults(this.getCalcInfo())).then(loop);
             return loop();
           });
@@ -154,11 +157,47 @@ class EmfLord extends EmfMaster {
       return loop();
     }).then(() => {
       this.calcCnt++;
+      if (this.options.rank != 0) return Promise.resolve();  // one writer of the result files
       return this.saveCalcResults(this.getCalcInfo());
     }).then(() => {
       this._status = 'ready';
       return this.history;
     });
+  }
+
+  /**
+   * Multi-GPU train(): the Lord forks one process per GPU (cf. EmfMaster.createWorkers, lib/emf/EmfMaster.js:44-98:
+   * child_process.fork of the worker entry point), hands every one the same options, its rank and the
+   * communicator id the native library made (the role of the TCP registration of EmfLord.initClusterLord /
+   * EmfChief.initClusterChief, lib/emf/EmfLord.js:668-747, EmfChief.js:87-231), and waits for 'trained'.
+   * The per-GPU processes run in lockstep through the library's exchange; rank 0 writes the result files.
+   * @param datasetSpec {inline: {users, items, user[], item[], rating[], type[]}} or {dir, validate, test, totalRatingsAvg}
+   * @return Promise of rank 0's {history, calcInfo, stepInfo}
+   */
+  trainOnGpus(datasetSpec, config) {
+    const world = this.options.gpus, transport = this.options.commTransport;
+    if (!(world > 1)) return Promise.reject(new Error('trainOnGpus needs options.gpus > 1'));
+    const commId = Buffer.from(als.native.commUniqueId(als.commTransport[transport])).toString('base64');
+    let devices = 1;
+    try { devices = als.native.deviceCount(); } catch (e) { return Promise.reject(e); }
+    const kids = [];
+    const stop = () => kids.forEach((k) => { try { k.send({ cmd: 'destroy' }); } catch (e) { /* already gone */ } });
+    const all = (evt, after) => Promise.all(kids.map((k) => new Promise((resolve, reject) => {
+      const onMsg = (m) => {
+        if (m.evt == evt) { k.removeListener('message', onMsg); resolve(m); }
+        else if (m.evt == 'error') { k.removeListener('message', onMsg); reject(new Error(m.error)); }
+      };
+      k.on('message', onMsg);
+      k.once('exit', (code) => { if (code) reject(new Error('GPU process exited with code ' + code)); });
+      after(k);
+    })));
+    for (let r = 0; r < world; r++) kids.push(child_process.fork(path.join(__dirname, 'EmfGpuProcess.js'), [], { stdio: 'inherit' }));
+    const opts = Object.assign({}, this.options, { gpus: 1 });
+    return all('ready', (k) => {
+      const rank = kids.indexOf(k);
+      k.send({ cmd: 'init', config: config || {}, options: opts, rank, world, commId, device: rank % devices, dataset: datasetSpec });
+    }).then(() => all('trained', (k) => k.send({ cmd: 'train' })))
+      .then((res) => { stop(); return res[0]; }, (e) => { stop(); kids.forEach((k) => k.kill()); return Promise.reject(e); });
   }
 
   /** 2 steps - first fix item vectors and calc user vectors, then vice versa (EmfLord.js:954-958) */

@@ -28,13 +28,67 @@ class EmfMaster extends EmfManager {
     return Promise.resolve();
   }
 
+  /**
+   * Modelled cost of re-solving a row with n ratings (the constants of python/ycnr_als/emf.py row_cost,
+   * DESIGN.md 6): shards are cut so that they finish together, not so that they hold equal ratings.
+   */
+  static rowCost(n, k, double) {
+    if (n <= 0) return 0;
+    const nb = Math.ceil(k / 16);
+    const dualMax = (double || k % 4) ? 0 : 16 * Math.min(k > 128 ? 10 : 6, nb - 1);
+    if (n <= dualMax) return 3600.0 * Math.pow(Math.ceil(n / 16), 1.36) * (k / 100);
+    return n * (1.7 * k) + 0.025 * k * k * k;
+  }
+
+  /**
+   * parts + 1 ascending row ids cutting rows [lo0, hi0) into contiguous ranges of equal modelled cost: the
+   * greedy cumulative cut of splitToPortions (lib/emf/EmfLord.js:571-592) with one portion per GPU (or per
+   * pipelined piece of a GPU's shard).  Same rule as shard_ranges of the Python mirror.
+   */
+  static shardRanges(rowPtr, lo0, hi0, parts, k, double) {
+    const n = hi0 - lo0, cum = new Float64Array(n + 1);
+    for (let i = 0; i < n; i++) cum[i + 1] = cum[i] + EmfMaster.rowCost(rowPtr[lo0 + i + 1] - rowPtr[lo0 + i], k, double);
+    const b = [lo0];
+    for (let p = 1; p < parts; p++) {
+      const target = cum[n] * p / parts;
+      let lo = 0, hi = n + 1;  // first index whose cumulative cost reaches the target
+      while (lo < hi) {
+        const mid = (lo + hi) >> 1;
+        if (cum[mid] < target) lo = mid + 1; else hi = mid;
+      }
+      b.push(Math.max(b[b.length - 1], lo0 + Math.min(lo, n)));
+    }
+    b.push(hi0);
+    return b;
+  }
+
   /** Upload the ratings once: replaces createWorkPortionBuffers + per-portion fetches (EmfMaster.js:156-234,501-614) */
   prepareWorkersToTrain() {
-    const ds = this.dataset, n = als.native;
-    n.setRatings(this.handle, als.BY_USER, ds.trainByUser.rowPtr, ds.trainByUser.indx, ds.trainByUser.vals);
-    n.setRatings(this.handle, als.BY_ITEM, ds.trainByItem.rowPtr, ds.trainByItem.indx, ds.trainByItem.vals);
-    if (ds.validate) n.setRmseRatings(this.handle, als.RMSE_VALIDATE, ds.validate.rowPtr, ds.validate.indx, ds.validate.vals);
-    if (ds.test) n.setRmseRatings(this.handle, als.RMSE_TEST, ds.test.rowPtr, ds.test.indx, ds.test.vals);
+    const ds = this.dataset, n = als.native, o = this.options;
+    this.shardUsers = [0, this.totalUsersCount];
+    if (o.world > 1) {
+      // one process per GPU: this rank's place in the exchange, then the sharded upload of both sides
+      n.commInit(this.handle, als.commTransport[o.commTransport], Uint8Array.from(Buffer.from(o.commId, 'base64')), o.rank, o.world);
+      const k = this.factorsCount, dbl = o.useDoublePrecision, s1 = this.TypedArraySize1;
+      const sharded = (side, csr, rows) => {
+        const shards = EmfMaster.shardRanges(csr.rowPtr, 0, rows, o.world, k, dbl);
+        const nch = rows * k * s1 / o.world >= (8 << 20) ? Math.max(1, o.exchangeChunks) : 1;
+        const bounds = new Float64Array(o.world * (nch + 1));
+        for (let r = 0; r < o.world; r++)
+          bounds.set(EmfMaster.shardRanges(csr.rowPtr, shards[r], shards[r + 1], nch, k, dbl), r * (nch + 1));
+        n.setRatingsSharded(this.handle, side, csr.rowPtr, csr.indx, csr.vals, nch, bounds);
+        return shards;
+      };
+      const su = sharded(als.BY_USER, ds.trainByUser, this.totalUsersCount);
+      sharded(als.BY_ITEM, ds.trainByItem, this.totalItemsCount);
+      this.shardUsers = [su[o.rank], su[o.rank + 1]];
+    } else {
+      n.setRatings(this.handle, als.BY_USER, ds.trainByUser.rowPtr, ds.trainByUser.indx, ds.trainByUser.vals);
+      n.setRatings(this.handle, als.BY_ITEM, ds.trainByItem.rowPtr, ds.trainByItem.indx, ds.trainByItem.vals);
+    }
+    const [ub, ue] = this.shardUsers;
+    if (ds.validate) n.setRmseRatings(this.handle, als.RMSE_VALIDATE, ds.validate.rowPtr, ds.validate.indx, ds.validate.vals, ub, ue);
+    if (ds.test) n.setRmseRatings(this.handle, als.RMSE_TEST, ds.test.rowPtr, ds.test.indx, ds.test.vals, ub, ue);
     return Promise.resolve();
   }
 
@@ -59,6 +113,8 @@ class EmfMaster extends EmfManager {
     this.globalAvgShift = this.calcGlobalAvgShift ? 0 : this.globalAvgShift;
     const ends = Float64Array.from(this.portionsRowIdTo[stepType]);
     const parts = als.native.rmse(this.handle, als.rmseSet[stepType], this.globalAvgShift, ends);
+    // 'rmseSaveCalcs' (EmfMaster.js:726-736): every rank's partial sums of every portion, summed
+    if (this.options.world > 1) als.native.allreduceSum(this.handle, parts);
     this.rSum = 0; this.rSumDiff2 = 0; this.rCnt = 0;
     let last = -1;
     for (let p = 0; p < ends.length; p++) {
