@@ -170,8 +170,10 @@ def main():
             for sd in ("byUser", "byItem")}
 
     def x6_of(side):
+        # bf16x6 Gramian: the LDS-DMA kernels (k % 4 == 0, k <= 112, fixed matrix < 2 GB) and the
+        # workgroup-per-row kernels of k > 128 (als_wg_*, any fixed matrix size)
         fixed_rows = items if side == "byUser" else users
-        return (not args.double) and k % 4 == 0 and k <= 112 and fixed_rows * k * 4 < 2 ** 31
+        return (not args.double) and (k > 128 or (k % 4 == 0 and k <= 112 and fixed_rows * k * 4 < 2 ** 31))
 
     for st in lord.stepTimes:
         i = st["info"]
@@ -201,12 +203,8 @@ def main():
         else:
             whole_rows = (row_k, dual_k)
         for name, ms, fg, fs, by in whole_rows + (
-                # k > 128: this interval holds the Gramian and solve kernels of the 4-wave path, so the
-                # rows' solve work is priced here too
-                ("als_gram_big+als_solve_big" if k > 128 else "als_gram_slab_kernel", i.gramSlabMs,
-                 chunk_ratings * gram_rating, (i.splitRows * solve_row if k > 128 else 0), chunk_ratings * bytes_rating),
-                ("als_reduce_solve_kernel", i.reduceSolveMs, 0.0, 0 if k > 128 else i.splitRows * solve_row,
-                 i.splitRows * (k * s + 8))):
+                ("als_gram_slab_kernel", i.gramSlabMs, chunk_ratings * gram_rating, 0.0, chunk_ratings * bytes_rating),
+                ("als_reduce_solve_kernel", i.reduceSolveMs, 0.0, i.splitRows * solve_row, i.splitRows * (k * s + 8))):
             if fg + fs > 0:
                 d = kern.setdefault(f"{name}[{side}]", {"ms": 0.0, "fg": 0.0, "fs": 0.0, "bytes": 0.0, "launches": 0, "x6": x6})
                 d["ms"] += ms

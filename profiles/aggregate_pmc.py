@@ -20,9 +20,9 @@ import json
 import os
 import sys
 
-BENCH_NAME = (("als_gram_solve", "als_gram_solve_kernel"), ("als_dual_solve", "als_dual_solve_kernel"),
-              ("als_gram_slab", "als_gram_slab_kernel"), ("als_gram_big", "als_gram_big+als_solve_big"),
-              ("als_solve_big", "als_gram_big+als_solve_big"), ("als_reduce_solve", "als_reduce_solve_kernel"))
+# kernel name fragment -> bench.py's entry (the workgroup-per-row kernels of k > 128, als_wg_*, fill the same roles)
+BENCH_NAME = (("gram_solve", "als_gram_solve_kernel"), ("dual_solve", "als_dual_solve_kernel"),
+              ("gram_slab", "als_gram_slab_kernel"), ("reduce_solve", "als_reduce_solve_kernel"))
 
 
 def main():
@@ -45,18 +45,14 @@ def main():
     half, seen, prev = 1, set(), ""
     for did in order:
         n = rows[did]["name"].split("(")[0]
-        slab = "als_gram_slab" in n
-        big = "als_gram_big" in n or "als_solve_big" in n
-        prev_big = "als_gram_big" in prev or "als_solve_big" in prev
+        slab = "gram_slab" in n
         new_half = False
         if seen:
-            if "als_reduce_solve" in prev:
+            if "reduce_solve" in prev:
                 new_half = True
-            elif slab and "als_gram_slab" not in prev:
+            elif slab and "gram_slab" not in prev:
                 new_half = True
-            elif big and not prev_big:
-                new_half = True
-            elif n in seen and not big and not slab:
+            elif n in seen and not slab:
                 new_half = True
         if new_half:
             half += 1
