@@ -126,6 +126,27 @@ napi_value AlsCalcPortion(napi_env env, napi_callback_info info) {
   return num(env, (double)n);
 }
 
+// s/dAlsPinFixedFactors(fixedFactors, k): keep the step's fixed matrix on the device for the portion calls that follow
+template <bool DOUBLE>
+napi_value AlsPinFixedFactors(napi_env env, napi_callback_info info) {
+  size_t argc = 2;
+  napi_value a[2];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, a, nullptr, nullptr));
+  int64_t k;
+  if (argc < 2 || !get_int(env, a[1], &k) || k < 1) return throw_msg(env, "AlsPinFixedFactors(fixedFactors, k)");
+  View fixed = view_of(env, a[0]);
+  if (!fixed.ok || fixed.type != (DOUBLE ? napi_float64_array : napi_float32_array)) return throw_msg(env, "invalid type!");
+  int rc = DOUBLE ? ycnr_dAlsPinFixedFactors(static_cast<const double *>(fixed.data), (int64_t)(fixed.length / k), (int)k)
+                  : ycnr_sAlsPinFixedFactors(static_cast<const float *>(fixed.data), (int64_t)(fixed.length / k), (int)k);
+  if (rc) return throw_last(env, "AlsPinFixedFactors", rc);
+  return nullptr;
+}
+napi_value AlsReleasePortionState(napi_env env, napi_callback_info) {
+  ycnr_AlsReleasePortionState();
+  (void)env;
+  return nullptr;
+}
+
 template <bool DOUBLE>
 napi_value RmsePortion(napi_env env, napi_callback_info info) {
   size_t argc = 7;
@@ -645,6 +666,9 @@ napi_value Init(napi_env env, napi_value exports) {
       {"csrFromTriplets", nullptr, CsrFromTriplets, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
       {"csrTranspose", nullptr, CsrTranspose, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
       {"recommendItems", nullptr, RecommendItems, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+      {"sAlsPinFixedFactors", nullptr, AlsPinFixedFactors<false>, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+      {"dAlsPinFixedFactors", nullptr, AlsPinFixedFactors<true>, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+      {"alsReleasePortionState", nullptr, AlsReleasePortionState, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
       {"commUniqueId", nullptr, CommUniqueId, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
       {"commInit", nullptr, CommInit, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
       {"setRatingsSharded", nullptr, SetRatingsSharded, nullptr, nullptr, nullptr, napi_enumerable, nullptr},

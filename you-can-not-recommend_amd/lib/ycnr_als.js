@@ -41,6 +41,17 @@
   };
 
   /**
+   * Optional, once per half-step (where the worker handles 'startTrainStep', lib/emf/EmfWorker.js:43-51): keep the
+   * step's fixed factor matrix on the device, so that the portion calls that follow with the same typed array
+   * skip the per-portion gather + upload -- the replacement of the per-rating BLAS.BufCopy of
+   * EmfBase.copySubFixedFactors (lib/emf/EmfBase.js:537-555).  Pin again after the matrix has changed.
+   */
+  als.alsPinFixedFactors = function (fixedFactors, factorsCount) {
+    return typeCheck(fixedFactors) ? native.dAlsPinFixedFactors(fixedFactors, factorsCount) :
+      native.sAlsPinFixedFactors(fixedFactors, factorsCount);
+  };
+
+  /**
    * Drop-in for EmfWorker.mw_calcRmsePortion (lib/emf/EmfWorker.js:266-315).
    * Returns {rSumDiff2, rCnt, rSum}.
    */
