@@ -578,10 +578,10 @@ def test_full_iterations_ml100k_shape(als, oracle):
     assert h1[-1]["rmseValidate"] < h1[0]["rmseValidate"]  # it learns
 
 
-@pytest.mark.parametrize("world", [2, 8])
+@pytest.mark.parametrize("world", [2, 4])
 def test_ranks_on_one_gpu_equal_one_rank(tmp_path, world):
-    """The sharded HIP path end to end: 2 / 8 gloo ranks sharing cuda:0 (functional stand-in for
-    that many GPUs over RCCL) must reproduce the single-process factors bit for bit -- shard
+    """The sharded HIP path end to end: 2 / 4 gloo ranks sharing cuda:0 (functional stand-in for
+    that many GPUs over RCCL; the GPU boxes allow at most 6 processes on the card, this one included) must reproduce the single-process factors bit for bit -- shard
     ranges, per-shard CSR upload, the chunked pipelined exchange, the padded all-gather and
     the RMSE all-reduce included."""
     import subprocess
