@@ -43,6 +43,42 @@ _ZN4ycnr3badEv: ; @bad
 """
 
 
+DPP_GOOD = """
+_ZN4ycnr7dppgoodEv: ; @dppgood
+	v_mul_f32 v6, v6, v3
+	s_nop 1
+	v_fmac_f32_dpp v4, -v6, v2 row_newbcast:1 row_mask:0xf bank_mask:0xf bound_ctrl:1
+	v_mov_b32_e32 v9, v4
+	v_add_f32_e32 v1, v1, v1
+	v_add_f32_e32 v1, v1, v1
+	v_add_f32_dpp v9, v9, v9 row_ror:8 row_mask:0xf bank_mask:0xf
+	s_endpgm
+"""
+
+DPP_BAD = """
+_ZN4ycnr6dppbadEv: ; @dppbad
+	s_cbranch_scc1 .LBB0_2
+	v_accvgpr_read_b32 v6, a3
+	s_branch .LBB0_3
+.LBB0_2:
+	v_mov_b32_e32 v6, v7
+	s_nop 0
+.LBB0_3:
+	v_fmac_f32_dpp v4, -v6, v2 row_newbcast:1 row_mask:0xf bank_mask:0xf bound_ctrl:1
+	s_endpgm
+"""
+
+
+def test_dpp_lint_counts_wait_states_over_every_path(tmp_path, capsys):
+    lint = load_lint()
+    good, bad = tmp_path / "good.s", tmp_path / "bad.s"
+    good.write_text(DPP_GOOD)
+    bad.write_text(DPP_BAD)
+    assert lint.lint_dpp(str(good), []) == 0
+    assert lint.lint_dpp(str(bad), []) == 2  # the AGPR reload through the branch, the copy one wait state before the label
+    assert "FAIL" in capsys.readouterr().out
+
+
 def test_lint_accepts_waited_uses_and_flags_premature_ones(tmp_path, capsys):
     lint = load_lint()
     good, bad = tmp_path / "good.s", tmp_path / "bad.s"
@@ -62,3 +98,6 @@ def test_device_assembly_has_no_premature_lds_uses(tmp_path):
                     "-I" + os.path.join(ROOT, "include"), "--cuda-device-only", "-S", "-o", str(out),
                     os.path.join(CSRC, "ycnr_als.hip")], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     assert lint.lint(str(out), []) == 0
+    # the inline-asm v_fmac_f32_dpp pivot updates: no compiler-inserted copy may sit within two wait states
+    # in front of one
+    assert lint.lint_dpp(str(out), []) == 0

@@ -46,6 +46,11 @@
 #ifndef YCNR_SLAB_PREFETCH
 #define YCNR_SLAB_PREFETCH 3
 #endif
+// Pivots of the float32 diagonal tile: 1 = multipliers by DPP row_newbcast from a copy of the pivot
+// column replicated into every 16-lane row (one instruction per updated column), 0 = v_readlane + v_fma
+#ifndef YCNR_DPP_PIVOTS
+#define YCNR_DPP_PIVOTS 1
+#endif
 #ifndef YCNR_SLAB_WAVES_PER_SIMD
 #define YCNR_SLAB_WAVES_PER_SIMD 2
 #endif
@@ -756,6 +761,58 @@ struct SolveMfmaF32 {
     out[3] = r3;
   }
 
+  // value of lane N of the caller's 16-lane row, in every lane of the row (DPP row_newbcast)
+  template <int N>
+  static __device__ __forceinline__ float row_bcast(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + N, 0xF, 0xF, true));
+  }
+  // Pivot P of the diagonal tile without v_readlane.  Lane groups 0 / 2 hold the rows of D (lane i: row i),
+  // groups 1 / 3 the columns of the identity that become L^-1.  The multiplier of column j is L[j][P], the
+  // value lane j of group 0 has in R[P]: one v_permlane16_swap copies that register's group 0 / 2 values into
+  // groups 1 / 3, after which every 16-lane row finds L[j][P] in its own lane j and the update of column j
+  // is ONE v_fmac_f32 with a DPP row_newbcast operand for all four groups (v_readlane + v_fma before).
+  // Same products, same fma: bit for bit the results of the v_readlane form.
+  // Pivot P of the diagonal tile without v_readlane for the multipliers.  The multiplier of column j is
+  // L[j][P], the value lane j of group 0 has in R[P]: one v_permlane16_swap copies that register's group
+  // 0 / 2 values into groups 1 / 3, after which every 16-lane row finds L[j][P] in its own lane j and the
+  // update of column j is ONE v_fmac_f32 with a DPP row_newbcast operand for all four groups (v_readlane +
+  // v_fma before): same products, same fma, bit for bit the results of the v_readlane form.
+  // hipcc does not fold a DPP move into v_fmac, so the updates are inline asm, one statement each (the
+  // compiler interleaves the next pivot's v_readlane -> v_rsq -> scale chain with them; asm statements
+  // grouped per pivot behind scheduling barriers were slower).  hipcc pads no hazards for inline asm: the
+  // two wait states a DPP read needs after a VALU write of its source follow the multiply that produces l,
+  // and devtest/isa_lint.py checks on the device assembly of every build that no register copy the
+  // compiler put in front of a v_fmac_f32_dpp breaks that (tests/test_isa_lint.py).
+  template <int P, int Jn>
+  struct PivotDpp {
+    static __device__ __forceinline__ void updates(float (&R)[16], float l) {
+      if constexpr (Jn < 16) {
+        asm("v_fmac_f32_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+            : "+v"(R[Jn])
+            : "v"(l), "v"(R[P]), "n"(Jn));
+        PivotDpp<P, Jn + 1>::updates(R, l);
+      }
+    }
+  };
+  // Pivots P .. N-1 (N = 4, 8, 12 or 16; pivots past the real ones are rows of the identity: scale 1,
+  // multipliers 0, exact -- a count fixed at compile time keeps the sequence free of branches)
+  template <int P, int N>
+  static __device__ __forceinline__ void pivots_dpp(float (&R)[16], float &dmin) {
+    if constexpr (P < N) {
+      float a = R[P], b = R[P];
+      // a.row1 <-> b.row0, a.row3 <-> b.row2: a = column P of D in all four rows (b is scratch)
+      asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+      const float d = readlane(R[P], P);
+      dmin = fminf(dmin, d);
+      const float rs = __builtin_amdgcn_rsqf(d);
+      R[P] *= rs;  // L[i][P] in groups 0 / 2, Linv[P][c] in groups 1 / 3
+      float l;     // L[j][P] in lane j of every 16-lane row
+      asm("v_mul_f32 %0, %1, %2\n\ts_nop 1" : "=v"(l) : "v"(a), "v"(rs));
+      PivotDpp<P, P + 1>::updates(R, l);
+      pivots_dpp<P + 1, N>(R, dmin);
+    }
+  }
+
   // Solves (A + lam I) x = b.  In: upper tiles of A in acc, per-lane-group partials of b in
   // bacc.  Out: xcol[cb] = x[16 cb + c] in every lane group; returns true when a real pivot
   // was not positive.  acc is destroyed.
@@ -808,6 +865,20 @@ struct SolveMfmaF32 {
           R[4 * m4 + 3] = xlane ? (c == 4 * m4 + 3 ? 1.0f : 0.0f) : v.w;
         }
       }
+#if YCNR_DPP_PIVOTS
+      // padded pivots (index >= k; only the last tile has any) are skipped; one-tile systems run all 16
+      // (see the v_readlane form below for why)
+      if (NB > 1 && J == NB - 1) {
+        // the last tile of a system with more than one: only the real pivots, in fours (wave-uniform)
+        const int n4 = (k - J * 16 + 3) >> 2;
+        if (n4 == 1) pivots_dpp<0, 4>(R, dmin);
+        else if (n4 == 2) pivots_dpp<0, 8>(R, dmin);
+        else if (n4 == 3) pivots_dpp<0, 12>(R, dmin);
+        else pivots_dpp<0, 16>(R, dmin);
+      } else {
+        pivots_dpp<0, 16>(R, dmin);
+      }
+#else
 #pragma unroll
       for (int p = 0; p < 16; ++p) {
         // padded pivots (index >= k) are rows of the identity: their scale is 1 and their
@@ -843,6 +914,7 @@ struct SolveMfmaF32 {
           }
         }
       }
+#endif
       // ---- 2. W = L^-1 (column c in lanes 16-31) -> LDS -> C/D layout and A-operand layout
       if (g == 1) {
         float4 *dst = reinterpret_cast<float4 *>(Wt + c * LDW);

@@ -16,6 +16,15 @@ come out clean too (the compiler waits before every use): that is the self-check
 
 Limits: straight-line walk (a loop back-edge is not followed; a branch does not reset the FIFO),
 scalar memory loads share the counter but may return out of order and are ignored.
+
+Second check (DPP): a DPP instruction must not read, through its DPP operand (src0), a VGPR that a
+vector-ALU instruction wrote less than two wait states earlier (gfx9 data hazard "VALU writes VGPR ->
+DPP reads that VGPR").  hipcc inserts the wait states between instructions it generates itself but not
+around inline asm: the pivot updates of SolveMfmaF32 are inline-asm `v_fmac_f32_dpp` whose source is
+produced by an asm multiply followed by `s_nop 1`, and a register copy (or an AGPR reload) the compiler
+places directly in front of such a statement would break that silently.  The walk goes backwards from
+every DPP instruction over two wait states (`s_nop N` counts N + 1), through labels into every branch
+that targets them.
 """
 import re
 import sys
@@ -78,7 +87,92 @@ def lint(path, wanted):
     return total
 
 
+def _dest_regs(ins):
+    """VGPRs a vector-ALU instruction writes (first operand; both operands of a permlane swap)."""
+    parts = ins.split(None, 1)
+    if len(parts) < 2 or not parts[0].startswith("v_"):
+        return set()
+    ops = [o.strip() for o in parts[1].split(",")]
+    if parts[0].startswith("v_permlane") and "swap" in parts[0]:
+        return regs_of(ops[0]) | regs_of(ops[1])
+    if parts[0].startswith("v_cmp") or parts[0].startswith("v_readlane") or parts[0].startswith("v_readfirstlane"):
+        return set()
+    return regs_of(ops[0])
+
+
+def lint_dpp(path, wanted):
+    text = open(path).read()
+    total = checked = 0
+    for m in re.finditer(r"^(_Z[\w]+):[^\n]*$", text, re.M):
+        name = m.group(1)
+        if "ycnr" not in name or (wanted and not any(w in name for w in wanted)):
+            continue
+        end = text.find("s_endpgm", m.end())
+        ins_list, labels = [], {}
+        for raw in text[m.end():end].split("\n"):
+            ins = raw.split(";")[0].strip()
+            if not ins or ins.startswith("."):
+                if ins.endswith(":") and ins.startswith(".L"):
+                    labels[ins[:-1]] = len(ins_list)
+                continue
+            if ins.endswith(":"):
+                labels[ins[:-1]] = len(ins_list)
+                continue
+            ins_list.append(ins)
+        sources = {}  # label position -> indices of the branches that jump there
+        for i, ins in enumerate(ins_list):
+            op = ins.split()[0]
+            if op.startswith("s_cbranch") or op == "s_branch":
+                tgt = ins.split()[-1]
+                if tgt in labels:
+                    sources.setdefault(labels[tgt], []).append(i)
+        label_at = set(labels.values())
+
+        def writers(i, slots, depth=0):
+            """instructions in the `slots` wait states before instruction index i, over every path"""
+            out = []
+            j = i - 1
+            while slots > 0:
+                if j + 1 in label_at and depth < 4:
+                    for b in sources.get(j + 1, []):
+                        out += writers(b, slots, depth + 1)
+                if j < 0:
+                    break
+                prev = ins_list[j]
+                op = prev.split()[0]
+                if op == "s_branch":  # no fall-through from here
+                    break
+                if op == "s_nop":
+                    slots -= int(prev.split()[1]) + 1
+                else:
+                    out.append(prev)
+                    slots -= 1
+                j -= 1
+            return out
+
+        issues = 0
+        for i, ins in enumerate(ins_list):
+            op = ins.split()[0]
+            if "_dpp" not in op:
+                continue
+            checked += 1
+            ops = [o.strip() for o in ins.split(None, 1)[1].split(",")]
+            src = regs_of(ops[1].split()[0]) if len(ops) > 1 else set()
+            for w in writers(i, 2):
+                if _dest_regs(w) & src:
+                    issues += 1
+                    if issues <= 5:
+                        print(f"  {name[:70]}: '{ins[:60]}' reads v{sorted(src)} written by '{w}' less than two wait states earlier")
+        if issues:
+            print(f"FAIL {name[:90]}: {issues} DPP reads too early")
+        total += issues
+    print(f"DPP instructions checked: {checked}")
+    return total
+
+
 if __name__ == "__main__":
     n = lint(sys.argv[1], sys.argv[2:])
     print("premature uses:", n)
-    sys.exit(1 if n else 0)
+    nd = lint_dpp(sys.argv[1], sys.argv[2:])
+    print("DPP reads too early:", nd)
+    sys.exit(1 if n or nd else 0)
