@@ -927,41 +927,46 @@ struct SolveMfmaF32 {
         const float4 v = *reinterpret_cast<const float4 *>(Wt + c * LDW + 4 * g);
         W = acc_t{v.x, v.y, v.z, v.w};
       }
-      float Aop[4];  // A operand of MFMA q: W[i = c][kk = 4q + g]
+      // A operand of MFMA q: W[i = c][kk = 4g + q].  The contraction index of the four MFMAs of a tile
+      // product is split as kk = 4g + q (lane group g, MFMA q) instead of the natural 4q + g: any split
+      // works as long as both operands use it, and with this one register q of a tile in C/D layout
+      // (row 4g + q, column c) already IS the B operand of MFMA q -- the panel and the trailing update
+      // need no register <-> lane-group transposes (8 v_permlane swaps with their wait states per tile
+      // before).  Two lane groups share a bank pair here: conflict-free in each half of the wave.
+      float Aop[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) Aop[q] = Wt[(4 * q + g) * LDW + c];
+      for (int q = 0; q < 4; ++q) Aop[q] = Wt[(4 * g + q) * LDW + c];
       acc[tile_index(J, J, NB)] = W;
       // ---- 5a. z_J = W b_J, row form
 #pragma unroll
       for (int t = 0; t < 4; ++t) zrow[J][t] = row_sum(W[t] * bcol[J]);
       // ---- 3. panel tiles and 5b. rhs update
-      float Pt[NB > 1 ? NB - 1 : 1][4];  // transposed panel tiles, index bj - J - 1
 #pragma unroll
       for (int bj = J + 1; bj < NB; ++bj) {
-        float Bop[4];
-        transpose_rg(acc[tile_index(J, bj, NB)], Bop);
+        const acc_t T = acc[tile_index(J, bj, NB)];
         acc_t P = acc_t{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int q = 0; q < 4; ++q) P = Tr::mma(Aop[q], Bop[q], P);
+        for (int q = 0; q < 4; ++q) P = Tr::mma(Aop[q], T[q], P);
         acc[tile_index(J, bj, NB)] = P;  // U[J][bj]
-        transpose_rg(P, Pt[bj - J - 1]);
         float s = P[0] * zrow[J][0];
         s = fmaf(P[1], zrow[J][1], s);
         s = fmaf(P[2], zrow[J][2], s);
         s = fmaf(P[3], zrow[J][3], s);
         bcol[bj] -= group_sum(s);
       }
-      // ---- 4. trailing update
+      // ---- 4. trailing update: T[bi][bj] -= U[J][bi]^T U[J][bj], operands straight from the panel tiles
 #pragma unroll
       for (int bi = J + 1; bi < NB; ++bi) {
+        const acc_t Pi = acc[tile_index(J, bi, NB)];
         float nA[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) nA[q] = -Pt[bi - J - 1][q];
+        for (int q = 0; q < 4; ++q) nA[q] = -Pi[q];
 #pragma unroll
         for (int bj = bi; bj < NB; ++bj) {
+          const acc_t Pj = acc[tile_index(J, bj, NB)];
           acc_t t = acc[tile_index(bi, bj, NB)];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) t = Tr::mma(nA[q], Pt[bj - J - 1][q], t);
+          for (int q = 0; q < 4; ++q) t = Tr::mma(nA[q], Pj[q], t);
           acc[tile_index(bi, bj, NB)] = t;
         }
       }
