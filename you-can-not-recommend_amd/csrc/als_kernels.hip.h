@@ -826,10 +826,13 @@ struct SolveMfmaF32 {
     const int g = lane >> 4, c = lane & 15;
     float *Dt = S;             // D image, [row][col], row stride LDW
     float *Wt = S + 16 * LDW;  // W image stored transposed: Wt[col][row] = W[row][col]
-    // right-hand side in column form: bcol[cb] = b[16 cb + c], the same in all four lane groups
-    float bcol[NB];
+    // right-hand side as per-lane-group partials: b[16 cb + c] = sum over the four groups of bpart[cb].
+    // The updates b_bj -= U[J][bj]^T z_J subtract each group's share of the product; the sum over the
+    // groups is taken once per block, when the block becomes the pivot block (one cross-group sum per
+    // block instead of one per panel tile).
+    float bpart[NB];
 #pragma unroll
-    for (int cb = 0; cb < NB; ++cb) bcol[cb] = group_sum(bacc[cb]);
+    for (int cb = 0; cb < NB; ++cb) bpart[cb] = bacc[cb];
     // A += lam I on the real diagonal, 1 on the padded one (rows/cols >= k are otherwise 0)
     {
       const bool mine = (c >> 2) == g;
@@ -938,8 +941,11 @@ struct SolveMfmaF32 {
       for (int q = 0; q < 4; ++q) Aop[q] = Wt[(4 * g + q) * LDW + c];
       acc[tile_index(J, J, NB)] = W;
       // ---- 5a. z_J = W b_J, row form
+      {
+        const float bcolJ = group_sum(bpart[J]);  // b[16 J + c] after the updates of the block steps before
 #pragma unroll
-      for (int t = 0; t < 4; ++t) zrow[J][t] = row_sum(W[t] * bcol[J]);
+        for (int t = 0; t < 4; ++t) zrow[J][t] = row_sum(W[t] * bcolJ);
+      }
       // ---- 3. panel tiles and 5b. rhs update
 #pragma unroll
       for (int bj = J + 1; bj < NB; ++bj) {
@@ -948,11 +954,12 @@ struct SolveMfmaF32 {
 #pragma unroll
         for (int q = 0; q < 4; ++q) P = Tr::mma(Aop[q], T[q], P);
         acc[tile_index(J, bj, NB)] = P;  // U[J][bj]
-        float s = P[0] * zrow[J][0];
-        s = fmaf(P[1], zrow[J][1], s);
-        s = fmaf(P[2], zrow[J][2], s);
-        s = fmaf(P[3], zrow[J][3], s);
-        bcol[bj] -= group_sum(s);
+        float s = bpart[bj];
+        s = fmaf(-P[0], zrow[J][0], s);
+        s = fmaf(-P[1], zrow[J][1], s);
+        s = fmaf(-P[2], zrow[J][2], s);
+        s = fmaf(-P[3], zrow[J][3], s);
+        bpart[bj] = s;
       }
       // ---- 4. trailing update: T[bi][bj] -= U[J][bi]^T U[J][bj], operands straight from the panel tiles
 #pragma unroll
