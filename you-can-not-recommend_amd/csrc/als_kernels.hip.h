@@ -51,6 +51,10 @@
 #ifndef YCNR_DPP_PIVOTS
 #define YCNR_DPP_PIVOTS 1
 #endif
+// Primal float32 solve of k = 16 m + 4 factors: eliminate the four edge columns first (SolveMfmaF32::solve_edge4)
+#ifndef YCNR_EDGE4_SOLVE
+#define YCNR_EDGE4_SOLVE 1
+#endif
 #ifndef YCNR_SLAB_WAVES_PER_SIMD
 #define YCNR_SLAB_WAVES_PER_SIMD 2
 #endif
@@ -777,12 +781,19 @@ struct SolveMfmaF32 {
   // 0 / 2 values into groups 1 / 3, after which every 16-lane row finds L[j][P] in its own lane j and the
   // update of column j is ONE v_fmac_f32 with a DPP row_newbcast operand for all four groups (v_readlane +
   // v_fma before): same products, same fma, bit for bit the results of the v_readlane form.
-  // hipcc does not fold a DPP move into v_fmac, so the updates are inline asm, one statement each (the
-  // compiler interleaves the next pivot's v_readlane -> v_rsq -> scale chain with them; asm statements
-  // grouped per pivot behind scheduling barriers were slower).  hipcc pads no hazards for inline asm: the
-  // two wait states a DPP read needs after a VALU write of its source follow the multiply that produces l,
-  // and devtest/isa_lint.py checks on the device assembly of every build that no register copy the
-  // compiler put in front of a v_fmac_f32_dpp breaks that (tests/test_isa_lint.py).
+  // hipcc does not fold a DPP move into v_fmac, so the updates are inline asm (the compiler still
+  // interleaves the next pivot's v_readlane -> v_rsq -> scale chain with them; statements grouped per
+  // pivot behind scheduling barriers were slower).  hipcc pads no hazards around inline asm, so the asm
+  // is arranged to need none from it:
+  //   * the swap has the two wait states a v_permlane swap needs after a VALU write of its operands in
+  //     front and the two a DPP read needs after a VALU write of its source behind it;
+  //   * everything that consumes the v_rsq result is compiler-generated (a multiply inside asm directly
+  //     behind the v_rsq read a stale scale: the transcendental-result wait state was missing);
+  //   * column P + 1, which the next pivot's v_readlane reads, is updated together with column P + 2 in
+  //     one statement (or with an s_nop behind it), so one instruction always separates the two;
+  //   * devtest/isa_lint.py checks these three rules, and that no register copy the compiler placed in
+  //     front of a v_fmac_f32_dpp renews the DPP hazard, on the device assembly of every build
+  //     (tests/test_isa_lint.py).
   template <int P, int Jn>
   struct PivotDpp {
     static __device__ __forceinline__ void updates(float (&R)[16], float l) {
@@ -793,22 +804,34 @@ struct SolveMfmaF32 {
         PivotDpp<P, Jn + 1>::updates(R, l);
       }
     }
+    // columns P + 1 and P + 2 in one statement
+    static __device__ __forceinline__ void first_two(float (&R)[16], float l) {
+      if constexpr (P + 2 < 16) {
+        asm("v_fmac_f32_dpp %0, -%2, %3 row_newbcast:%4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_fmac_f32_dpp %1, -%2, %3 row_newbcast:%5 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+            : "+v"(R[P + 1]), "+v"(R[P + 2])
+            : "v"(l), "v"(R[P]), "n"(P + 1), "n"(P + 2));
+        PivotDpp<P, P + 3>::updates(R, l);
+      } else if constexpr (P + 1 < 16) {
+        asm("v_fmac_f32_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_nop 0"
+            : "+v"(R[P + 1])
+            : "v"(l), "v"(R[P]), "n"(P + 1));
+      }
+    }
   };
   // Pivots P .. N-1 (N = 4, 8, 12 or 16; pivots past the real ones are rows of the identity: scale 1,
   // multipliers 0, exact -- a count fixed at compile time keeps the sequence free of branches)
   template <int P, int N>
   static __device__ __forceinline__ void pivots_dpp(float (&R)[16], float &dmin) {
     if constexpr (P < N) {
-      float a = R[P], b = R[P];
-      // a.row1 <-> b.row0, a.row3 <-> b.row2: a = column P of D in all four rows (b is scratch)
-      asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
       const float d = readlane(R[P], P);
       dmin = fminf(dmin, d);
       const float rs = __builtin_amdgcn_rsqf(d);
       R[P] *= rs;  // L[i][P] in groups 0 / 2, Linv[P][c] in groups 1 / 3
-      float l;     // L[j][P] in lane j of every 16-lane row
-      asm("v_mul_f32 %0, %1, %2\n\ts_nop 1" : "=v"(l) : "v"(a), "v"(rs));
-      PivotDpp<P, P + 1>::updates(R, l);
+      float l = R[P], b = R[P];
+      // l.row1 <-> b.row0, l.row3 <-> b.row2: l = L[j][P] in lane j of every 16-lane row (b is scratch)
+      asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(l), "+v"(b));
+      PivotDpp<P, P + 1>::first_two(R, l);
       pivots_dpp<P + 1, N>(R, dmin);
     }
   }
@@ -1004,11 +1027,119 @@ struct SolveMfmaF32 {
     return !(dmin > 0.0f) || __any(!(chk == 0.0f));
   }
 
+  // k = 16 (NB - 1) + 4 (k = 100, 20, 36, ...): the last block has four real columns.  Instead of carrying
+  // them through every block step as a 16-wide tile column (108 of the 308 float32 MFMAs at NB = 7, one
+  // more diagonal tile and six panel tiles), they are eliminated FIRST:
+  //     A = [A11 A12; A21 A22],  A22 + lam I = C C^T (4 x 4),  V = C^-1 A21 (4 x 16 (NB-1)),  z2 = C^-1 b2
+  //     (A11 + lam I - V^T V) x1 = b1 - V^T z2      -- a rank-4 update: ONE MFMA of K = 4 per tile
+  //     x2 = C^-T (z2 - V x1)
+  // The 4 x 4 factor and its inverse are computed redundantly in every lane from v_readlane values; A21
+  // reaches the MFMA operand layout (lane (g, c): V[g][16 bi + c]) through a 256-byte LDS image per block.
+  // The (NB - 1)-block system then goes through the ordinary solve.  Cholesky with another elimination
+  // order: the same arithmetic class and error bound as the plain form.
+  static __device__ __forceinline__ bool solve_edge4(acc_t (&acc)[NT], const float (&bacc)[NB], float *S, float lam,
+                                                     float (&xcol)[NB], int lane) {
+    static_assert(NB >= 2 && (NB - 1) * 64 * sizeof(float) <= lds_bytes(), "edge image must fit the solver's LDS");
+    using Inner = SolveMfmaF32<NB - 1>;
+    constexpr int L = NB - 1;  // the edge block
+    const int g = lane >> 4, c = lane & 15;
+    // ---- A22 + lam I and b2, wave-uniform
+    const acc_t e = acc[tile_index(L, L, NB)];  // element (row 4g + t, col c) in reg t: rows 0..3 <-> lanes 0..15
+    const float a00 = readlane(e[0], 0) + lam;
+    const float a10 = readlane(e[1], 0), a11 = readlane(e[1], 1) + lam;
+    const float a20 = readlane(e[2], 0), a21 = readlane(e[2], 1), a22 = readlane(e[2], 2) + lam;
+    const float a30 = readlane(e[3], 0), a31 = readlane(e[3], 1), a32 = readlane(e[3], 2), a33 = readlane(e[3], 3) + lam;
+    const float bs = group_sum(bacc[L]);
+    const float b0 = readlane(bs, 0), b1 = readlane(bs, 1), b2 = readlane(bs, 2), b3 = readlane(bs, 3);
+    // ---- C = chol(A22) (lower), M = C^-1
+    const float r0 = __builtin_amdgcn_rsqf(a00);
+    const float l10 = a10 * r0, l20 = a20 * r0, l30 = a30 * r0;
+    const float d1 = fmaf(-l10, l10, a11);
+    const float r1 = __builtin_amdgcn_rsqf(d1);
+    const float l21 = fmaf(-l20, l10, a21) * r1, l31 = fmaf(-l30, l10, a31) * r1;
+    const float d2 = fmaf(-l21, l21, fmaf(-l20, l20, a22));
+    const float r2 = __builtin_amdgcn_rsqf(d2);
+    const float l32 = fmaf(-l31, l21, fmaf(-l30, l20, a32)) * r2;
+    const float d3 = fmaf(-l32, l32, fmaf(-l31, l31, fmaf(-l30, l30, a33)));
+    const float r3 = __builtin_amdgcn_rsqf(d3);
+    const float dmin = fminf(fminf(a00, d1), fminf(d2, d3));
+    const float m10 = -(l10 * r0) * r1;
+    const float m21 = -(l21 * r1) * r2;
+    const float m32 = -(l32 * r2) * r3;
+    const float m20 = -fmaf(l21, m10, l20 * r0) * r2;
+    const float m31 = -fmaf(l32, m21, l31 * r1) * r3;
+    const float m30 = -fmaf(l32, m20, fmaf(l31, m10, l30 * r0)) * r3;
+    // z2 = M b2
+    const float z0 = r0 * b0;
+    const float z1 = fmaf(m10, b0, r1 * b1);
+    const float z2 = fmaf(m20, b0, fmaf(m21, b1, r2 * b2));
+    const float z3 = fmaf(m30, b0, fmaf(m31, b1, fmaf(m32, b2, r3 * b3)));
+    // row g of M and z2[g] for this lane's group
+    const float Mg0 = g == 0 ? r0 : g == 1 ? m10 : g == 2 ? m20 : m30;
+    const float Mg1 = g == 0 ? 0.0f : g == 1 ? r1 : g == 2 ? m21 : m31;
+    const float Mg2 = g < 2 ? 0.0f : g == 2 ? r2 : m32;
+    const float Mg3 = g < 3 ? 0.0f : r3;
+    const float zg = g == 0 ? z0 : g == 1 ? z1 : g == 2 ? z2 : z3;
+    // ---- A21 through LDS: image[bi][row][c'] (4 floats per row of the block), then V in operand layout
+    if (c < 4) {
+#pragma unroll
+      for (int bi = 0; bi < L; ++bi) {
+        const acc_t t = acc[tile_index(bi, L, NB)];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) S[bi * 64 + (4 * g + q) * 4 + c] = t[q];
+      }
+    }
+    __syncthreads();
+    float V[L];
+    acc_t in[Inner::NT];
+    float bin[L];
+#pragma unroll
+    for (int bi = 0; bi < L; ++bi) {
+      const float4 a = *reinterpret_cast<const float4 *>(S + bi * 64 + c * 4);
+      V[bi] = fmaf(Mg3, a.w, fmaf(Mg2, a.z, fmaf(Mg1, a.y, Mg0 * a.x)));
+      bin[bi] = fmaf(-V[bi], zg, bacc[bi]);  // this group's share of b1 - V^T z2
+    }
+    __syncthreads();  // the image is read before the inner solve reuses S
+    // ---- A11 - V^T V: one MFMA (K = 4: the four rows of V) per tile
+#pragma unroll
+    for (int bi = 0; bi < L; ++bi) {
+      const float nv = -V[bi];
+#pragma unroll
+      for (int bj = bi; bj < L; ++bj) in[tile_index(bi, bj, L)] = Tr::mma(nv, V[bj], acc[tile_index(bi, bj, NB)]);
+    }
+    float x1[L];
+    const bool bad = Inner::template solve<true>(in, bin, S, 16 * L, lam, x1, lane);
+    // ---- x2 = M^T (z2 - V x1)
+    float s = 0.0f;
+#pragma unroll
+    for (int bi = 0; bi < L; ++bi) {
+      xcol[bi] = x1[bi];
+      s = fmaf(V[bi], x1[bi], s);
+    }
+    const float yg = zg - row_sum(s);  // (z2 - V x1)[g] in every lane of group g
+    const float y0 = readlane(yg, 0), y1 = readlane(yg, 16), y2 = readlane(yg, 32), y3 = readlane(yg, 48);
+    const float x20 = fmaf(m30, y3, fmaf(m20, y2, fmaf(m10, y1, r0 * y0)));
+    const float x21 = fmaf(m31, y3, fmaf(m21, y2, r1 * y1));
+    const float x22 = fmaf(m32, y3, r2 * y2);
+    const float x23 = r3 * y3;
+    xcol[L] = c == 0 ? x20 : c == 1 ? x21 : c == 2 ? x22 : x23;
+    return bad || !(dmin > 0.0f) || !(x20 * 0.0f == 0.0f) || !(x21 * 0.0f == 0.0f) || !(x22 * 0.0f == 0.0f) || !(x23 * 0.0f == 0.0f);
+  }
+
   static __device__ __forceinline__ void run(acc_t (&acc)[NT], const float (&bacc)[NB], float *S, int k, float lam,
                                              float *__restrict__ out_row, int row, ErrInfo *err, int lane) {
     const int g = lane >> 4, c = lane & 15;
     float xcol[NB];
-    const bool bad = solve<true>(acc, bacc, S, k, lam, xcol, lane);
+    bool bad;
+    if constexpr (NB >= 2 && YCNR_EDGE4_SOLVE) {
+      if (k == 16 * (NB - 1) + 4) {  // wave-uniform (a launch constant in the primal kernels)
+        bad = solve_edge4(acc, bacc, S, lam, xcol, lane);
+      } else {
+        bad = solve<true>(acc, bacc, S, k, lam, xcol, lane);
+      }
+    } else {
+      bad = solve<true>(acc, bacc, S, k, lam, xcol, lane);
+    }
     // lane group g stores blocks g and g + 4: two full 256-byte stores per row for k >= 64
 #pragma unroll
     for (int cb = 0; cb < NB; ++cb) {
@@ -1724,11 +1855,25 @@ __global__ __launch_bounds__(64, 2) void als_gram_solve_x6d_kernel(StepArgs<floa
   float bacc[NB];
 #pragma unroll
   for (int cb = 0; cb < NB; ++cb) bacc[cb] = 0.0f;
+#ifdef YCNR_ABLATE_GRAM  // timing experiments only: skip the Gramian (results are wrong)
+  acc[0][0] = (float)u.beg;
+  (void)ring;
+#else
   G::accumulate(acc, bacc, ring, a.indx, a.vals, a.fixed, a.fixedBytes, a.k, u.beg, u.end - u.beg, lane);
   if constexpr (PADRHS) G::extract_rhs(acc, bacc, a.k, lane);
+#endif
   const float lam = (float)(a.lambda * (double)(u.end - u.beg));
+#ifdef YCNR_ABLATE_SOLVE  // timing experiments only: skip the solve, keep the Gramian live
+  {
+    float sum = lam;
+    for (int t = 0; t < G::NT; ++t) sum += acc[t][0] + acc[t][1] + acc[t][2] + acc[t][3];
+    for (int cb = 0; cb < NB; ++cb) sum += bacc[cb];
+    if (lane < a.k) a.solved[(int64_t)u.row * a.k + lane] = sum;
+  }
+#else
   SolverFor<float, NB, LDS_SOLVER>::type::run(acc, bacc, reinterpret_cast<float *>(smem), a.k, lam,
                                               a.solved + (int64_t)u.row * a.k, u.row, a.err, lane);
+#endif
 }
 
 // Kernel 1c: the same row solve in its DUAL form, for rows with fewer ratings than factors.
@@ -1794,7 +1939,11 @@ __global__ __launch_bounds__(64) void als_dual_solve_kernel(StepArgs<float> a) {
       }
     }
   };
+#ifdef YCNR_DUAL_ABLATE_G  // timing experiments only (results are wrong)
+  if constexpr (false) {
+#else
   if constexpr (X6) {
+#endif
     typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     const int ksteps32 = (k + 31) >> 5;
@@ -1865,6 +2014,7 @@ __global__ __launch_bounds__(64) void als_dual_solve_kernel(StepArgs<float> a) {
       }
     }
   } else {
+#ifndef YCNR_DUAL_ABLATE_G
     load(ya, 0);
     for (int s = 0; s < ksteps; ++s) {
       if (s + 1 < ksteps) load(yb, s + 1);
@@ -1872,14 +2022,28 @@ __global__ __launch_bounds__(64) void als_dual_solve_kernel(StepArgs<float> a) {
 #pragma unroll
       for (int ba = 0; ba < NBN; ++ba) ya[ba] = yb[ba];
     }
+#endif
   }
   const float lam = (float)(a.lambda * (double)n);
   float wcol[NBN];
+#ifdef YCNR_DUAL_ABLATE_SOLVE  // timing experiments only
+  bool bad = false;
+  for (int ba = 0; ba < NBN; ++ba) {
+    wcol[ba] = bacc[ba] + lam;
+    for (int bb = ba; bb < NBN; ++bb) wcol[ba] += acc[tile_index(ba, bb, NBN)][0] + acc[tile_index(ba, bb, NBN)][1] + acc[tile_index(ba, bb, NBN)][2] + acc[tile_index(ba, bb, NBN)][3];
+  }
+#else
   const bool bad = Sv::template solve<YCNR_DUAL_BATCH>(acc, bacc, reinterpret_cast<float *>(smem), n, lam, wcol, lane);
+#endif
   // x[f] = sum_a Y[a][f] w[a]: per lane the 4 factors 16 s + 4 g + j of its NBN ratings,
   // summed over the 16 lanes of the group; lane c == 0 of each group stores them
   float *out = a.solved + (int64_t)u.row * k;
+#ifdef YCNR_DUAL_ABLATE_X  // timing experiments only
+  if (lane < NBN) out[lane] = wcol[0];
+  for (int s = 0; s < 0; ++s) {
+#else
   for (int s = 0; s < ksteps; ++s) {
+#endif
     load(ya, s);
     float4 x = float4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll

@@ -24,7 +24,10 @@ around inline asm: the pivot updates of SolveMfmaF32 are inline-asm `v_fmac_f32_
 produced by an asm multiply followed by `s_nop 1`, and a register copy (or an AGPR reload) the compiler
 places directly in front of such a statement would break that silently.  The walk goes backwards from
 every DPP instruction over two wait states (`s_nop N` counts N + 1), through labels into every branch
-that targets them.
+that targets them.  The same walk checks two single-wait-state rules: no v_readlane of a VGPR written by the
+instruction directly in front of it, and no vector-ALU read of a transcendental result (v_rsq, ...) by the
+instruction directly behind it -- an asm multiply placed right behind the compiler's v_rsq once read a stale
+scale (wrong columns for k = 112 and 128, caught by tests/test_gpu_parity.py).
 """
 import re
 import sys
@@ -85,6 +88,9 @@ def lint(path, wanted):
             print(f"{'FAIL' if issues else 'ok  '} {name[:90]}: {reads} LDS reads, {issues} premature uses")
         total += issues
     return total
+
+
+TRANS = ("v_rsq", "v_rcp", "v_sqrt", "v_exp", "v_log", "v_sin", "v_cos")
 
 
 def _dest_regs(ins):
@@ -163,6 +169,25 @@ def lint_dpp(path, wanted):
                     issues += 1
                     if issues <= 5:
                         print(f"  {name[:70]}: '{ins[:60]}' reads v{sorted(src)} written by '{w}' less than two wait states earlier")
+        # the two single-wait-state rules hipcc keeps for its own instructions but cannot keep for inline asm:
+        # a v_readlane / v_readfirstlane of a VGPR the instruction before wrote, and a vector-ALU read of a
+        # transcendental result (v_rsq, v_rcp, ...) by the instruction directly behind it
+        for i, ins in enumerate(ins_list):
+            parts = ins.split(None, 1)
+            if len(parts) < 2 or not parts[0].startswith("v_"):
+                continue
+            ops = [o.strip() for o in parts[1].split(",")]
+            lane_read = parts[0].startswith("v_readlane") or parts[0].startswith("v_readfirstlane")
+            reads = regs_of(",".join(ops[1:]))
+            if parts[0].startswith("v_fmac") or parts[0].startswith("v_mfma") or "swap" in parts[0]:
+                reads |= regs_of(ops[0])
+            for w in writers(i, 1):
+                wop = w.split()[0]
+                hit = _dest_regs(w) & reads
+                if hit and (lane_read or wop.startswith(TRANS)) and not parts[0].startswith(TRANS):
+                    issues += 1
+                    if issues <= 5:
+                        print(f"  {name[:70]}: '{ins[:60]}' reads v{sorted(hit)} one instruction behind '{w[:50]}'")
         if issues:
             print(f"FAIL {name[:90]}: {issues} DPP reads too early")
         total += issues
