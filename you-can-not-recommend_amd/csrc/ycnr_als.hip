@@ -58,7 +58,7 @@ constexpr int64_t kBandBytes = (int64_t)96 << 20;  // slice of the fixed matrix 
 constexpr size_t kErrBytes = 65536;
 constexpr size_t kZeroRowBytes = 2048;  // >= kMaxFactors doubles
 constexpr int kMaxDualBlocks = 10;       // dual-form kernels exist for 1..10 blocks of 16 ratings
-constexpr int kMaxDualBlocksSmallK = 6;  // k <= 128: beyond 96 ratings the row kernel (k x k) is as cheap
+constexpr int kMaxDualBlocksSmallK = 5;  // k <= 128: beyond 80 ratings the row kernel (k x k) is cheaper (MAL scale, k = 100: 6 -> 5 blocks took 0.2 ms off the user half-step once the solve had lost its readlanes and transposes; 4 was slower)
 
 size_t tsize(int dtype) { return dtype == YCNR_F64 ? 8 : 4; }
 
@@ -480,7 +480,9 @@ int dual_max_ratings(const ycnr_als_options &o) {
   const int nb = slab_nb(o.factorsCount);
   // k > 128: every row that is not dual goes through slabs and the 4-wave LDS solve, whose cost
   // grows with k^3; an n x n problem with n <= 160 still fits one wave's registers
-  return 16 * std::min(o.factorsCount > kMaxFactors ? kMaxDualBlocks : kMaxDualBlocksSmallK, nb - 1);
+  int most = o.factorsCount > kMaxFactors ? kMaxDualBlocks : kMaxDualBlocksSmallK;
+  if (const char *e = getenv("YCNR_DUAL_MAX_BLOCKS")) most = std::max(0, std::min(atoi(e), o.factorsCount > kMaxFactors ? kMaxDualBlocks : kMaxDualBlocksSmallK));  // experiments
+  return 16 * std::min(most, nb - 1);
 }
 
 // copy `bytes` from src (host or device) to a device destination

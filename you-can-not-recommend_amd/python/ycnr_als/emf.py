@@ -111,15 +111,15 @@ def row_cost(counts, k, double=False):
     to cut shards that finish together.  A rating costs the Gramian update of a k x k matrix, a row
     costs its solve whatever its length, and rows with fewer ratings than factors take the cheaper
     dual (n x n) form; constants from the per-kernel times of the MAL-scale run at k = 100
-    (170 cycles per rating and 25 K per solve in the row kernel; 3.6 K ... 41 K per row
-    for the dual classes of 16 ... 96 ratings).  Balancing ratings alone (what the reference's
+    (120 cycles per rating and 16.5 K per solve in the row kernel; 2.7 K ... 24 K per row
+    for the dual classes of 16 ... 80 ratings).  Balancing ratings alone (what the reference's
     splitToPortions does, lib/emf/EmfLord.js:571-592) gives the shard with many short rows more
     work per rating."""
     n = np.asarray(counts, np.float64)
     nb = (k + 15) // 16
-    dual_max = 0 if (double or k % 4) else 16 * min(10 if k > 128 else 6, nb - 1)
-    primal = n * (1.7 * k) + 0.025 * float(k) ** 3
-    dual = 3600.0 * np.ceil(n / 16.0) ** 1.36 * (k / 100.0)
+    dual_max = 0 if (double or k % 4) else 16 * min(10 if k > 128 else 5, nb - 1)
+    primal = n * (1.2 * k) + 0.0165 * float(k) ** 3
+    dual = 2700.0 * np.ceil(n / 16.0) ** 1.36 * (k / 100.0)
     c = np.where(n <= dual_max, dual, primal)
     return np.where(n > 0, c, 0.0)
 
