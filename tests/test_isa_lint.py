@@ -101,3 +101,5 @@ def test_device_assembly_has_no_premature_lds_uses(tmp_path):
     # the inline-asm v_fmac_f32_dpp pivot updates: no compiler-inserted copy may sit within two wait states
     # in front of one
     assert lint.lint_dpp(str(out), []) == 0
+    # no instantiation may spill hundreds of bytes per lane to scratch (one did, unnoticed, at twice the run time)
+    assert lint.lint_scratch(str(out)) == 0

@@ -891,56 +891,59 @@ struct SolveMfmaF32 {
           R[4 * m4 + 3] = xlane ? (c == 4 * m4 + 3 ? 1.0f : 0.0f) : v.w;
         }
       }
-#if YCNR_DPP_PIVOTS
-      // padded pivots (index >= k; only the last tile has any) are skipped; one-tile systems run all 16
-      // (see the v_readlane form below for why)
-      if (NB > 1 && J == NB - 1) {
-        // the last tile of a system with more than one: only the real pivots, in fours (wave-uniform)
-        const int n4 = (k - J * 16 + 3) >> 2;
-        if (n4 == 1) pivots_dpp<0, 4>(R, dmin);
-        else if (n4 == 2) pivots_dpp<0, 8>(R, dmin);
-        else if (n4 == 3) pivots_dpp<0, 12>(R, dmin);
-        else pivots_dpp<0, 16>(R, dmin);
-      } else {
-        pivots_dpp<0, 16>(R, dmin);
-      }
-#else
-#pragma unroll
-      for (int p = 0; p < 16; ++p) {
-        // padded pivots (index >= k) are rows of the identity: their scale is 1 and their
-        // multipliers are 0, so skipping them is exact (a wave-uniform branch).  Only the last
-        // tile has any: 16 (NB - 1) < k by the choice of NB (and of the dual class).
-        // Not for NB = 1: there hipcc kept the pivot loop rolled because of the break (up to 120
-        // trips of three s_set_gpr_idx moves each), and a guard per pivot made it copy R between
-        // the guarded blocks; 16 straight-line pivots are cheaper than either.
-        if constexpr (NB > 1) {
-          if (J == NB - 1 && J * 16 + p >= k) break;
-        }
-        const float d = readlane(R[p], p);  // D[p][p] after the updates of pivots < p (lane p, group 0)
-        // the smallest pivot decides whether the row is reported: the first pivot that is not
-        // positive is an ordinary number (NaNs only appear after it), so a plain minimum keeps it
-        dmin = fminf(dmin, d);
-        // v_rsq_f32 as it is (1 ulp).  A Newton step on top of it (3 more instructions on the
-        // critical path of each of the 16 pivots) changed nothing measurable: lanes 16-31 invert
-        // the L that was actually computed, and the row errors against float64 had the same
-        // median / p99 / max with and without it (tests/tools/errstats.py), 0.37 ms per MAL iteration.
-        const float rs = __builtin_amdgcn_rsqf(d);
-        R[p] *= rs;                             // L[i][p] in lanes 0-15, Linv[p][c] in lanes 16-31
-        if constexpr (BATCH) {
-          float mult[16];
-#pragma unroll
-          for (int j = p + 1; j < 16; ++j) mult[j] = readlane(R[p], j);  // L[j][p]
-#pragma unroll
-          for (int j = p + 1; j < 16; ++j) R[j] = fmaf(-R[p], mult[j], R[j]);
+      // NB = 10 (dual rows of 145 .. 160 ratings at k > 128) keeps the v_readlane form: with the inline-asm
+      // updates hipcc stopped using the accumulator half of the register file there (183 + 8 registers and
+      // 1104 bytes of scratch per lane instead of 256 + 256 and none) and the class ran twice as long
+      if constexpr (YCNR_DPP_PIVOTS && NB <= 9) {
+        // padded pivots (index >= k; only the last tile has any) are skipped; one-tile systems run all 16
+        // (see the v_readlane form below for why)
+        if (NB > 1 && J == NB - 1) {
+          // the last tile of a system with more than one: only the real pivots, in fours (wave-uniform)
+          const int n4 = (k - J * 16 + 3) >> 2;
+          if (n4 == 1) pivots_dpp<0, 4>(R, dmin);
+          else if (n4 == 2) pivots_dpp<0, 8>(R, dmin);
+          else if (n4 == 3) pivots_dpp<0, 12>(R, dmin);
+          else pivots_dpp<0, 16>(R, dmin);
         } else {
+          pivots_dpp<0, 16>(R, dmin);
+        }
+      } else {
 #pragma unroll
-          for (int j = p + 1; j < 16; ++j) {
-            const float s = readlane(R[p], j);  // L[j][p]
-            R[j] = fmaf(-R[p], s, R[j]);
+        for (int p = 0; p < 16; ++p) {
+          // padded pivots (index >= k) are rows of the identity: their scale is 1 and their
+          // multipliers are 0, so skipping them is exact (a wave-uniform branch).  Only the last
+          // tile has any: 16 (NB - 1) < k by the choice of NB (and of the dual class).
+          // Not for NB = 1: there hipcc kept the pivot loop rolled because of the break (up to 120
+          // trips of three s_set_gpr_idx moves each), and a guard per pivot made it copy R between
+          // the guarded blocks; 16 straight-line pivots are cheaper than either.
+          if constexpr (NB > 1) {
+            if (J == NB - 1 && J * 16 + p >= k) break;
+          }
+          const float d = readlane(R[p], p);  // D[p][p] after the updates of pivots < p (lane p, group 0)
+          // the smallest pivot decides whether the row is reported: the first pivot that is not
+          // positive is an ordinary number (NaNs only appear after it), so a plain minimum keeps it
+          dmin = fminf(dmin, d);
+          // v_rsq_f32 as it is (1 ulp).  A Newton step on top of it (3 more instructions on the
+          // critical path of each of the 16 pivots) changed nothing measurable: lanes 16-31 invert
+          // the L that was actually computed, and the row errors against float64 had the same
+          // median / p99 / max with and without it (tests/tools/errstats.py), 0.37 ms per MAL iteration.
+          const float rs = __builtin_amdgcn_rsqf(d);
+          R[p] *= rs;                             // L[i][p] in lanes 0-15, Linv[p][c] in lanes 16-31
+          if constexpr (BATCH) {
+            float mult[16];
+#pragma unroll
+            for (int j = p + 1; j < 16; ++j) mult[j] = readlane(R[p], j);  // L[j][p]
+#pragma unroll
+            for (int j = p + 1; j < 16; ++j) R[j] = fmaf(-R[p], mult[j], R[j]);
+          } else {
+#pragma unroll
+            for (int j = p + 1; j < 16; ++j) {
+              const float s = readlane(R[p], j);  // L[j][p]
+              R[j] = fmaf(-R[p], s, R[j]);
+            }
           }
         }
       }
-#endif
       // ---- 2. W = L^-1 (column c in lanes 16-31) -> LDS -> C/D layout and A-operand layout
       if (g == 1) {
         float4 *dst = reinterpret_cast<float4 *>(Wt + c * LDW);
@@ -1126,17 +1129,17 @@ struct SolveMfmaF32 {
     return bad || !(dmin > 0.0f) || !(x20 * 0.0f == 0.0f) || !(x21 * 0.0f == 0.0f) || !(x22 * 0.0f == 0.0f) || !(x23 * 0.0f == 0.0f);
   }
 
+  // E4: the caller launches this instantiation only for k = 16 (NB - 1) + 4 (the edge columns go first,
+  // solve_edge4).  A compile-time choice: with both forms behind a run-time branch the fused row kernel
+  // spilled 168 bytes per lane to scratch.
+  template <bool E4 = false>
   static __device__ __forceinline__ void run(acc_t (&acc)[NT], const float (&bacc)[NB], float *S, int k, float lam,
                                              float *__restrict__ out_row, int row, ErrInfo *err, int lane) {
     const int g = lane >> 4, c = lane & 15;
     float xcol[NB];
     bool bad;
-    if constexpr (NB >= 2 && YCNR_EDGE4_SOLVE) {
-      if (k == 16 * (NB - 1) + 4) {  // wave-uniform (a launch constant in the primal kernels)
-        bad = solve_edge4(acc, bacc, S, lam, xcol, lane);
-      } else {
-        bad = solve<true>(acc, bacc, S, k, lam, xcol, lane);
-      }
+    if constexpr (E4 && NB >= 2 && YCNR_EDGE4_SOLVE) {
+      bad = solve_edge4(acc, bacc, S, lam, xcol, lane);
     } else {
       bad = solve<true>(acc, bacc, S, k, lam, xcol, lane);
     }
@@ -1805,7 +1808,7 @@ __global__ __launch_bounds__(64, 2) void als_gram_slab_x6d_kernel(StepArgs<float
 
 // Kernel 1b (dominant on the user side): one wave per row that fits one unit -- gather +
 // Gramian + rhs, then the row's solve, all in registers.
-template <typename T, int NB, bool LDS_SOLVER, bool EDGE>
+template <typename T, int NB, bool LDS_SOLVER, bool EDGE, bool E4 = false>
 __global__ __launch_bounds__(64, sizeof(T) == 8 ? 1 : YCNR_FUSED_WAVES_PER_SIMD) void als_gram_solve_kernel(StepArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using G = typename GramSel<T, NB, EDGE>::type;
@@ -1834,14 +1837,18 @@ __global__ __launch_bounds__(64, sizeof(T) == 8 ? 1 : YCNR_FUSED_WAVES_PER_SIMD)
     if (lane < a.k) a.solved[(int64_t)u.row * a.k + lane] = sum;
   }
 #else
-  SolverFor<T, NB, LDS_SOLVER>::type::run(acc, bacc, reinterpret_cast<T *>(smem), a.k, lam,
+  if constexpr (E4 && std::is_same<T, float>::value && !LDS_SOLVER) {
+    SolveMfmaF32<NB>::template run<true>(acc, bacc, reinterpret_cast<float *>(smem), a.k, lam, a.solved + (int64_t)u.row * a.k, u.row, a.err, lane);
+  } else {
+    SolverFor<T, NB, LDS_SOLVER>::type::run(acc, bacc, reinterpret_cast<T *>(smem), a.k, lam,
                                           a.solved + (int64_t)u.row * a.k, u.row, a.err, lane);
+  }
 #endif
 }
 
 // Kernel 1b': the fused row kernel with the bf16x6 / LDS-DMA Gramian (GramX6D) in place of the
 // float32-MFMA one; the solve is unchanged.  float32, k % 4 == 0, k <= 112, fixed matrix < 2 GB.
-template <int NB, bool PADRHS, bool LDS_SOLVER>
+template <int NB, bool PADRHS, bool LDS_SOLVER, bool E4 = false>
 __global__ __launch_bounds__(64, 2) void als_gram_solve_x6d_kernel(StepArgs<float> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using G = GramX6D<NB, PADRHS>;
@@ -1871,8 +1878,12 @@ __global__ __launch_bounds__(64, 2) void als_gram_solve_x6d_kernel(StepArgs<floa
     if (lane < a.k) a.solved[(int64_t)u.row * a.k + lane] = sum;
   }
 #else
-  SolverFor<float, NB, LDS_SOLVER>::type::run(acc, bacc, reinterpret_cast<float *>(smem), a.k, lam,
-                                              a.solved + (int64_t)u.row * a.k, u.row, a.err, lane);
+  if constexpr (E4 && !LDS_SOLVER) {
+    SolveMfmaF32<NB>::template run<true>(acc, bacc, reinterpret_cast<float *>(smem), a.k, lam, a.solved + (int64_t)u.row * a.k, u.row, a.err, lane);
+  } else {
+    SolverFor<float, NB, LDS_SOLVER>::type::run(acc, bacc, reinterpret_cast<float *>(smem), a.k, lam,
+                                                a.solved + (int64_t)u.row * a.k, u.row, a.err, lane);
+  }
 #endif
 }
 
@@ -2067,7 +2078,7 @@ __global__ __launch_bounds__(64) void als_dual_solve_kernel(StepArgs<float> a) {
 }
 
 // Kernel 2: one wave per split row -- sum its slabs in slab order, then solve.
-template <typename T, int NB, bool LDS_SOLVER, bool EDGE>
+template <typename T, int NB, bool LDS_SOLVER, bool EDGE, bool E4 = false>
 __global__ __launch_bounds__(64) void als_reduce_solve_kernel(StepArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using G = typename GramSel<T, NB, EDGE>::type;
@@ -2081,8 +2092,12 @@ __global__ __launch_bounds__(64) void als_reduce_solve_kernel(StepArgs<T> a) {
   T bacc[NB];
   G::to_tiles(st, acc, bacc, reinterpret_cast<T *>(smem), lane);
   const T lam = (T)(a.lambda * (double)sr.n);
-  SolverFor<T, NB, LDS_SOLVER>::type::run(acc, bacc, reinterpret_cast<T *>(smem), a.k, lam,
+  if constexpr (E4 && std::is_same<T, float>::value && !LDS_SOLVER) {
+    SolveMfmaF32<NB>::template run<true>(acc, bacc, reinterpret_cast<float *>(smem), a.k, lam, a.solved + (int64_t)sr.row * a.k, sr.row, a.err, lane);
+  } else {
+    SolverFor<T, NB, LDS_SOLVER>::type::run(acc, bacc, reinterpret_cast<T *>(smem), a.k, lam,
                                           a.solved + (int64_t)sr.row * a.k, sr.row, a.err, lane);
+  }
 }
 
 // ---------------------------------------------------------------------------------------

@@ -195,9 +195,27 @@ def lint_dpp(path, wanted):
     return total
 
 
+def lint_scratch(path, limit=512):
+    """Kernels whose registers spill to scratch memory (`; ScratchSize: N` in the assembly).  A change that
+    looked harmless (inline-asm pivot updates) once made hipcc give up the accumulator half of the register
+    file in one instantiation: 1104 bytes of scratch per lane and twice the run time, and no test noticed."""
+    text = open(path).read()
+    bad = 0
+    for m in re.finditer(r"^\s*\.amdhsa_kernel (\S+).*?\.amdhsa_private_segment_fixed_size (\d+)", text, re.M | re.S):
+        name, size = m.group(1), int(m.group(2))
+        if "ycnr" in name and size > limit:
+            bad += 1
+            print(f"FAIL {name[:90]}: {size} bytes of scratch per lane")
+        elif "ycnr" in name and size > 64:
+            print(f"note {name[:90]}: {size} bytes of scratch per lane")
+    return bad
+
+
 if __name__ == "__main__":
     n = lint(sys.argv[1], sys.argv[2:])
     print("premature uses:", n)
     nd = lint_dpp(sys.argv[1], sys.argv[2:])
     print("DPP reads too early:", nd)
-    sys.exit(1 if n or nd else 0)
+    ns = lint_scratch(sys.argv[1])
+    print("kernels spilling to scratch:", ns)
+    sys.exit(1 if n or nd or ns else 0)

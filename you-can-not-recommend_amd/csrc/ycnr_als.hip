@@ -252,11 +252,16 @@ void (*slab_x6d_kernel(int))(StepArgs<T>) { return nullptr; }
 YCNR_X6D(1) YCNR_X6D(2) YCNR_X6D(3) YCNR_X6D(4) YCNR_X6D(5) YCNR_X6D(6) YCNR_X6D(7)
 #undef YCNR_X6D
 
+// k = 16 (NB - 1) + 4 in float32 with the register solver: the instantiations that eliminate the four edge
+// columns first (SolveMfmaF32::solve_edge4)
+template <int NB, bool LDS_SOLVER>
+constexpr bool edge4_k(int k) { return YCNR_EDGE4_SOLVE && NB >= 2 && !LDS_SOLVER && k == 16 * (NB - 1) + 4; }
+
 template <typename T, int NB, bool LDS_SOLVER>
 void (*fused_x6d_kernel(int))(StepArgs<T>) { return nullptr; }
 #define YCNR_X6D(NBV, LDSV) \
   template <>               \
-  void (*fused_x6d_kernel<float, NBV, LDSV>(int k))(StepArgs<float>) { return k % 4 ? nullptr : k < 16 * NBV ? als_gram_solve_x6d_kernel<NBV, true, LDSV> : als_gram_solve_x6d_kernel<NBV, false, LDSV>; }
+  void (*fused_x6d_kernel<float, NBV, LDSV>(int k))(StepArgs<float>) { return k % 4 ? nullptr : k < 16 * NBV ? (edge4_k<NBV, LDSV>(k) ? als_gram_solve_x6d_kernel<NBV, true, LDSV, true> : als_gram_solve_x6d_kernel<NBV, true, LDSV, false>) : als_gram_solve_x6d_kernel<NBV, false, LDSV, false>; }
 YCNR_X6D(1, false) YCNR_X6D(2, false) YCNR_X6D(3, false) YCNR_X6D(4, false) YCNR_X6D(5, false) YCNR_X6D(6, false) YCNR_X6D(7, false)
 YCNR_X6D(1, true) YCNR_X6D(2, true) YCNR_X6D(3, true) YCNR_X6D(4, true) YCNR_X6D(5, true) YCNR_X6D(6, true) YCNR_X6D(7, true)
 #undef YCNR_X6D
@@ -269,10 +274,16 @@ int launch_nbe(StepArgs<T> args, int64_t nUnits, int64_t nSplitUnits, int64_t nS
   const size_t lds = SolverFor<T, NB, LDS_SOLVER>::type::lds_bytes();
   void (*k0)(StepArgs<T>) = SLABX6 ? slab_x6_kernel<T, NB>() : als_gram_slab_kernel<T, NB, EDGE && !SLABX6>;
   if (SLABX6 && slab_x6d_kernel<T, NB>(args.k) && !env_flags().noX6d) k0 = slab_x6d_kernel<T, NB>(args.k);
-  void (*k1)(StepArgs<T>) = als_gram_solve_kernel<T, NB, LDS_SOLVER, EDGE>;
+  void (*k1)(StepArgs<T>) = als_gram_solve_kernel<T, NB, LDS_SOLVER, EDGE, false>;
+  void (*k2)(StepArgs<T>) = als_reduce_solve_kernel<T, NB, LDS_SOLVER, EDGE && !SLABX6, false>;
+  if constexpr (std::is_same<T, float>::value && NB >= 2 && !LDS_SOLVER) {
+    if (edge4_k<NB, LDS_SOLVER>(args.k)) {
+      k1 = als_gram_solve_kernel<T, NB, LDS_SOLVER, EDGE, true>;
+      k2 = als_reduce_solve_kernel<T, NB, LDS_SOLVER, EDGE && !SLABX6, true>;
+    }
+  }
   if (SLABX6 && fused_x6d_kernel<T, NB, LDS_SOLVER>(args.k) && !env_flags().noX6d && !env_flags().noFusedX6d)
     k1 = fused_x6d_kernel<T, NB, LDS_SOLVER>(args.k);
-  auto k2 = als_reduce_solve_kernel<T, NB, LDS_SOLVER, EDGE && !SLABX6>;
   const size_t pad = env_flags().k1LdsPad;  // experiments: limits blocks per CU
   if (int rcl = set_max_lds(reinterpret_cast<const void *>(k1), lds + pad)) return rcl;
   if (int rcl = set_max_lds(reinterpret_cast<const void *>(k2), lds)) return rcl;
