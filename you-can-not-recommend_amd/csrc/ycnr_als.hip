@@ -1233,6 +1233,10 @@ static int build_part(ycnr_als *h, int side, const int64_t *rowPtr, const int32_
     HIP_TRY(hipMemcpy(S.dUnits, units.data(), sizeof(Unit) * units.size(), hipMemcpyHostToDevice));
   }
   if (S.nSplit) {
+    // the reduce kernel takes the rows in this order, one wave each: rows with the most slabs first, so that
+    // the 64-slab rows of the most popular items do not start when everything else has finished
+    if (!big)
+      std::stable_sort(split.begin(), split.end(), [](const SplitRow &x, const SplitRow &y) { return x.nslabs > y.nslabs; });
     HIP_TRY(hipMalloc(&S.dSplit, sizeof(SplitRow) * split.size()));
     HIP_TRY(hipMemcpy(S.dSplit, split.data(), sizeof(SplitRow) * split.size(), hipMemcpyHostToDevice));
     const size_t slabElems = big ? (size_t)wg_slab_floats(slab_nb(h->opt.factorsCount)) : (size_t)slab_regs(h->opt, side) * 64;
