@@ -430,33 +430,33 @@ struct WgSolve {
   static __device__ __forceinline__ bool factor_diag(float *S, float *Dt, int J, int k, int lane) {
     const int g = lane >> 4, c = lane & 15;
     float *T = tile(S, J, J);
-    float R[16], X[16];
+    // Round 2: the pivot loop of the one-wave solve (SolveMfmaF32::pivots_dpp).  Lane groups 0 / 2 hold the rows
+    // of D, groups 1 / 3 the columns of the identity that become L^-1; one v_permlane16_swap per pivot copies
+    // the scaled pivot column into the identity groups and every updated column is ONE v_fmac with a DPP
+    // row_newbcast operand (before: every lane carried a row of D and a row of the identity, two multiply-adds
+    // per column -- these 16 pivots are the critical chain of the late block steps).
+    float R[16];
     {
       const int sw = (c >> 1) & 3;
+      const bool xlane = (g & 1) != 0;
 #pragma unroll
       for (int m4 = 0; m4 < 4; ++m4) {
         const acc_t v = *reinterpret_cast<const acc_t *>(T + c * 16 + 4 * (m4 ^ sw));  // row c = column c (D is symmetric)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          R[4 * m4 + t] = v[t];
-          X[4 * m4 + t] = c == 4 * m4 + t ? 1.0f : 0.0f;
-        }
+        for (int t = 0; t < 4; ++t) R[4 * m4 + t] = xlane ? (c == 4 * m4 + t ? 1.0f : 0.0f) : v[t];
       }
     }
     float dmin = 3.0e38f;
     // padded pivots (index >= k; only the last tile has any) are rows of the identity (diagonal 1, nothing
-    // else): their scale is 1 and their multipliers 0, so running them is exact, and 16 unconditional
-    // pivots keep R and X in fixed registers (a guard per pivot made the compiler copy and spill them)
-    pivot<0>(R, X, dmin);  pivot<1>(R, X, dmin);  pivot<2>(R, X, dmin);  pivot<3>(R, X, dmin);
-    pivot<4>(R, X, dmin);  pivot<5>(R, X, dmin);  pivot<6>(R, X, dmin);  pivot<7>(R, X, dmin);
-    pivot<8>(R, X, dmin);  pivot<9>(R, X, dmin);  pivot<10>(R, X, dmin); pivot<11>(R, X, dmin);
-    pivot<12>(R, X, dmin); pivot<13>(R, X, dmin); pivot<14>(R, X, dmin); pivot<15>(R, X, dmin);
+    // else): their scale is 1 and their multipliers 0, so running them is exact
+    Sm::template pivots_dpp<0, 16>(R, dmin);
     (void)k;
-    // X[j] = L^-T[c][j] = W[j][c] = element (row c, col j) of the tile; lane group g writes columns 4g .. 4g+3
+    // groups 1 / 3: R[j] = L^-1[j][c] = W[j][c] = element (row c, col j) of the tile; group 1 writes columns
+    // 0 .. 7, group 3 columns 8 .. 15
     __builtin_amdgcn_s_waitcnt(0xc07f);  // the tile reads above have returned before the tile is overwritten
 #pragma unroll
     for (int j = 0; j < 16; ++j)
-      if ((j >> 2) == g) T[j * 16 + 4 * ((c >> 2) ^ ((j >> 1) & 3)) + (c & 3)] = X[j];
+      if ((g & 1) && (j >> 3) == (g >> 1)) T[j * 16 + 4 * ((c >> 2) ^ ((j >> 1) & 3)) + (c & 3)] = R[j];
     (void)Dt;
     return !(dmin > 0.0f);
   }
