@@ -2077,6 +2077,186 @@ __global__ __launch_bounds__(64) void als_dual_solve_kernel(StepArgs<float> a) {
   }
 }
 
+// Kernel 1e: FOUR rows of at most 16 ratings per wave (float32, bf16x6 products, k % 4 == 0, k <= 128, fixed
+// matrix below 4 GB).  The one-tile class is bound by vector instructions (PMC: 966 per row at MAL scale, 72 %
+// of the SIMD's issue rate), and most of them do not depend on the row's length: 16 pivots with their
+// replication and the L^-1 they build for block steps that a one-tile system does not have, two LDS round
+// trips, seven rounds of cross-lane sums for x = Y^T w.  Here lane group s owns row s:
+//   * G_s = Y_s Y_s^T: one 16 x 16 tile per row, bf16x6 MFMAs as in als_dual_solve_kernel (the same loads and
+//     splits per row); a register <-> lane-group transpose of the four tiles leaves lane (s, i) with row i
+//     of G_s in 16 registers;
+//   * the four 16 x 16 systems are solved TOGETHER by Gaussian elimination without pivoting (exact for a
+//     symmetric positive definite matrix in the sense of Cholesky: the same pivots d_p, growth factor 1), one
+//     row per lane: pivot p broadcasts row p inside each 16-lane group by DPP row_newbcast, lane i > p
+//     subtracts m_i = A[i][p] / d_p times it; the right-hand side rides along; back substitution the same way.
+//     No L^-1, no LDS, and every instruction works for four rows;
+//   * x_s = Y_s^T w_s with lane (s, c) owning float4 c and c + 16 of the row: per rating one broadcast of its
+//     id and its w inside the group, two 16-byte loads, eight fma; no cross-lane sums.
+// Ratings past a row's end: zero rows of G with a unit diagonal and a zero right-hand side (w = 0).
+__global__ __launch_bounds__(64) void als_dual_quad_kernel(StepArgs<float> a, int32_t count) {
+  using Sv = SolveMfmaF32<1>;
+  using Tr = MfmaTraits<float>;
+  using acc_t = typename Tr::acc_t;
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  constexpr int KS = 4;  // K-steps of 32 factors: k <= 128
+  const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+  const int k = a.k, kq = k >> 2;
+  const int ksteps32 = (k + 31) >> 5;
+  const int first = 4 * (int)blockIdx.x;
+  // the four rows (a short last quad repeats its last row; only valid groups store)
+  Unit us[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) us[s] = a.units[a.firstDual + min(first + s, count - 1)];
+  int ns[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) ns[s] = (int)(us[s].end - us[s].beg);
+  const int nmax = max(max(ns[0], ns[1]), max(ns[2], ns[3]));
+  // this lane group's row
+  const int n_g = g == 0 ? ns[0] : g == 1 ? ns[1] : g == 2 ? ns[2] : ns[3];
+  const int64_t beg_g = g == 0 ? us[0].beg : g == 1 ? us[1].beg : g == 2 ? us[2].beg : us[3].beg;
+  const int row_g = g == 0 ? us[0].row : g == 1 ? us[1].row : g == 2 ? us[2].row : us[3].row;
+  const bool valid_g = first + g < count;
+  const int64_t q_g = beg_g + (c < n_g ? c : n_g - 1);
+  const unsigned id_g = (unsigned)a.indx[q_g];            // a rating past the end repeats the last one (w = 0)
+  float y = c < n_g ? a.vals[q_g] : 0.0f;                  // right-hand side of row g, lane i: r[i]
+  // ---- Gramians: one tile per row
+  acc_t acc[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int64_t q = us[s].beg + (c < ns[s] ? c : ns[s] - 1);
+    const float *rowp = c < ns[s] ? a.fixed + (int64_t)a.indx[q] * k : a.zeros;
+    float4 z[KS][2];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      const int f = 32 * kk + 8 * g;
+      z[kk][0] = *reinterpret_cast<const float4 *>(f < k ? rowp + f : a.zeros);
+      z[kk][1] = *reinterpret_cast<const float4 *>(f + 4 < k ? rowp + f + 4 : a.zeros);
+    }
+    acc_t t = acc_t{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      if (kk < ksteps32) {  // wave-uniform
+        const float x[8] = {z[kk][0].x, z[kk][0].y, z[kk][0].z, z[kk][0].w, z[kk][1].x, z[kk][1].y, z[kk][1].z, z[kk][1].w};
+        unsigned h[4], m[4], l[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {  // exact 3-way bf16 split by truncation
+          const float x0 = x[2 * jj], x1 = x[2 * jj + 1];
+          const unsigned u0 = __builtin_bit_cast(unsigned, x0), u1 = __builtin_bit_cast(unsigned, x1);
+          h[jj] = __builtin_amdgcn_perm(u1, u0, 0x07060302);
+          const float s0 = x0 - __builtin_bit_cast(float, u0 & 0xFFFF0000u);
+          const float s1 = x1 - __builtin_bit_cast(float, u1 & 0xFFFF0000u);
+          const unsigned v0 = __builtin_bit_cast(unsigned, s0), v1 = __builtin_bit_cast(unsigned, s1);
+          m[jj] = __builtin_amdgcn_perm(v1, v0, 0x07060302);
+          const float t0 = s0 - __builtin_bit_cast(float, v0 & 0xFFFF0000u);
+          const float t1 = s1 - __builtin_bit_cast(float, v1 & 0xFFFF0000u);
+          l[jj] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, t1), __builtin_bit_cast(unsigned, t0), 0x07060302);
+        }
+        const bf16x8 p1 = __builtin_bit_cast(bf16x8, u32x4{h[0], h[1], h[2], h[3]});
+        const bf16x8 p2 = __builtin_bit_cast(bf16x8, u32x4{m[0], m[1], m[2], m[3]});
+        const bf16x8 p3 = __builtin_bit_cast(bf16x8, u32x4{l[0], l[1], l[2], l[3]});
+        // smallest terms first
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(p2, p2, t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(p1, p3, t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(p3, p1, t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(p1, p2, t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(p2, p1, t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(p1, p1, t, 0, 0, 0);
+      }
+    }
+    acc[s] = t;
+  }
+  // ---- lane (s, i) <- row i of G_s: acc[s'][t] at lane (q, c) is G_s'[4q + t][c] = G_s'[c][4q + t]
+  float R[16];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const acc_t in = acc_t{acc[0][t], acc[1][t], acc[2][t], acc[3][t]};
+    float out[4];
+    Sv::transpose_rg(in, out);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) R[4 * q + t] = out[q];
+  }
+  // + lambda n on the diagonal of the real rows, 1 on the padded ones
+  {
+    const float dv = c < n_g ? (float)(a.lambda * (double)n_g) : 1.0f;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) R[m] += c == m ? dv : 0.0f;
+  }
+  // ---- forward elimination, four systems at once
+  float myinv = 1.0f;
+  bool bad = false;
+  auto bc = [](float v, auto P) { return Sv::template row_bcast<decltype(P)::value>(v); };
+  auto pivot = [&](auto P) {
+    constexpr int p = decltype(P)::value;
+    const float d = bc(R[p], P);
+    bad = bad || !(d > 0.0f);
+    const float inv = __builtin_amdgcn_rcpf(d);
+    const float m = c > p ? R[p] * inv : 0.0f;
+    myinv = c == p ? inv : myinv;
+    auto upd = [&](auto J) {
+      constexpr int j = decltype(J)::value;
+      if constexpr (j > p) R[j] = fmaf(-m, bc(R[j], P), R[j]);
+    };
+    upd(std::integral_constant<int, 1>{}); upd(std::integral_constant<int, 2>{}); upd(std::integral_constant<int, 3>{});
+    upd(std::integral_constant<int, 4>{}); upd(std::integral_constant<int, 5>{}); upd(std::integral_constant<int, 6>{});
+    upd(std::integral_constant<int, 7>{}); upd(std::integral_constant<int, 8>{}); upd(std::integral_constant<int, 9>{});
+    upd(std::integral_constant<int, 10>{}); upd(std::integral_constant<int, 11>{}); upd(std::integral_constant<int, 12>{});
+    upd(std::integral_constant<int, 13>{}); upd(std::integral_constant<int, 14>{}); upd(std::integral_constant<int, 15>{});
+    y = fmaf(-m, bc(y, P), y);
+  };
+#define YCNR_P(N) pivot(std::integral_constant<int, N>{});
+  YCNR_P(0) YCNR_P(1) YCNR_P(2) YCNR_P(3) YCNR_P(4) YCNR_P(5) YCNR_P(6) YCNR_P(7)
+  YCNR_P(8) YCNR_P(9) YCNR_P(10) YCNR_P(11) YCNR_P(12) YCNR_P(13) YCNR_P(14) YCNR_P(15)
+#undef YCNR_P
+  // ---- back substitution: w[j] = (y[j] - sum_{i > j} U[j][i] w[i]) / U[j][j], columns from the right
+  float w = 0.0f;
+  auto back = [&](auto J) {
+    constexpr int j = decltype(J)::value;
+    const float t = y * myinv;             // lane j: w[j]
+    w = c == j ? t : w;
+    y = fmaf(-R[j], bc(t, J), y);          // lanes < j take column j out (the others are done or do not matter)
+  };
+#define YCNR_B(N) back(std::integral_constant<int, N>{});
+  YCNR_B(15) YCNR_B(14) YCNR_B(13) YCNR_B(12) YCNR_B(11) YCNR_B(10) YCNR_B(9) YCNR_B(8)
+  YCNR_B(7) YCNR_B(6) YCNR_B(5) YCNR_B(4) YCNR_B(3) YCNR_B(2) YCNR_B(1) YCNR_B(0)
+#undef YCNR_B
+  // ---- x = Y^T w: lane (g, c) owns float4 c and c + 16 of row g's result
+  const char *base = reinterpret_cast<const char *>(a.fixed);
+  const unsigned off0 = (unsigned)min(c, kq - 1) * 16u, off1 = (unsigned)min(c + 16, kq - 1) * 16u;
+  float4 x0 = float4{0.0f, 0.0f, 0.0f, 0.0f}, x1 = float4{0.0f, 0.0f, 0.0f, 0.0f};
+  auto gather = [&](auto I) {
+    constexpr int i = decltype(I)::value;
+    if (i < nmax) {  // wave-uniform
+      const unsigned idi = __builtin_bit_cast(unsigned, bc(__builtin_bit_cast(float, id_g), I));
+      const float wi = bc(w, I);
+      const unsigned ro = idi * (unsigned)(k * 4);
+      const float4 v0 = *reinterpret_cast<const float4 *>(base + (ro + off0));
+      const float4 v1 = *reinterpret_cast<const float4 *>(base + (ro + off1));
+      x0.x = fmaf(v0.x, wi, x0.x); x0.y = fmaf(v0.y, wi, x0.y); x0.z = fmaf(v0.z, wi, x0.z); x0.w = fmaf(v0.w, wi, x0.w);
+      x1.x = fmaf(v1.x, wi, x1.x); x1.y = fmaf(v1.y, wi, x1.y); x1.z = fmaf(v1.z, wi, x1.z); x1.w = fmaf(v1.w, wi, x1.w);
+    }
+  };
+#define YCNR_G(N) gather(std::integral_constant<int, N>{});
+  YCNR_G(0) YCNR_G(1) YCNR_G(2) YCNR_G(3) YCNR_G(4) YCNR_G(5) YCNR_G(6) YCNR_G(7)
+  YCNR_G(8) YCNR_G(9) YCNR_G(10) YCNR_G(11) YCNR_G(12) YCNR_G(13) YCNR_G(14) YCNR_G(15)
+#undef YCNR_G
+  if (valid_g) {
+    float *out = a.solved + (int64_t)row_g * k;
+    if (c < kq) *reinterpret_cast<float4 *>(out + 4 * c) = x0;
+    if (c + 16 < kq) *reinterpret_cast<float4 *>(out + 4 * (c + 16)) = x1;
+    // a pivot that was not positive, or NaN / Inf in the result
+  }
+  {
+    // a pivot that was not positive, or NaN / Inf in the result: one report per row
+    const float chk = (x0.x + x0.y + x0.z + x0.w + x1.x + x1.y + x1.z + x1.w) * 0.0f;
+    const unsigned long long m = __ballot(valid_g && (bad || !(chk == 0.0f)));
+    if (c == 0 && ((m >> (16 * g)) & 0xFFFFull)) {
+      atomicAdd(&a.err->count, 1);
+      a.err->firstRow = row_g;
+    }
+  }
+}
+
 // Kernel 2: one wave per split row -- sum its slabs in slab order, then solve.
 template <typename T, int NB, bool LDS_SOLVER, bool EDGE, bool E4 = false>
 __global__ __launch_bounds__(64) void als_reduce_solve_kernel(StepArgs<T> a) {

@@ -161,12 +161,12 @@ void build_schedule(const int64_t *rowPtr, int64_t rowBegin, int64_t nRows, int 
 
 // environment toggles for A/B experiments from unmodified hosts, read once per process
 struct EnvFlags {
-  bool noDualX6, noX6d, noFusedX6d, noOverlap, ignoreNumeric;
+  bool noDualX6, noX6d, noFusedX6d, noOverlap, ignoreNumeric, noDualQuad;
   size_t k1LdsPad;
 };
 const EnvFlags &env_flags() {
   static const EnvFlags f = {getenv("YCNR_NO_DUAL_X6") != nullptr, getenv("YCNR_NO_X6D") != nullptr, getenv("YCNR_NO_FUSED_X6D") != nullptr,
-                             getenv("YCNR_NO_OVERLAP") != nullptr, getenv("YCNR_IGNORE_NUMERIC") != nullptr,
+                             getenv("YCNR_NO_OVERLAP") != nullptr, getenv("YCNR_IGNORE_NUMERIC") != nullptr, getenv("YCNR_NO_DUAL_QUAD") != nullptr,
                              getenv("YCNR_K1_LDSPAD") ? (size_t)atoi(getenv("YCNR_K1_LDSPAD")) : 0};
   return f;
 }
@@ -208,6 +208,14 @@ int launch_dual(StepArgs<float> args, const DualPlan &dp, hipStream_t stream) {
   if (dp.count[M] > 0) {
     if (dp.nSide > 0) stream = dp.side[dp.nextSide++ % dp.nSide];
     args.firstDual = (int32_t)dp.first[M];
+    if constexpr (M == 1) {
+      // rows of at most 16 ratings: four to a wave (needs 32-bit offsets into a fixed matrix below 4 GB, k <= 128)
+      if (!dp.noX6 && !env_flags().noDualX6 && !env_flags().noDualQuad && args.k <= 128 && args.k % 4 == 0 && args.fixedBytes != 0) {
+        hipLaunchKernelGGL(als_dual_quad_kernel, dim3((unsigned)((dp.count[M] + 3) / 4)), dim3(64), 0, stream, args, (int32_t)dp.count[M]);
+        HIP_TRY(hipGetLastError());
+        return YCNR_OK;
+      }
+    }
     // bf16x6 form unless switched off; NBN = 1 has a single tile and too little to gain
     const bool x6 = !dp.noX6 && !env_flags().noDualX6;
     void (*kd)(StepArgs<float>) = als_dual_solve_kernel<M, false>;
