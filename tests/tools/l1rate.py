@@ -37,8 +37,17 @@ def call(p):
     return n
 
 
-call(portions[0])
-t = time.perf_counter()
-n = sum(call(p) for p in portions)
-dt = time.perf_counter() - t
-print(f"{len(portions)} portions, {n} ratings: {dt / len(portions) * 1e3:.3f} ms per portion, {len(portions) / dt:.1f} portions/s, {n / dt / 1e6:.2f} M ratings/s")
+def run(label):
+    call(portions[0])
+    t = time.perf_counter()
+    n = sum(call(p) for p in portions)
+    dt = time.perf_counter() - t
+    print(f"{label}: {len(portions)} portions, {n} ratings: {dt / len(portions) * 1e3:.3f} ms per portion, {len(portions) / dt:.1f} portions/s, {n / dt / 1e6:.2f} M ratings/s")
+
+
+run("fixed rows compacted and uploaded per portion")
+if hasattr(L, "ycnr_sAlsPinFixedFactors"):
+    L.ycnr_sAlsPinFixedFactors.restype = C.c_int
+    L.ycnr_sAlsPinFixedFactors.argtypes = [C.c_void_p, C.c_int64, C.c_int]
+    assert L.ycnr_sAlsPinFixedFactors(V.ctypes.data, items, k) == 0
+    run("fixed matrix pinned on the device")

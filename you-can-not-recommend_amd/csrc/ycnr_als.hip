@@ -1793,7 +1793,21 @@ struct DevArena {
 struct L1Ctx {
   int device = -1;
   hipStream_t stream = nullptr;
-  DevArena units, split, indx, vals, fixed, solved, slabs, misc;  // misc: ErrInfo + zero row
+  DevArena io, slabs, misc;  // io: [solved | ErrInfo | units | split | indx | vals | compacted fixed rows]; misc: zero row
+  // page-locked host image of io: ONE copy in (everything behind the solved rows) and ONE copy out (solved rows +
+  // ErrInfo) per portion instead of five pageable copies, two memsets and two copies back
+  void *hostIo = nullptr;
+  size_t hostIoCap = 0;
+  hipError_t reserve_host(size_t bytes) {
+    if (bytes <= hostIoCap) return hipSuccess;
+    if (hostIo) (void)hipHostFree(hostIo);
+    hostIo = nullptr;
+    hostIoCap = 0;
+    const size_t cap = bytes + bytes / 2;
+    hipError_t e = hipHostMalloc(&hostIo, cap, hipHostMallocDefault);
+    if (e == hipSuccess) hostIoCap = cap;
+    return e;
+  }
   // fixed matrix pinned by ycnr_{s,d}AlsPinFixedFactors
   const void *pinnedHost = nullptr;
   int64_t pinnedRows = 0;
@@ -1806,7 +1820,10 @@ struct L1Ctx {
       (void)hipStreamDestroy(stream);
     }
     stream = nullptr;
-    for (DevArena *a : {&units, &split, &indx, &vals, &fixed, &solved, &slabs, &misc, &pinned}) a->release();
+    for (DevArena *a : {&io, &slabs, &misc, &pinned}) a->release();
+    if (hostIo) (void)hipHostFree(hostIo);
+    hostIo = nullptr;
+    hostIoCap = 0;
     pinnedHost = nullptr;
     device = -1;
   }
@@ -1828,8 +1845,8 @@ int l1_prepare(L1Ctx &C) {
   }
   if (!C.stream) HIP_TRY(hipStreamCreateWithFlags(&C.stream, hipStreamNonBlocking));
   if (!C.misc.p) {
-    HIP_TRY(C.misc.reserve(kErrBytes + kZeroRowBytes));
-    HIP_TRY(hipMemsetAsync(C.misc.p, 0, kErrBytes + kZeroRowBytes, C.stream));
+    HIP_TRY(C.misc.reserve(kZeroRowBytes));
+    HIP_TRY(hipMemsetAsync(C.misc.p, 0, kZeroRowBytes, C.stream));
   }
   return YCNR_OK;
 }
@@ -1889,17 +1906,21 @@ int64_t als_calc_portion(double lambda, int k, const int32_t *alsRows, const int
   if (rc) return rc;
   const bool pinned = C.pinnedHost == fixedFactors && C.pinnedRows == fixedRows && C.pinnedK == k && C.pinnedDtype == dtype;
   // compact the referenced fixed rows unless the whole matrix is resident
-  std::vector<int32_t> uniq, cidx;
-  std::vector<T> cfix;
+  std::vector<int32_t> uniq, remap;  // remap: fixed row -> compacted row when the fixed side is small enough to mark
   if (!pinned) {
-    uniq.assign(alsIndx, alsIndx + total);
-    std::sort(uniq.begin(), uniq.end());
-    uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
-    cidx.resize((size_t)total);
-    for (int64_t i = 0; i < total; ++i)
-      cidx[i] = (int32_t)(std::lower_bound(uniq.begin(), uniq.end(), alsIndx[i]) - uniq.begin());
-    cfix.resize(uniq.size() * (size_t)k);
-    for (size_t u = 0; u < uniq.size(); ++u) memcpy(&cfix[u * k], fixedFactors + (size_t)uniq[u] * k, sizeof(T) * k);
+    if (fixedRows <= 16 * total) {
+      remap.assign((size_t)fixedRows, -1);
+      for (int64_t i = 0; i < total; ++i) remap[alsIndx[i]] = 0;
+      for (int64_t r = 0; r < fixedRows; ++r)
+        if (remap[r] == 0) {
+          remap[r] = (int32_t)uniq.size();
+          uniq.push_back((int32_t)r);
+        }
+    } else {
+      uniq.assign(alsIndx, alsIndx + total);
+      std::sort(uniq.begin(), uniq.end());
+      uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+    }
   }
   std::vector<Unit> units;
   std::vector<SplitRow> split;
@@ -1908,8 +1929,6 @@ int64_t als_calc_portion(double lambda, int k, const int32_t *alsRows, const int
 
   const int nb = slab_nb(k);
   const size_t slabElems = big ? (size_t)wg_slab_floats(nb) : (size_t)slab_elems(nb);
-  std::vector<T> hostSolved((size_t)nRows * k);
-  ErrInfo ei{};
 #define L1_TRY(expr)                                                                                  \
   do {                                                                                                \
     hipError_t e_ = (expr);                                                                           \
@@ -1917,28 +1936,44 @@ int64_t als_calc_portion(double lambda, int k, const int32_t *alsRows, const int
       return fail(e_ == hipErrorOutOfMemory ? YCNR_ERR_NOMEM : YCNR_ERR_HIP, "%s failed: %s", #expr,  \
                   hipGetErrorString(e_));                                                             \
   } while (0)
-  L1_TRY(C.units.reserve(sizeof(Unit) * std::max<size_t>(1, units.size())));
-  L1_TRY(C.split.reserve(sizeof(SplitRow) * std::max<size_t>(1, split.size())));
-  L1_TRY(C.indx.reserve(sizeof(int32_t) * (size_t)total + 64));
-  L1_TRY(C.vals.reserve(sizeof(T) * (size_t)total + 64));
-  if (!pinned) L1_TRY(C.fixed.reserve(sizeof(T) * cfix.size()));
-  L1_TRY(C.solved.reserve(sizeof(T) * hostSolved.size()));
+  // layout of the io arena (device) and of its page-locked host image, 256-byte aligned parts
+  auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  const size_t oSolved = 0, bSolved = sizeof(T) * (size_t)nRows * k;
+  const size_t oErr = al(oSolved + bSolved);
+  const size_t oUnits = al(oErr + sizeof(ErrInfo)), oSplit = al(oUnits + sizeof(Unit) * std::max<size_t>(1, units.size()));
+  const size_t oIndx = al(oSplit + sizeof(SplitRow) * std::max<size_t>(1, split.size()));
+  const size_t oVals = al(oIndx + sizeof(int32_t) * (size_t)total + 64);
+  const size_t oFixed = al(oVals + sizeof(T) * (size_t)total + 64);
+  const size_t ioBytes = al(oFixed + (pinned ? 0 : sizeof(T) * uniq.size() * (size_t)k));
+  L1_TRY(C.io.reserve(ioBytes));
+  L1_TRY(C.reserve_host(ioBytes));
   L1_TRY(C.slabs.reserve(sizeof(T) * std::max<size_t>(1, (size_t)nSlabs * slabElems)));
+  char *hb = (char *)C.hostIo, *db = (char *)C.io.p;
+  memset(hb + oErr, 0, sizeof(ErrInfo));
+  if (!units.empty()) memcpy(hb + oUnits, units.data(), sizeof(Unit) * units.size());
+  if (!split.empty()) memcpy(hb + oSplit, split.data(), sizeof(SplitRow) * split.size());
+  if (pinned) {
+    memcpy(hb + oIndx, alsIndx, sizeof(int32_t) * (size_t)total);
+  } else {
+    int32_t *cidx = (int32_t *)(hb + oIndx);
+    if (!remap.empty()) {
+      for (int64_t i = 0; i < total; ++i) cidx[i] = remap[alsIndx[i]];
+    } else {
+      for (int64_t i = 0; i < total; ++i) cidx[i] = (int32_t)(std::lower_bound(uniq.begin(), uniq.end(), alsIndx[i]) - uniq.begin());
+    }
+    T *cfix = (T *)(hb + oFixed);
+    for (size_t u = 0; u < uniq.size(); ++u) memcpy(cfix + u * k, fixedFactors + (size_t)uniq[u] * k, sizeof(T) * k);
+  }
+  memcpy(hb + oVals, alsVals, sizeof(T) * (size_t)total);
   hipStream_t stream = C.stream;
-  ErrInfo *dErr = (ErrInfo *)C.misc.p;
-  T *dZeros = (T *)((char *)C.misc.p + kErrBytes);
-  L1_TRY(hipMemsetAsync(dErr, 0, sizeof(ErrInfo), stream));
-  L1_TRY(hipMemsetAsync(C.solved.p, 0, sizeof(T) * hostSolved.size(), stream));
-  if (!units.empty()) L1_TRY(hipMemcpyAsync(C.units.p, units.data(), sizeof(Unit) * units.size(), hipMemcpyHostToDevice, stream));
-  if (!split.empty()) L1_TRY(hipMemcpyAsync(C.split.p, split.data(), sizeof(SplitRow) * split.size(), hipMemcpyHostToDevice, stream));
-  L1_TRY(hipMemcpyAsync(C.indx.p, pinned ? alsIndx : cidx.data(), sizeof(int32_t) * (size_t)total, hipMemcpyHostToDevice, stream));
-  L1_TRY(hipMemcpyAsync(C.vals.p, alsVals, sizeof(T) * (size_t)total, hipMemcpyHostToDevice, stream));
-  if (!pinned) L1_TRY(hipMemcpyAsync(C.fixed.p, cfix.data(), sizeof(T) * cfix.size(), hipMemcpyHostToDevice, stream));
+  ErrInfo *dErr = (ErrInfo *)(db + oErr);
+  T *dZeros = (T *)C.misc.p;
+  L1_TRY(hipMemcpyAsync(db + oErr, hb + oErr, ioBytes - oErr, hipMemcpyHostToDevice, stream));
   {
     // rows are numbered 0..nRows-1 on the device and scattered to rowId on the host
-    const T *dFixed = pinned ? (const T *)C.pinned.p : (const T *)C.fixed.p;
-    StepArgs<T> a{(const Unit *)C.units.p, (const SplitRow *)C.split.p, (const int32_t *)C.indx.p, (const T *)C.vals.p, dFixed, dZeros,
-                  (T *)C.solved.p, (T *)C.slabs.p, dErr, lambda, k, 0, 0, 0u};
+    const T *dFixed = pinned ? (const T *)C.pinned.p : (const T *)(db + oFixed);
+    StepArgs<T> a{(const Unit *)(db + oUnits), (const SplitRow *)(db + oSplit), (const int32_t *)(db + oIndx), (const T *)(db + oVals), dFixed, dZeros,
+                  (T *)(db + oSolved), (T *)C.slabs.p, dErr, lambda, k, 0, 0, 0u};
     if constexpr (std::is_same<T, float>::value) {
       if (big) rc = launch_step_big(a, (int64_t)units.size(), nSlabs, (int64_t)split.size(), stream, nullptr, DualPlan());
       else rc = launch_step<T>(a, (int64_t)units.size(), nSlabs, (int64_t)split.size(), stream, nullptr);
@@ -1947,15 +1982,17 @@ int64_t als_calc_portion(double lambda, int k, const int32_t *alsRows, const int
     }
     if (rc) return rc;
   }
-  L1_TRY(hipMemcpyAsync(hostSolved.data(), C.solved.p, sizeof(T) * hostSolved.size(), hipMemcpyDeviceToHost, stream));
-  L1_TRY(hipMemcpyAsync(&ei, dErr, sizeof ei, hipMemcpyDeviceToHost, stream));
+  // rows without ratings are never written by the kernels and never copied back below
+  L1_TRY(hipMemcpyAsync(hb + oSolved, db + oSolved, oErr + sizeof(ErrInfo), hipMemcpyDeviceToHost, stream));
   L1_TRY(hipStreamSynchronize(stream));
 #undef L1_TRY
+  const ErrInfo ei = *(const ErrInfo *)(hb + oErr);
+  const T *hostSolved = (const T *)(hb + oSolved);
   if (ei.count > 0)
     return fail(YCNR_ERR_NUMERIC, "%d row(s) of the portion had a normal matrix that is not positive definite", ei.count);
   for (int r = 0; r < nRows; ++r) {
     if (rowPtr[r + 1] == rowPtr[r]) continue;  // cols == 0: left untouched
-    memcpy(solvedFactors + (size_t)alsRows[1 + 2 * r] * k, &hostSolved[(size_t)r * k], sizeof(T) * k);
+    memcpy(solvedFactors + (size_t)alsRows[1 + 2 * r] * k, hostSolved + (size_t)r * k, sizeof(T) * k);
   }
   return total;
 }
