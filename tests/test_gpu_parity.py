@@ -202,7 +202,7 @@ def test_every_row_length_class(als, k):
         info = dev.step("byUser")
         if name == "dual":
             nb = (k + 15) // 16
-            dual_max = 16 * min(10 if k > 128 else 5, nb - 1)   # k > 128: up to 160 ratings stay one wave's n x n problem
+            dual_max = 16 * min(11 if k > 128 else 5, nb - 1)   # k > 128: up to 176 ratings stay one wave's n x n problem
             assert info.dualRows == sum(1 for n in lens if 0 < n <= dual_max)
         else:
             assert info.dualRows == 0

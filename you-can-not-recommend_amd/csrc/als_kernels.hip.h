@@ -891,7 +891,7 @@ struct SolveMfmaF32 {
           R[4 * m4 + 3] = xlane ? (c == 4 * m4 + 3 ? 1.0f : 0.0f) : v.w;
         }
       }
-      // NB = 10 (dual rows of 145 .. 160 ratings at k > 128) keeps the v_readlane form: with the inline-asm
+      // NB >= 10 (dual rows of 145 .. 176 ratings at k > 128) keeps the v_readlane form: with the inline-asm
       // updates hipcc stopped using the accumulator half of the register file there (183 + 8 registers and
       // 1104 bytes of scratch per lane instead of 256 + 256 and none) and the class ran twice as long
       if constexpr (YCNR_DPP_PIVOTS && NB <= 9) {

@@ -37,7 +37,7 @@
 //
 //  Rows longer than a launch wants in one workgroup are cut into chunks whose tiles go to a slab in
 //  global memory in image layout (als_wg_gram_slab_kernel) and are summed in slab order before the
-//  same solve (als_wg_reduce_solve_kernel).  Rows of <= 160 ratings never come here: they take the
+//  same solve (als_wg_reduce_solve_kernel).  Rows of <= 176 ratings never come here: they take the
 //  dual form (als_dual_solve_kernel).
 #pragma once
 #include "als_kernels.hip.h"

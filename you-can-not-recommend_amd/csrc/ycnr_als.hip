@@ -57,7 +57,7 @@ constexpr int kMaxSlabsPerRow = 64;  // heavier rows get proportionally longer c
 constexpr int64_t kBandBytes = (int64_t)96 << 20;  // slice of the fixed matrix one band of chunks gathers from (cache-sized)
 constexpr size_t kErrBytes = 65536;
 constexpr size_t kZeroRowBytes = 2048;  // >= kMaxFactors doubles
-constexpr int kMaxDualBlocks = 10;       // dual-form kernels exist for 1..10 blocks of 16 ratings
+constexpr int kMaxDualBlocks = 11;       // dual-form kernels exist for 1..11 blocks of 16 ratings (12 spills 1452 bytes per lane)
 constexpr int kMaxDualBlocksSmallK = 5;  // k <= 128: beyond 80 ratings the row kernel (k x k) is cheaper (MAL scale, k = 100: 6 -> 5 blocks took 0.2 ms off the user half-step once the solve had lost its readlanes and transposes; 4 was slower)
 
 size_t tsize(int dtype) { return dtype == YCNR_F64 ? 8 : 4; }
@@ -230,7 +230,8 @@ template <typename T>
 int launch_duals(const StepArgs<T> &, const DualPlan &, hipStream_t) { return YCNR_OK; }
 template <>
 int launch_duals<float>(const StepArgs<float> &args, const DualPlan &dp, hipStream_t stream) {
-  int rc = launch_dual<10>(args, dp, stream);
+  int rc = launch_dual<11>(args, dp, stream);
+  if (!rc) rc = launch_dual<10>(args, dp, stream);
   if (!rc) rc = launch_dual<9>(args, dp, stream);
   if (!rc) rc = launch_dual<8>(args, dp, stream);
   if (!rc) rc = launch_dual<7>(args, dp, stream);
@@ -498,7 +499,7 @@ int dual_max_ratings(const ycnr_als_options &o) {
   if (o.dtype != YCNR_F32 || (o.flags & (YCNR_FLAG_LDS_SOLVER | YCNR_FLAG_NO_DUAL)) || (o.factorsCount % 4 != 0 && o.factorsCount <= kMaxFactors)) return 0;
   const int nb = slab_nb(o.factorsCount);
   // k > 128: every row that is not dual goes through slabs and the 4-wave LDS solve, whose cost
-  // grows with k^3; an n x n problem with n <= 160 still fits one wave's registers
+  // grows with k^3; an n x n problem with n <= 176 still fits one wave's registers
   int most = o.factorsCount > kMaxFactors ? kMaxDualBlocks : kMaxDualBlocksSmallK;
   if (const char *e = getenv("YCNR_DUAL_MAX_BLOCKS")) most = std::max(0, std::min(atoi(e), o.factorsCount > kMaxFactors ? kMaxDualBlocks : kMaxDualBlocksSmallK));  // experiments
   return 16 * std::min(most, nb - 1);
