@@ -770,12 +770,7 @@ struct SolveMfmaF32 {
   static __device__ __forceinline__ float row_bcast(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + N, 0xF, 0xF, true));
   }
-  // Pivot P of the diagonal tile without v_readlane.  Lane groups 0 / 2 hold the rows of D (lane i: row i),
-  // groups 1 / 3 the columns of the identity that become L^-1.  The multiplier of column j is L[j][P], the
-  // value lane j of group 0 has in R[P]: one v_permlane16_swap copies that register's group 0 / 2 values into
-  // groups 1 / 3, after which every 16-lane row finds L[j][P] in its own lane j and the update of column j
-  // is ONE v_fmac_f32 with a DPP row_newbcast operand for all four groups (v_readlane + v_fma before).
-  // Same products, same fma: bit for bit the results of the v_readlane form.
+  // Lane groups 0 / 2 hold the rows of D (lane i: row i), groups 1 / 3 the columns of the identity that become L^-1.
   // Pivot P of the diagonal tile without v_readlane for the multipliers.  The multiplier of column j is
   // L[j][P], the value lane j of group 0 has in R[P]: one v_permlane16_swap copies that register's group
   // 0 / 2 values into groups 1 / 3, after which every 16-lane row finds L[j][P] in its own lane j and the
