@@ -1678,13 +1678,28 @@ struct GramX6D {
         if constexpr (SPLIT) {
           asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NH) : "memory");  // block bi of step s + 1 has landed
           const unsigned ra = rdBase + (unsigned)bi * 2048u;
+#ifdef YCNR_X6D_PLAIN_LDS  // experiment on the packed-rhs failure: LDS loads the compiler counts itself
+          {
+            typedef __attribute__((address_space(3))) const float lds_float;
+            lds_float *sp = (lds_float *)(uintptr_t)ra;
+            x01 = f32x2{sp[0], sp[32]};
+            x23 = f32x2{sp[64], sp[96]};
+            x45 = f32x2{sp[128], sp[160]};
+            x67 = f32x2{sp[192], sp[224]};
+          }
+#else
           asm volatile("ds_read2_b32 %0, %4 offset1:32\n\tds_read2_b32 %1, %4 offset0:64 offset1:96\n\t"
                        "ds_read2_b32 %2, %4 offset0:128 offset1:160\n\tds_read2_b32 %3, %4 offset0:192 offset1:224"
                        : "=&v"(x01), "=&v"(x23), "=&v"(x45), "=&v"(x67) : "v"(ra) : "memory");
+#endif
         }
         if constexpr (MMA) mma_row(bi);
         if constexpr (SPLIT) {
+#ifdef YCNR_X6D_PK_NOP  // experiment on the packed-rhs failure: idle cycles between the wait and the first use
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 7\n\ts_nop 7" : "+v"(x01), "+v"(x23), "+v"(x45), "+v"(x67)::"memory");
+#else
           asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x01), "+v"(x23), "+v"(x45), "+v"(x67)::"memory");
+#endif
           gather_block(bi);  // step s + 2 into the slots just read
           float x[8] = {x01[0], x01[1], x23[0], x23[1], x45[0], x45[1], x67[0], x67[1]};
           if (bi == NB - 1) {
