@@ -286,20 +286,28 @@ struct GramPlain {
                                                          const T *zeros, int k, int64_t beg, int64_t end, int lane) {
     G::accumulate(s.acc, s.bacc, indx, vals, fixed, zeros, k, beg, end, lane);  // plain form: one step ahead
   }
+  // Plain slab layout (also written by the bf16x6 chunk kernels): tile t as 64 lanes x 4 registers, i.e. ONE
+  // 16-byte (float) access per lane and tile, then the rhs partials one register per 64-lane row.  s points at
+  // the slab's element of this lane (base + lane), as before.  (Round 1 stored one register per 64-lane row
+  // throughout: 119 four-byte loads per slab against a 63-deep vmcnt; the reduce kernel now has 4x the bytes in
+  // flight per wave.)
+  struct alignas(sizeof(T) * 4) Quad {
+    T v[4];
+  };
   static __device__ __forceinline__ void store_slab(const State &st, T *s) {
+    Quad *q = reinterpret_cast<Quad *>(s + 3 * (int)threadIdx.x);  // base + 4 lane
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) s[(t * 4 + r) * 64] = st.acc[t][r];
-    }
+    for (int t = 0; t < NT; ++t) q[t * 64] = Quad{{st.acc[t][0], st.acc[t][1], st.acc[t][2], st.acc[t][3]}};
 #pragma unroll
     for (int cb = 0; cb < NB; ++cb) s[(NT * 4 + cb) * 64] = st.bacc[cb];
   }
   static __device__ __forceinline__ void add_slab(State &st, const T *s) {
+    const Quad *q = reinterpret_cast<const Quad *>(s + 3 * (int)threadIdx.x);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
+      const Quad v = q[t * 64];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) st.acc[t][r] += s[(t * 4 + r) * 64];
+      for (int r = 0; r < 4; ++r) st.acc[t][r] += v.v[r];
     }
 #pragma unroll
     for (int cb = 0; cb < NB; ++cb) st.bacc[cb] += s[(NT * 4 + cb) * 64];
@@ -1513,12 +1521,11 @@ __global__ __launch_bounds__(64, 1) void als_gram_slab_x6_kernel(StepArgs<float>
     mma6(q1, q2, q3);             // step s + 1 (all zero when s + 1 == nsteps)
   }
   // same slab layout as GramPlain: [tile][reg][lane], then NB rhs partials
+  // plain slab layout (Gram<float, NB>::store_slab): 16 bytes per lane and tile, then the rhs partials
   float *sl = a.slabs + (int64_t)u.slab * slab_elems(NB) + lane;
+  float4 *sq = reinterpret_cast<float4 *>(a.slabs + (int64_t)u.slab * slab_elems(NB)) + lane;
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) sl[(t * 4 + r) * 64] = acc[t][r];
-  }
+  for (int t = 0; t < NT; ++t) sq[t * 64] = float4{acc[t][0], acc[t][1], acc[t][2], acc[t][3]};
 #pragma unroll
   for (int cb = 0; cb < NB; ++cb) sl[(NT * 4 + cb) * 64] = bacc[cb];
 }
@@ -1806,12 +1813,11 @@ __global__ __launch_bounds__(64, 2) void als_gram_slab_x6d_kernel(StepArgs<float
   for (int cb = 0; cb < NB; ++cb) bacc[cb] = 0.0f;
   G::accumulate(acc, bacc, lds, a.indx, a.vals, a.fixed, a.fixedBytes, a.k, u.beg, u.end - u.beg, lane);
   if constexpr (PADRHS) G::extract_rhs(acc, bacc, a.k, lane);
+  // plain slab layout (Gram<float, NB>::store_slab): 16 bytes per lane and tile, then the rhs partials
   float *sl = a.slabs + (int64_t)u.slab * slab_elems(NB) + lane;
+  float4 *sq = reinterpret_cast<float4 *>(a.slabs + (int64_t)u.slab * slab_elems(NB)) + lane;
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) sl[(t * 4 + r) * 64] = acc[t][r];
-  }
+  for (int t = 0; t < NT; ++t) sq[t * 64] = float4{acc[t][0], acc[t][1], acc[t][2], acc[t][3]};
 #pragma unroll
   for (int cb = 0; cb < NB; ++cb) sl[(NT * 4 + cb) * 64] = bacc[cb];
 }
