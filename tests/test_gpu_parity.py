@@ -597,3 +597,26 @@ def test_ranks_on_one_gpu_equal_one_rank(tmp_path, world):
     a, b = np.load(one), np.load(two)
     assert np.array_equal(a["U"], b["U"]) and np.array_equal(a["V"], b["V"])
     assert abs(float(a["rmse"]) - float(b["rmse"])) < 1e-12
+
+@pytest.mark.gpu
+def test_four_rows_per_wave_kernel_against_the_one_row_kernel(tmp_path):
+    """Rows of at most 16 ratings take als_dual_quad_kernel (four rows per wave, Gaussian elimination in 16-lane
+    groups); YCNR_NO_DUAL_QUAD=1 sends them through als_dual_solve_kernel<1> (block Cholesky) instead.  The
+    toggle is read once per process, so each build of the result is a child process of bench.py; the two must
+    agree to float32 rounding on every row, and the half of the users that have at most 16 ratings must
+    actually differ somewhere (else the toggle did nothing)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = [sys.executable, os.path.join(root, "bench.py"), "--workload", "ml100k", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    quad, one = str(tmp_path / "quad.npz"), str(tmp_path / "one.npz")
+    env = dict(os.environ)
+    env.pop("YCNR_NO_DUAL_QUAD", None)
+    subprocess.check_call(common + ["--dump-factors", quad], timeout=600, env=env, stdout=subprocess.DEVNULL)
+    env["YCNR_NO_DUAL_QUAD"] = "1"
+    subprocess.check_call(common + ["--dump-factors", one], timeout=600, env=env, stdout=subprocess.DEVNULL)
+    a, b = np.load(quad), np.load(one)
+    for name in ("U", "V"):
+        d = np.abs(a[name].astype(np.float64) - b[name]).max(axis=1) / np.maximum(np.abs(b[name]).max(axis=1), 1e-30)
+        assert d.max() <= 2e-5, (name, float(d.max()))
+    assert not np.array_equal(a["U"], b["U"])
