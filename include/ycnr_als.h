@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define YCNR_ALS_ABI_VERSION 2
+#define YCNR_ALS_ABI_VERSION 3
 
 /* error codes */
 #define YCNR_OK 0
@@ -93,6 +93,11 @@ int64_t ycnr_dAlsCalcPortion(double lambda, int k, const int32_t *alsRows, const
  * cached per thread either way; ycnr_AlsReleasePortionState frees them. */
 int ycnr_sAlsPinFixedFactors(const float *fixedFactors, int64_t fixedRows, int k);
 int ycnr_dAlsPinFixedFactors(const double *fixedFactors, int64_t fixedRows, int k);
+/* Forget the pinned matrix (the device copy stays allocated for the next pin).  A portion call whose
+ * solvedFactors overlaps the pinned host range does this by itself: the reference's host updates its matrices
+ * in place (the matrix pinned for 'byUser' is the one 'byItem' writes, EmfBase.js:518-532), so such a call
+ * has just made the device copy stale. */
+int ycnr_AlsUnpinFixedFactors(void);
 int ycnr_AlsReleasePortionState(void);
 
 /* ycnr_{s,d}RmsePortion replaces EmfWorker.mw_calcRmsePortion, lib/emf/EmfWorker.js:266-315:
@@ -262,16 +267,17 @@ int ycnr_comm_unique_id(int transport, void *id128);
 int ycnr_als_comm_init(ycnr_als *h, int transport, const void *id128, int rank, int world);
 int ycnr_als_comm_destroy(ycnr_als *h);
 /* Sharded upload of one side for all ranks of the communicator (world = 1 without one):
- *   bounds   int64[world * (nChunks + 1)], ascending; rank r solves rows [bounds[r (nChunks+1)],
+ *   boundsWorld  the number of ranks `bounds` describes; must equal the communicator's world
+ *   bounds   int64[boundsWorld * (nChunks + 1)], ascending; rank r solves rows [bounds[r (nChunks+1)],
  *            bounds[r (nChunks+1) + nChunks]) in nChunks pieces cut at the values in between; the
- *            shards tile the side's rows in rank order.  The host chooses the cuts (cost-balanced:
+ *            shards tile the side's rows [0, rows) in rank order.  The host chooses the cuts (cost-balanced:
  *            the counterpart of EmfLord.splitToPortions, lib/emf/EmfLord.js:510-612).
  * rowPtr / indx / vals describe the WHOLE side (only this rank's slice is copied to the device).
  * After this call ycnr_als_step(side) includes the exchange: piece c's rows travel while piece
  * c + 1 is being solved, and the step returns when every replica holds every solved row -- the
  * meaning of 'stepComplete' in the reference's cluster (EmfLord.alsTrainStep, EmfLord.js:963-984). */
 int ycnr_als_set_ratings_sharded(ycnr_als *h, int side, const int64_t *rowPtr, const int32_t *indx, const void *vals,
-                                 int memKind, int nChunks, const int64_t *bounds);
+                                 int memKind, int nChunks, int boundsWorld, const int64_t *bounds);
 /* The exchange alone, whole shards, synchronous (e.g. after ycnr_als_set_factors of local rows). */
 int ycnr_als_exchange(ycnr_als *h, int side);
 /* root's whole matrix to every rank. */

@@ -12,9 +12,9 @@ const { Dataset, rng } = require(path.join(root, 'lib', 'Dataset'));
 const n = als.native;
 for (const f of ['sAlsCalcPortion', 'dAlsCalcPortion', 'sRmsePortion', 'dRmsePortion', 'create', 'destroy', 'setRatings',
   'setRmseRatings', 'setFactors', 'getFactors', 'step', 'rmse', 'deviceCount', 'lastError', 'version',
-  'commUniqueId', 'commInit', 'setRatingsSharded', 'allreduceSum', 'broadcastFactors', 'exchange'])
+  'alsUnpinFixedFactors', 'commUniqueId', 'commInit', 'setRatingsSharded', 'allreduceSum', 'broadcastFactors', 'exchange'])
   assert.strictEqual(typeof n[f], 'function', f);
-assert.strictEqual(n.version(), 2);
+assert.strictEqual(n.version(), 3);
 // the communicator id of the shared-memory stand-in needs no GPU: 128 bytes, not all zero, new every time
 const id1 = n.commUniqueId(als.COMM_SHM), id2 = n.commUniqueId(als.COMM_SHM);
 assert.strictEqual(id1.length, 128);

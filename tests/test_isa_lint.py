@@ -69,6 +69,24 @@ _ZN4ycnr6dppbadEv: ; @dppbad
 """
 
 
+PK_BAD = """
+_ZN4ycnr24als_gram_slab_x6d_kernelILi4ELb0EEEvNS_8StepArgsIfEE: ; @x6d
+	v_pk_fma_f32 v[120:121], v[122:123], v[30:31], v[120:121] op_sel_hi:[1,0,1]
+	s_endpgm
+_ZN4ycnr21als_dual_solve_kernelILi2ELb1EEEvNS_8StepArgsIfEE: ; @other kernels may pack
+	v_pk_fma_f32 v[2:3], v[4:5], v[6:7], v[2:3]
+	s_endpgm
+"""
+
+
+def test_packed_fma_lint_names_the_gram_x6d_kernels_only(tmp_path, capsys):
+    lint = load_lint()
+    f = tmp_path / "pk.s"
+    f.write_text(PK_BAD)
+    assert lint.lint_packed_fma(str(f)) == 1
+    assert "x6d" in capsys.readouterr().out
+
+
 def test_dpp_lint_counts_wait_states_over_every_path(tmp_path, capsys):
     lint = load_lint()
     good, bad = tmp_path / "good.s", tmp_path / "bad.s"
@@ -103,3 +121,6 @@ def test_device_assembly_has_no_premature_lds_uses(tmp_path):
     assert lint.lint_dpp(str(out), []) == 0
     # no instantiation may spill hundreds of bytes per lane to scratch (one did, unnoticed, at twice the run time)
     assert lint.lint_scratch(str(out)) == 0
+    # the fence of the stale-b hazard: hipcc must not have packed any multiply-add of a GramX6D kernel into
+    # v_pk_fma_f32 (devtest/pkrepro.hip is the reproducer)
+    assert lint.lint_packed_fma(str(out)) == 0

@@ -55,6 +55,22 @@ def test_js_host_on_cpu(tmp_path):
         assert "hip" in out["prepareError"].lower()
 
 
+def test_js_lord_rejects_when_a_gpu_process_dies():
+    """EmfLord.trainOnGpus: a per-GPU process killed by a signal reports code === null; the Lord must
+    reject and kill the survivors instead of waiting for 'trained' forever (and an overall time limit
+    covers a process that neither answers nor dies)."""
+    script = os.path.join(HERE, "js", "lord_death.js")
+    r = subprocess.run(["node", script], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["outcome"] == "rejected" and "SIGKILL" in out["error"] and out["ms"] < 20000, out
+    env = dict(os.environ, YCNR_TEST_DIE_SIGNAL="SIGSTOP", YCNR_TEST_TIMEOUT_MS="1500")
+    r = subprocess.run(["node", script], capture_output=True, text=True, timeout=60, env=env)
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["outcome"] == "rejected" and "no result within" in out["error"], out
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("double", [False, True])
 def test_js_train_matches_python_host(tmp_path, double):

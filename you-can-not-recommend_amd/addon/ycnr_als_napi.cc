@@ -141,6 +141,10 @@ napi_value AlsPinFixedFactors(napi_env env, napi_callback_info info) {
   if (rc) return throw_last(env, "AlsPinFixedFactors", rc);
   return nullptr;
 }
+napi_value AlsUnpinFixedFactors(napi_env env, napi_callback_info) {
+  ycnr_AlsUnpinFixedFactors();
+  return nullptr;
+}
 napi_value AlsReleasePortionState(napi_env env, napi_callback_info) {
   ycnr_AlsReleasePortionState();
   (void)env;
@@ -447,8 +451,9 @@ napi_value SetRatingsSharded(napi_env env, napi_callback_info info) {
   if (nChunks < 1 || bounds.empty() || bounds.size() % (size_t)(nChunks + 1) != 0) return throw_msg(env, "bounds must hold world * (nChunks + 1) row ids");
   if (rowPtr.back() < 0 || (size_t)rowPtr.back() > indx.length || (size_t)rowPtr.back() > vals.length)
     return throw_msg(env, "indx / vals shorter than rowPtr says");
+  // the library checks the rank count the array describes against its communicator's world
   int rc = ycnr_als_set_ratings_sharded(hd->h, (int)side, rowPtr.data(), static_cast<const int32_t *>(indx.data), vals.data, YCNR_MEM_HOST,
-                                        (int)nChunks, bounds.data());
+                                        (int)nChunks, (int)(bounds.size() / (size_t)(nChunks + 1)), bounds.data());
   if (rc) return throw_last(env, "setRatingsSharded", rc);
   return nullptr;
 }
@@ -668,6 +673,7 @@ napi_value Init(napi_env env, napi_value exports) {
       {"recommendItems", nullptr, RecommendItems, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
       {"sAlsPinFixedFactors", nullptr, AlsPinFixedFactors<false>, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
       {"dAlsPinFixedFactors", nullptr, AlsPinFixedFactors<true>, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+      {"alsUnpinFixedFactors", nullptr, AlsUnpinFixedFactors, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
       {"alsReleasePortionState", nullptr, AlsReleasePortionState, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
       {"commUniqueId", nullptr, CommUniqueId, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
       {"commInit", nullptr, CommInit, nullptr, nullptr, nullptr, napi_enumerable, nullptr},

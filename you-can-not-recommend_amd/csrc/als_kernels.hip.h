@@ -1351,6 +1351,7 @@ struct StepArgs {
   int32_t firstFused;  // units[0 .. firstFused) are split chunks, the rest whole rows
   int32_t firstDual;   // first unit of the dual-form launch in flight
   uint32_t fixedBytes; // size of the fixed matrix when it is below 4 GB (buffer loads), else 0
+  int32_t kReal = 0;   // != 0: only the first kReal of the k columns are factors, the rest zero padding (unit diagonal)
 };
 
 // Kernel 1a: one wave per SPLIT unit -- gather + Gramian + rhs of a chunk of a heavy row,

@@ -471,10 +471,12 @@ struct WgSolve {
     int *flag = reinterpret_cast<int *>(smem + C::FLAG_OFF), *rowCounter = flag + 1;
     const float lam = (float)(a.lambda * (double)nRatings);
     const int off = wg_tile_lane_off(lane) >> 2;
-    // diagonal: + lam on real indices, 1 on padded ones
+    // diagonal: + lam on real indices, 1 on padded ones (also the zero columns a row padded to a multiple of 4
+    // carries: with lam there, a regularisation of 0 would make their pivots 0)
+    const int kDiag = a.kReal > 0 ? a.kReal : k;
     for (int i = tid; i < NB * 16; i += kWgThreads) {
       const int r = i & 15;
-      tile(S, i >> 4, i >> 4)[r * 16 + 4 * ((r >> 2) ^ ((r >> 1) & 3)) + (r & 3)] += (i < k) ? lam : 1.0f;
+      tile(S, i >> 4, i >> 4)[r * 16 + 4 * ((r >> 2) ^ ((r >> 1) & 3)) + (r & 3)] += (i < kDiag) ? lam : 1.0f;
     }
     if (tid == 0) *flag = 0;
     YCNR_STAMP(a, 0);

@@ -211,6 +211,28 @@ def lint_scratch(path, limit=512):
     return bad
 
 
+def lint_packed_fma(path, kernels=("x6d",)):
+    """The fence of the stale-b hazard: with the right-hand side's multiply-adds of two column
+    blocks SLP-packed into v_pk_fma_f32, the GramX6D kernels computed a wrong b in lanes 48..63 under full
+    occupancy (devtest/pkrepro.hip reproduces it).  The source keeps hipcc from packing with an empty asm
+    per accumulator; a compiler that packs somewhere else would pass every CPU test and fail only on the
+    GPU, so the build itself is checked: NO v_pk_fma_f32 in any kernel built around GramX6D."""
+    text = open(path).read()
+    bad = seen = 0
+    for m in re.finditer(r"^(_Z[\w]+):[^\n]*$", text, re.M):
+        name = m.group(1)
+        if "ycnr" not in name or not any(w in name for w in kernels):
+            continue
+        seen += 1
+        end = text.find("s_endpgm", m.end())
+        n = len(re.findall(r"^\s*v_pk_fma_f32\b", text[m.end():end], re.M))
+        if n:
+            bad += 1
+            print(f"FAIL {name[:90]}: {n} v_pk_fma_f32 in a GramX6D kernel")
+    print(f"GramX6D kernels checked for packed multiply-adds: {seen}")
+    return bad
+
+
 if __name__ == "__main__":
     n = lint(sys.argv[1], sys.argv[2:])
     print("premature uses:", n)
@@ -218,4 +240,6 @@ if __name__ == "__main__":
     print("DPP reads too early:", nd)
     ns = lint_scratch(sys.argv[1])
     print("kernels spilling to scratch:", ns)
-    sys.exit(1 if n or nd or ns else 0)
+    npk = lint_packed_fma(sys.argv[1])
+    print("GramX6D kernels with packed multiply-adds:", npk)
+    sys.exit(1 if n or nd or ns or npk else 0)

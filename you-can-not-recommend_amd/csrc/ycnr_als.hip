@@ -1300,12 +1300,17 @@ int ycnr_als_set_ratings(ycnr_als *h, int side, const int64_t *rowPtr, const int
 }
 
 int ycnr_als_set_ratings_sharded(ycnr_als *h, int side, const int64_t *rowPtr, const int32_t *indx, const void *vals, int memKind,
-                                 int nChunks, const int64_t *bounds) {
+                                 int nChunks, int boundsWorld, const int64_t *bounds) {
   if (!h || !bounds) return fail(YCNR_ERR_INVALID, "null argument");
   if (side != YCNR_BY_USER && side != YCNR_BY_ITEM) return fail(YCNR_ERR_INVALID, "bad side %d", side);
   if (nChunks < 1 || nChunks > 64) return fail(YCNR_ERR_INVALID, "set_ratings_sharded: nChunks %d outside [1, 64]", nChunks);
   const int world = h->comm.world, rank = h->comm.rank;
+  if (boundsWorld != world)
+    return fail(YCNR_ERR_INVALID, "set_ratings_sharded: bounds describe %d rank(s), the handle's communicator has %d", boundsWorld, world);
   const size_t n = (size_t)world * (size_t)(nChunks + 1);
+  if (bounds[0] != 0 || bounds[n - 1] != h->rows(side))
+    return fail(YCNR_ERR_INVALID, "set_ratings_sharded: the shards must tile rows [0, %lld) (got [%lld, %lld))", (long long)h->rows(side),
+                (long long)bounds[0], (long long)bounds[n - 1]);
   int64_t prev = 0;
   for (size_t i = 0; i < n; ++i) {
     if (bounds[i] < prev || bounds[i] > h->rows(side))
@@ -1401,6 +1406,7 @@ static int launch_part(ycnr_als *h, int side, Part &part) {
     StepArgs<float> a{S.dUnits, S.dSplit, R.dIndx, (const float *)R.dVals, fixedM,
                       (const float *)h->dZeros, solvedM, (float *)S.dSlabs, h->dErr, lambda, kk, 0, 0,
                       use_slab_x6(h->opt, side) ? (uint32_t)(h->rows(1 - side) * h->opt.factorsCount * 4) : 0u};
+    if (h->kPad) a.kReal = h->opt.factorsCount;
     DualPlan dp;
     dp.noX6 = (h->opt.flags & YCNR_FLAG_NO_BF16X6) != 0;
     if (dual_max_ratings(h->opt) > 0) {
@@ -1460,14 +1466,18 @@ int ycnr_als_step_async(ycnr_als *h, int side) {
   // c travel (on the communicator's stream) while piece c + 1 is being solved, and the step's
   // stream waits for the last piece to land -- the next half-step reads the whole matrix.
   if (h->kPad) {
-    for (int s = 0; s < 2; ++s) {
-      const int64_t n = h->rows(s) * h->kPad;
-      hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, (const float *)h->factors[s],
-                         h->padded[s], h->rows(s), h->opt.factorsCount, h->kPad);
-      HIP_TRY(hipGetLastError());
-    }
+    // only the FIXED side is read: the solved rows are written whole (x of a zero column is exactly 0) and
+    // copied back piece by piece (launch_part)
+    const int s = 1 - side;
+    const int64_t n = h->rows(s) * h->kPad;
+    hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, (const float *)h->factors[s],
+                       h->padded[s], h->rows(s), h->opt.factorsCount, h->kPad);
+    HIP_TRY(hipGetLastError());
   }
   const bool exchange = h->comm.active() && !h->bounds[side].empty();
+  if (exchange && h->bounds[side].size() != (size_t)h->comm.world * (parts.size() + 1))
+    return fail(YCNR_ERR_STATE, "step: the sharded upload of this side was made for another communicator (bounds of %zu values, world %d x %zu pieces)",
+                h->bounds[side].size(), h->comm.world, parts.size());
   h->exchangedInStep = exchange;
   memset(&h->info, 0, sizeof h->info);
   std::vector<int64_t> xb, xe;
@@ -1697,6 +1707,9 @@ int ycnr_als_comm_destroy(ycnr_als *h) {
   (void)hipSetDevice(h->opt.device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   comm_release(h->comm);
+  // exchange ranges belong to the communicator they were made for: a later ycnr_als_set_ratings[_sharded] renews them
+  h->bounds[0].clear();
+  h->bounds[1].clear();
   return YCNR_OK;
 }
 
@@ -1707,6 +1720,7 @@ int ycnr_als_exchange(ycnr_als *h, int side) {
   if (h->bounds[side].empty() || h->parts[side].empty()) return fail(YCNR_ERR_STATE, "exchange: no sharded upload for this side");
   HIP_TRY(hipSetDevice(h->opt.device));
   const int world = h->comm.world, np = (int)h->parts[side].size();
+  if (h->bounds[side].size() != (size_t)world * (size_t)(np + 1)) return fail(YCNR_ERR_STATE, "exchange: the sharded upload was made for another communicator");
   std::vector<int64_t> b((size_t)world), e((size_t)world);
   for (int r = 0; r < world; ++r) {
     b[(size_t)r] = h->bounds[side][(size_t)r * (np + 1)];
@@ -1910,6 +1924,14 @@ int64_t als_calc_portion(double lambda, int k, const int32_t *alsRows, const int
   L1Ctx &C = l1ctx();
   int rc = l1_prepare(C);
   if (rc) return rc;
+  // The reference's host updates its matrices in place: the matrix pinned for 'byUser' is the one 'byItem' writes.
+  // A portion that SOLVES into the pinned host range makes the device copy stale: drop the pin (the host pins
+  // again at its next 'startTrainStep'; until then portions upload the rows they need).
+  if (C.pinnedHost) {
+    const char *pb = (const char *)C.pinnedHost, *pe = pb + (size_t)C.pinnedRows * C.pinnedK * tsize(C.pinnedDtype);
+    const char *sb = (const char *)solvedFactors, *se = sb + (size_t)solvedRows * k * sizeof(T);
+    if (sb < pe && pb < se) C.pinnedHost = nullptr;
+  }
   const bool pinned = C.pinnedHost == fixedFactors && C.pinnedRows == fixedRows && C.pinnedK == k && C.pinnedDtype == dtype;
   // compact the referenced fixed rows unless the whole matrix is resident
   std::vector<int32_t> uniq, remap;  // remap: fixed row -> compacted row when the fixed side is small enough to mark
@@ -2071,6 +2093,10 @@ int ycnr_sAlsPinFixedFactors(const float *fixedFactors, int64_t fixedRows, int k
 }
 int ycnr_dAlsPinFixedFactors(const double *fixedFactors, int64_t fixedRows, int k) {
   return pin_fixed<double>(fixedFactors, fixedRows, k, YCNR_F64);
+}
+int ycnr_AlsUnpinFixedFactors(void) {
+  l1ctx().pinnedHost = nullptr;
+  return YCNR_OK;
 }
 int ycnr_AlsReleasePortionState(void) {
   l1ctx().release();

@@ -60,8 +60,8 @@ class EmfBase extends EventEmitter {
       // (reference: <repo>/data), GPU work-unit size (0 = library default), seed of the
       // initial factors (reference: unseeded)
       device: 0,
-      // multi-GPU (not in the reference, whose cluster is TCP, lib/emf/EmfLord.js:668-747): `gpus` > 1 makes
-      // train() fork one process per GPU (EmfLord.trainOnGpus); inside such a process `rank` / `world` /
+      // multi-GPU (not in the reference, whose cluster is TCP, lib/emf/EmfLord.js:668-747): `gpus` > 1 is what
+      // EmfLord.trainOnGpus() forks one process per GPU for (train() itself always drives ONE GPU); inside such a process `rank` / `world` /
       // `commId` / `commTransport` describe its place, and a large side is solved in `exchangeChunks`
       // pieces so that the exchange of one piece overlaps with the solve of the next
       gpus: 1,
@@ -70,6 +70,9 @@ class EmfBase extends EventEmitter {
       commId: null,
       commTransport: 'rccl', // 'rccl' | 'shm' (functional stand-in: several ranks on one GPU)
       exchangeChunks: 4,
+      gpuDevices: 0,            // devices the per-GPU processes are spread over (0 = what the library reports)
+      gpuProcessScript: null,   // entry point of a per-GPU process (default lib/emf/EmfGpuProcess.js)
+      gpuProcessTimeoutMs: 0,   // trainOnGpus gives up after this long (0 = no limit)
       dataDir: path.join(__dirname, '..', '..', 'data'),
       chunkRatings: 0,
       seed: 1,

@@ -178,26 +178,54 @@ class EmfLord extends EmfMaster {
     const world = this.options.gpus, transport = this.options.commTransport;
     if (!(world > 1)) return Promise.reject(new Error('trainOnGpus needs options.gpus > 1'));
     const commId = Buffer.from(als.native.commUniqueId(als.commTransport[transport])).toString('base64');
-    let devices = 1;
-    try { devices = als.native.deviceCount(); } catch (e) { return Promise.reject(e); }
+    let devices = this.options.gpuDevices || 0;  // 0: ask the library (fails loudly without a HIP device)
+    if (!devices) {
+      try { devices = als.native.deviceCount(); } catch (e) { return Promise.reject(e); }
+    }
     const kids = [];
     const stop = () => kids.forEach((k) => { try { k.send({ cmd: 'destroy' }); } catch (e) { /* already gone */ } });
+    // A GPU process that dies (non-zero code, or a signal: SIGSEGV, the OOM killer, a GPU fault report code === null)
+    // or cannot be started must end the whole train: its peers would otherwise wait for it inside the exchange.
+    let died = null;
+    const deaths = [];
+    const onDeath = (k, why) => {
+      if (died === null) died = new Error('GPU process of rank ' + kids.indexOf(k) + ' ' + why);
+      deaths.forEach((f) => f(died));
+    };
     const all = (evt, after) => Promise.all(kids.map((k) => new Promise((resolve, reject) => {
       const onMsg = (m) => {
         if (m.evt == evt) { k.removeListener('message', onMsg); resolve(m); }
         else if (m.evt == 'error') { k.removeListener('message', onMsg); reject(new Error(m.error)); }
       };
+      if (died !== null) return reject(died);
+      deaths.push(reject);
       k.on('message', onMsg);
-      k.once('exit', (code) => { if (code) reject(new Error('GPU process exited with code ' + code)); });
       after(k);
     })));
-    for (let r = 0; r < world; r++) kids.push(child_process.fork(path.join(__dirname, 'EmfGpuProcess.js'), [], { stdio: 'inherit' }));
+    for (let r = 0; r < world; r++) {
+      const k = child_process.fork(this.options.gpuProcessScript || path.join(__dirname, 'EmfGpuProcess.js'), [], { stdio: 'inherit' });
+      k.finished = false;
+      k.once('exit', (code, signal) => {
+        if (!k.finished && (code !== 0 || signal)) onDeath(k, signal ? 'was killed by ' + signal : 'exited with code ' + code);
+      });
+      k.once('error', (e) => onDeath(k, 'failed: ' + (e && e.message)));
+      kids.push(k);
+    }
     const opts = Object.assign({}, this.options, { gpus: 1 });
-    return all('ready', (k) => {
+    // no train runs longer than this without a message (options.gpuProcessTimeoutMs, 0 = no limit)
+    const limitMs = this.options.gpuProcessTimeoutMs || 0;
+    let timer = null;
+    const guarded = limitMs > 0 ? new Promise((_, reject) => {
+      timer = setTimeout(() => reject(new Error('trainOnGpus: no result within ' + limitMs + ' ms')), limitMs);
+    }) : null;
+    const run = all('ready', (k) => {
       const rank = kids.indexOf(k);
       k.send({ cmd: 'init', config: config || {}, options: opts, rank, world, commId, device: rank % devices, dataset: datasetSpec });
-    }).then(() => all('trained', (k) => k.send({ cmd: 'train' })))
-      .then((res) => { stop(); return res[0]; }, (e) => { stop(); kids.forEach((k) => k.kill()); return Promise.reject(e); });
+    }).then(() => all('trained', (k) => k.send({ cmd: 'train' })));
+    const done = (x) => { if (timer) clearTimeout(timer); kids.forEach((k) => { k.finished = true; }); return x; };
+    return (guarded ? Promise.race([run, guarded]) : run)
+      .then((res) => { done(); stop(); return res[0]; },
+            (e) => { done(); stop(); kids.forEach((k) => { try { k.kill('SIGKILL'); } catch (e2) { /* gone */ } }); return Promise.reject(e); });
   }
 
   /** 2 steps - first fix item vectors and calc user vectors, then vice versa (EmfLord.js:954-958) */

@@ -51,6 +51,9 @@
       native.sAlsPinFixedFactors(fixedFactors, factorsCount);
   };
 
+  /** Forget the pinned matrix.  A portion call that solves INTO the pinned typed array does this by itself. */
+  als.alsUnpinFixedFactors = function () { return native.alsUnpinFixedFactors(); };
+
   /**
    * Drop-in for EmfWorker.mw_calcRmsePortion (lib/emf/EmfWorker.js:266-315).
    * Returns {rSumDiff2, rCnt, rSum}.

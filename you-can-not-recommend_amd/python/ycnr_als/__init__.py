@@ -6,7 +6,7 @@ and the parity tests.  The NodeJS host lives in ../../lib/emf and ../../addon.
 """
 from . import _lib
 from ._lib import YcnrError
-from .trainer import (AlsDevice, als_calc_portion, pin_fixed_factors, release_portion_state, rmse_portion, split_to_sets,
+from .trainer import (AlsDevice, als_calc_portion, pin_fixed_factors, unpin_fixed_factors, release_portion_state, rmse_portion, split_to_sets,
                       rating_stats, recommend_items)
 
-__all__ = ["AlsDevice", "als_calc_portion", "pin_fixed_factors", "release_portion_state", "rmse_portion", "split_to_sets", "rating_stats", "recommend_items", "YcnrError", "_lib"]
+__all__ = ["AlsDevice", "als_calc_portion", "pin_fixed_factors", "unpin_fixed_factors", "release_portion_state", "rmse_portion", "split_to_sets", "rating_stats", "recommend_items", "YcnrError", "_lib"]

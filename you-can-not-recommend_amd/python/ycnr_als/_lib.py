@@ -24,7 +24,7 @@ FLAG_NO_OVERLAP = 64
 EXPORTS = [
     "ycnr_last_error", "ycnr_version", "ycnr_device_count",
     "ycnr_sAlsCalcPortion", "ycnr_dAlsCalcPortion", "ycnr_sRmsePortion", "ycnr_dRmsePortion",
-    "ycnr_sAlsPinFixedFactors", "ycnr_dAlsPinFixedFactors", "ycnr_AlsReleasePortionState",
+    "ycnr_sAlsPinFixedFactors", "ycnr_dAlsPinFixedFactors", "ycnr_AlsUnpinFixedFactors", "ycnr_AlsReleasePortionState",
     "ycnr_als_create", "ycnr_als_destroy", "ycnr_als_set_stream", "ycnr_als_set_ratings",
     "ycnr_als_set_rmse_ratings", "ycnr_als_set_factors", "ycnr_als_get_factors", "ycnr_als_factors_ptr",
     "ycnr_als_bind_factors", "ycnr_als_step", "ycnr_als_step_async", "ycnr_als_sync",
@@ -36,7 +36,7 @@ EXPORTS = [
 ]
 COMM_NONE, COMM_RCCL, COMM_SHM = 0, 1, 2
 COMM_ID_BYTES = 128
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class YcnrError(RuntimeError):
@@ -100,6 +100,8 @@ def load():
         f = getattr(L, f"ycnr_{p}AlsPinFixedFactors")
         f.restype = i32
         f.argtypes = [vp, i64, i32]
+    L.ycnr_AlsUnpinFixedFactors.restype = i32
+    L.ycnr_AlsUnpinFixedFactors.argtypes = []
     L.ycnr_AlsReleasePortionState.restype = i32
     L.ycnr_AlsReleasePortionState.argtypes = []
     L.ycnr_als_create.restype = i32
@@ -147,7 +149,7 @@ def load():
     L.ycnr_als_comm_destroy.restype = i32
     L.ycnr_als_comm_destroy.argtypes = [vp]
     L.ycnr_als_set_ratings_sharded.restype = i32
-    L.ycnr_als_set_ratings_sharded.argtypes = [vp, i32, vp, vp, vp, i32, i32, vp]
+    L.ycnr_als_set_ratings_sharded.argtypes = [vp, i32, vp, vp, vp, i32, i32, i32, vp]
     L.ycnr_als_exchange.restype = i32
     L.ycnr_als_exchange.argtypes = [vp, i32]
     L.ycnr_als_broadcast_factors.restype = i32

@@ -74,6 +74,11 @@ def pin_fixed_factors(fixedFactors, k):
     check(getattr(L, f"ycnr_{p}AlsPinFixedFactors")(fixedFactors.ctypes.data, fixedFactors.size // k, int(k)))
 
 
+def unpin_fixed_factors():
+    """Level 1: forget the pinned matrix (ycnr_AlsUnpinFixedFactors)."""
+    check(_lib.load().ycnr_AlsUnpinFixedFactors())
+
+
 def release_portion_state():
     check(_lib.load().ycnr_AlsReleasePortionState())
 
@@ -218,7 +223,7 @@ class AlsDevice:
         p2, k2 = _ptr_kind(vals, self.dtype)
         if not (k0 == k1 == k2):
             raise ValueError("rowPtr, indx and vals must live in the same kind of memory")
-        check(self._L.ycnr_als_set_ratings_sharded(self._h, SIDES[side], p0, p1, p2, k0, b.shape[1] - 1, b.ctypes.data))
+        check(self._L.ycnr_als_set_ratings_sharded(self._h, SIDES[side], p0, p1, p2, k0, b.shape[1] - 1, b.shape[0], b.ctypes.data))
 
     # -- multi-GPU exchange -----------------------------------------------------------
     @staticmethod
