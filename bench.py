@@ -70,8 +70,13 @@ def main():
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for functional tests)")
     ap.add_argument("--same-device", action="store_true",
                     help="functional test only: every rank uses cuda:0 (several ranks on one GPU, gloo)")
-    ap.add_argument("--transport", default="", choices=["", "rccl", "shm"],
-                    help="exchange transport inside libycnr_als.so for N > 1 (default: rccl; shm with --same-device / gloo)")
+    ap.add_argument("--transport", default="", choices=["", "rccl", "ipc", "shm"],
+                    help="exchange transport inside libycnr_als.so for N > 1 (default: rccl; shm with --same-device / gloo; "
+                         "ipc = mapped peer replicas + copy engines, also with several ranks on one GPU)")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="one GPU solves the shard of every rank of a world of this size in turn (exchange left out) and "
+                         "reports the compute time per rank, before and after the feedback re-cut of the shards")
+    ap.add_argument("--rebalance-after", type=int, default=1, help="N > 1: re-cut the shards from measured times after this many iterations (0 = never)")
     ap.add_argument("--exchange-chunks", type=int, default=4, help="pieces a large side's shard is solved in (exchange overlaps solve)")
     ap.add_argument("--dump-factors", default="", help="write the final factor matrices of rank 0 to this .npz")
     ap.add_argument("--debug-mod-idx", type=int, default=0,
@@ -102,6 +107,8 @@ def main():
 
     from ycnr_als.data import synth_ratings
     from ycnr_als.emf import Dataset, EmfLord
+    if args.emulate_world > 1:
+        return emulate_world(args, local_rank)
     users, items, nnz_target, k, max_rating, zipf_a, sigma, desc = WORKLOADS[args.workload]
     dev = torch.device("cuda", local_rank)
     t0 = time.time()
@@ -122,7 +129,7 @@ def main():
     ds = Dataset(by_user, by_item, validate=val, test=None, total_ratings_avg=float(by_user.vals.double().mean()))
     lord = EmfLord(options={"factorsCount": k, "trainIters": args.steps, "useDoublePrecision": args.double,
                             "dbType": "mal" if max_rating == 10 else "ml", "chunkRatings": args.chunk,
-                            "dataSetDistr": [90, 10, 0], "exchangeChunks": args.exchange_chunks,
+                            "dataSetDistr": [90, 10, 0], "exchangeChunks": args.exchange_chunks, "rebalanceAfterIters": args.rebalance_after,
                             "commTransport": args.transport or ("shm" if args.same_device or args.backend == "gloo" else "rccl")},
                     dist=dist)
     lord.prepareToTrain(ds, seed=20260004, device=local_rank)
@@ -267,6 +274,11 @@ def main():
         "iteration": {"kernel_ms_per_step": round(tot_ms / args.steps, 3),
                       "mfma_frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / peak, 4) if tot_ms else 0.0,
                       "hbm_frac": round(tot_by / (tot_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if tot_ms else 0.0,
+                      # SURVEY.md 8d's secondary figure: minimum-flop model (symmetric Gramian + Cholesky) of the whole
+                      # iteration / wall time / fp32 (fp64) peak -- above ~0.5 means the iteration exists only because
+                      # the Gramian left the fp32 pipe
+                      "flops_min_frac_of_fp32_peak": round(sum(algorithmic_flops(st["info"].ratings, st["info"].rows, k) for st in lord.stepTimes)
+                                                           / args.steps / (ms_per_step * 1e-3) / 1e12 / peak / world, 4),
                       "hbm_roof_ratings_per_s": round(PEAK_HBM_GBS * 1e9 / (2 * bytes_rating)),
                       "frac_of_hbm_roof_ratings_per_s": round(value / world / (PEAK_HBM_GBS * 1e9 / (2 * bytes_rating)), 4),
                       "byUser_ms": round(step_ms["byUser"] / args.steps, 3),
@@ -275,6 +287,7 @@ def main():
     if dom in traffic:
         roofline["traffic"] = traffic[dom]["hbm_bytes_per_launch"]
         roofline["traffic_source"] = tj.get("sources", {}).get(args.workload + ("_f64" if args.double else ""), "profiles/traffic.json")
+        roofline["traffic_measured_at_commit"] = tj.get("commits", {}).get(args.workload + ("_f64" if args.double else ""), tj.get("commit", "unknown"))
         roofline["traffic_over_algorithmic"] = round(traffic[dom]["hbm_bytes_per_launch"] / (kern[dom]["bytes"] / kern[dom]["launches"]), 3)
         roofline["traffic_frac_of_hbm_peak"] = round(mem_frac, 4)
 
@@ -288,10 +301,20 @@ def main():
                         "exposed_exchange_ms": round(c["exposed_exchange_ms"] / n, 4), "wall_ms": round(c["wall_ms"] / n, 4),
                         "bytes": int(c["bytes"] // n), "pieces": c["pieces"]}
     if dist:
+        # every replica must hold the same bytes after the last exchange: a checksum of both matrices per rank
+        sums = []
+        for side in (0, 1):
+            f = lord.backend.factors(side)
+            sums.append(int(f.view(torch.int32 if f.dtype == torch.float32 else torch.int64).to(torch.int64).sum().item()))
         per_rank = [None] * world
-        dist.all_gather_object(per_rank, {sd: exchange[sd]["compute_ms"] for sd in ("byUser", "byItem")})
+        dist.all_gather_object(per_rank, {"sums": sums, **{sd: exchange[sd]["compute_ms"] for sd in ("byUser", "byItem")}})
         for sd in ("byUser", "byItem"):
             exchange[sd]["compute_ms_by_rank"] = [r[sd] for r in per_rank]
+        exchange["replicas_consistent"] = all(r["sums"] == per_rank[0]["sums"] for r in per_rank)
+        if lord.rebalanced:
+            exchange["rebalanced_after_iter"] = args.rebalance_after
+            exchange["before_rebalance_ms_by_rank"] = {("byUser", "byItem")[sd]: [round(x, 4) for x in v["ms_by_rank"]]
+                                                       for sd, v in lord.rebalanced.items()}
 
     rmse = lord.calcRmse("rmseValidate", False)
     if args.dump_factors and rank == 0:
@@ -318,6 +341,93 @@ def main():
     lord.destroy()
     if dist:
         dist.destroy_process_group()
+
+
+class EmulatedDist:
+    """What EmfLord asks of torch.distributed, for ONE process that plays rank `rank` of `world` (--emulate-world)."""
+
+    def __init__(self, rank, world):
+        self.rank, self.world = rank, world
+
+    def get_rank(self):
+        return self.rank
+
+    def get_world_size(self):
+        return self.world
+
+    def broadcast_object_list(self, box, src=0):
+        if box[0] is None:
+            box[0] = bytes(128)  # the stub transport's id carries nothing
+
+    def all_gather_object(self, out, obj):
+        for i in range(len(out)):
+            out[i] = obj
+
+    def all_reduce(self, t, op=None):
+        return t
+
+    def barrier(self):
+        pass
+
+
+def emulate_world(args, local_rank):
+    """--emulate-world W: the shard of every rank of a W-GPU run, solved on ONE GPU one rank after the other with
+    the full fixed matrices and the real pieces (exchange left out: transport 'stub'), first with the cost-model
+    cut of the shards, then with the cut the feedback (EmfLord.rebalance -> rebalanced_ranges) derives from the
+    measured times.  Prints one JSON line: compute ms per rank and half-step, the imbalance max / mean, the
+    launch overhead of the pieces, and what the slowest rank implies for the W-GPU iteration."""
+    from ycnr_als.data import synth_ratings
+    from ycnr_als.emf import Dataset, EmfLord, rebalanced_ranges
+    W = args.emulate_world
+    users, items, nnz_target, k, max_rating, zipf_a, sigma, desc = WORKLOADS[args.workload]
+    dev = torch.device("cuda", local_rank)
+    tdt = torch.float64 if args.double else torch.float32
+    by_user, by_item = synth_ratings(users, items, nnz_target, max_rating=max_rating, seed=20260004, device=dev, dtype=tdt,
+                                     degree_sigma=sigma, zipf_a=zipf_a)
+    ds = Dataset(by_user, by_item, validate=None, test=None, total_ratings_avg=float(by_user.vals[: 1 << 24].double().mean()))
+    cnt = {0: by_user.counts().cpu().numpy(), 1: by_item.counts().cpu().numpy()}
+    names = ("byUser", "byItem")
+
+    def run(shards):
+        per = {n: {"compute_ms": [], "wall_ms": [], "pieces": 0, "exchange_bytes": []} for n in names}
+        used = None
+        for r in range(W):
+            lord = EmfLord(options={"factorsCount": k, "trainIters": args.steps, "useDoublePrecision": args.double,
+                                    "dbType": "mal" if max_rating == 10 else "ml", "chunkRatings": args.chunk, "dataSetDistr": [100, 0, 0],
+                                    "exchangeChunks": args.exchange_chunks, "commTransport": "stub", "rebalanceAfterIters": 0},
+                            dist=EmulatedDist(r, W))
+            lord.prepareToTrain(ds, seed=20260004, device=local_rank, shards=shards)
+            used = {s: np.asarray(lord.shards[s]).tolist() for s in (0, 1)}
+            for _ in range(max(args.warmup, 1)):
+                lord.alsTrainIter()
+            lord.stepTimes.clear()
+            for _ in range(args.steps):
+                lord.alsTrainIter()
+            for n in names:
+                st = [s for s in lord.stepTimes if s["stepType"] == n]
+                per[n]["compute_ms"].append(round(float(np.mean([s["info"].totalMs for s in st])), 4))
+                per[n]["wall_ms"].append(round(float(np.mean([s["wall"] for s in st])) * 1e3, 4))
+                per[n]["pieces"] = int(st[0]["info"].parts)
+                per[n]["exchange_bytes"].append(int(st[0]["info"].exchangeBytes))
+            lord.destroy()
+            del lord
+            torch.cuda.empty_cache()
+        for n in names:
+            c = np.asarray(per[n]["compute_ms"])
+            per[n]["imbalance_max_over_mean"] = round(float(c.max() / c.mean()), 4)
+            per[n]["launch_overhead_ms"] = round(float(np.mean(np.asarray(per[n]["wall_ms"]) - c)), 4)
+        per["iteration_ms_slowest_rank"] = round(max(per["byUser"]["wall_ms"]) + max(per["byItem"]["wall_ms"]), 4)
+        return per, used
+
+    first, shards0 = run(None)
+    new = {s: rebalanced_ranges(cnt[s], shards0[s], first[names[s]]["compute_ms"], k, args.double) for s in (0, 1)}
+    second, shards1 = run(new)
+    out = {"emulated_world": W, "workload": desc, "factorsCount": k, "dtype": "f64" if args.double else "f32", "steps": args.steps,
+           "note": "one GPU solves every rank's shard in turn: full fixed matrices, real pieces, exchange left out (transport 'stub'); "
+                   "iteration_ms_slowest_rank = what the W-GPU iteration costs before any exposed exchange",
+           "cost_model_cut": first, "after_feedback_recut": second,
+           "shards": {"cost_model": shards0, "feedback": shards1}}
+    print(json.dumps(out), flush=True)
 
 
 def host_cpus():

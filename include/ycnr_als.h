@@ -249,7 +249,7 @@ int ycnr_als_last_step_info(ycnr_als *h, ycnr_als_step_info *info);
  *       EmfLord.js:738-740)                                     -> ycnr_als_broadcast_factors
  *   'rmseSaveCalcs' partial sums to the Lord (EmfMaster.js:726-736, EmfLord.js:734-736)
  *                                                               -> ycnr_als_allreduce_sum
- * Transports: YCNR_COMM_RCCL is the product path -- one group of point-to-point ncclSend / ncclRecv
+ * Transports (YCNR_COMM_IPC and YCNR_COMM_STUB are described at their definitions): YCNR_COMM_RCCL is the product path -- one group of point-to-point ncclSend / ncclRecv
  * between all pairs of ranks straight into the replicated matrix at each shard's row offset (xGMI
  * is a point-to-point mesh: every link carries only what its two ends owe each other, all links at
  * once; uneven shards need no padding or staging).  YCNR_COMM_SHM is a functional stand-in for
@@ -262,6 +262,15 @@ int ycnr_als_last_step_info(ycnr_als *h, ycnr_als_step_info *info);
 #define YCNR_COMM_NONE 0
 #define YCNR_COMM_RCCL 1
 #define YCNR_COMM_SHM 2
+/* device-to-device without RCCL: peers' replicas mapped with hipIpcOpenMemHandle (handles through a shared-memory
+ * control segment), solved rows pushed with hipMemcpyAsync on the communicator's stream (copy engines, no
+ * compute units), one host barrier at the end of each half-step.  Works with several ranks on one device.
+ * Bind the factor matrices (ycnr_als_bind_factors) before ycnr_als_comm_init or before the collective
+ * ycnr_als_set_ratings_sharded, on every rank alike. */
+#define YCNR_COMM_IPC 3
+/* rank r of a world of N with the exchange left out (timing events only): one GPU can solve every rank's shard
+ * in turn and report the compute time per rank (bench.py --emulate-world) */
+#define YCNR_COMM_STUB 4
 #define YCNR_COMM_ID_BYTES 128
 int ycnr_comm_unique_id(int transport, void *id128);
 int ycnr_als_comm_init(ycnr_als *h, int transport, const void *id128, int rank, int world);

@@ -5,8 +5,10 @@ One GPU cannot show scaling, but it can show that the code the 8-GPU run depends
     pair and an all-reduce run on hardware (world size 1), and train() end to end under
     torch.distributed's nccl backend;
   * the sharded, pipelined half-step: pieces + exchange ranges give bit-identical factors;
-  * the shared-memory stand-in (several ranks on one GPU): exchange, broadcast and all-reduce between
-    real processes, against the single-process result bit for bit.
+  * several ranks on one GPU, between real processes, against the single-process result bit for bit: the
+    host-staged stand-in ('shm') and the device-to-device transport ('ipc': mapped peer replicas, rows pushed
+    by hipMemcpyAsync on the communicator's stream, piece by piece behind the kernels);
+  * two ranks on two devices over 'rccl' and 'ipc' when the box has them (the scaling job's node does).
 """
 import multiprocessing as mp
 import os
@@ -121,12 +123,13 @@ def test_train_under_the_nccl_backend(als):
     assert q.get(timeout=5) is True
 
 
-def _shm_rank(rank, world, uid, pieces, out):
+def _rank_main(rank, world, uid, pieces, out, transport="shm", device=0):
     import ycnr_als as als
     k, users, items, bu, bi, U, V = problem()
-    dev = als.AlsDevice(k, users, items)
-    dev.comm_init(uid, rank, world, "shm")
-    dev.comm_selftest(1024)
+    dev = als.AlsDevice(k, users, items, device=device)
+    dev.comm_init(uid, rank, world, transport)
+    if transport != "ipc":
+        dev.comm_selftest(1024)
     cut = lambda n, parts: np.linspace(0, n, parts + 1).astype(np.int64)
     us, its = cut(users, world), cut(items, world)
     ub = np.stack([us[r] + cut(us[r + 1] - us[r], pieces) for r in range(world)])
@@ -145,14 +148,18 @@ def _shm_rank(rank, world, uid, pieces, out):
     out.put((rank, got, s.tolist(), int(iu.parts), int(iu.exchangeBytes), int(ii.exchangeBytes)))
 
 
-@pytest.mark.parametrize("world,pieces", [(2, 1), (3, 4)])
-def test_shared_memory_ranks_on_one_gpu(als, world, pieces):
+@pytest.mark.parametrize("transport,world,pieces", [("shm", 2, 1), ("shm", 3, 4), ("ipc", 2, 1), ("ipc", 3, 4)])
+def test_ranks_of_one_node_on_one_gpu(als, transport, world, pieces):
+    """Several ranks sharing cuda:0: 'shm' stages rows through the host, 'ipc' is the device-to-device path -- every
+    rank maps its peers' replicas (hipIpcOpenMemHandle) and pushes its solved rows into them piece by piece on
+    the communicator's stream, behind the kernels that produced them.  Exchange, join-time broadcast and
+    all-reduce between real processes, against the single-process result bit for bit."""
     k, users, items, bu, bi, U, V = problem()
     U1, V1 = reference_iteration(als, k, users, items, bu, bi, U, V)
-    uid = als.AlsDevice.comm_unique_id("shm")
+    uid = als.AlsDevice.comm_unique_id(transport)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_shm_rank, args=(r, world, uid, pieces, q)) for r in range(world)]
+    procs = [ctx.Process(target=_rank_main, args=(r, world, uid, pieces, q, transport)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in procs]
@@ -163,3 +170,28 @@ def test_shared_memory_ranks_on_one_gpu(als, world, pieces):
         assert np.array_equal(Ug, U1) and np.array_equal(Vg, V1), f"rank {rank}: replicas differ from the single-process run"
         assert s == [world * (world + 1) / 2, float(bu.nnz)]
         assert parts == pieces and xu > 0 and xi > 0
+
+
+@pytest.mark.parametrize("transport", ["rccl", "ipc"])
+def test_two_ranks_on_two_gpus(als, transport):
+    """The product transports between two DEVICES (skipped on the one-GPU boxes; the scaling job's node has
+    eight): grouped ncclSend / ncclRecv into the live matrix, and the mapped-replica pushes, pipelined per piece,
+    against the single-process result bit for bit."""
+    L = als._lib.load()
+    if L.ycnr_device_count() < 2:
+        pytest.skip("needs two visible devices")
+    k, users, items, bu, bi, U, V = problem()
+    U1, V1 = reference_iteration(als, k, users, items, bu, bi, U, V)
+    uid = als.AlsDevice.comm_unique_id(transport)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, uid, 3, q, transport, r)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, (Ug, Vg), s, parts, xu, xi in res:
+        assert np.array_equal(Ug, U1) and np.array_equal(Vg, V1), f"rank {rank}: replicas differ from the single-process run"
+        assert parts == 3 and xu > 0 and xi > 0

@@ -1,11 +1,18 @@
-"""BASELINE.json's configurations C2, C3 and C5 (one GPU's shard) through the HIP path.
+"""BASELINE.json's configurations C2, C3 and C5 (whole, and one GPU's shard) through the HIP path, and the k = 100
+regimes of fixed matrices beyond 2 GB and 4 GB.
 
   C2  MovieLens-1M shape (6040 x 3883, ~1 M ratings), k = 100, 10 ALS iterations, float32 and
       float64, next to the CPU oracle run the same way through the same host classes
       (/root/reference README.md:118-129 is the configuration; lib/emf/EmfWorker.js:169-261 the path).
   C3  200 K x 20 K, 20 M ratings, k = 64 at full size: one iteration; oracle on a row sample of
       every length class + size-independent properties (normal equations, linearity).
-  C5  one GPU's eighth of 10 M x 100 K, 1 B ratings, k = 256 (1.25 M x 100 K, 125 M ratings): the same.
+  C5  10 M x 100 K, 1 B ratings, k = 256 at FULL size on one GPU (10.24 GB of user factors: 64-bit addressing on the
+      item side, index arrays past 2^31 bytes), and one GPU's eighth of it (1.25 M x 100 K, 125 M ratings): the same.
+      Rows beyond 400 K ratings are too slow for the CPU oracle (an item of the full C5 has up to ~10 M): they are
+      held to the float64 normal equations on the device instead.
+  big2g / big4g  k = 100 with 6 M / 11 M users (2.4 GB / 4.4 GB of user factors): the item side leaves the LDS-DMA
+      bf16x6 kernels (32-bit buffer offsets) for the float32-MFMA chunk kernel, its short rows the four-rows-per-wave
+      kernel (32-bit offsets); item rows of every length class, 1 ... 500 K ratings.
 
 Tolerances.  float64: every row within 1e-5 (relative, 2-norm) of the float64 oracle, RMSE within 1e-6
 (observed ~1e-12).  float32: the north star's flat 1e-5 is REPORTED as the fraction of rows that meet
@@ -121,7 +128,38 @@ CONFIGS = {
     # users, items, nnz, k, max_rating, zipf_a, degree_sigma   (bench.py WORKLOADS)
     "c3": (200_000, 20_000, 20_000_000, 64, 10, 0.8, 1.0),
     "c5shard": (1_250_000, 100_000, 125_000_000, 256, 10, 0.7, 1.0),
+    "c5": (10_000_000, 100_000, 1_000_000_000, 256, 10, 0.7, 1.0),
+    # nnz = None: item rows of prescribed lengths (ratings_by_item_lengths), users spread over the whole matrix
+    "big2g": (6_000_000, 12_700, None, 100, 10, 0, 0),
+    "big4g": (11_000_000, 12_700, None, 100, 10, 0, 0),
 }
+ORACLE_ROW_CAP = 400_000  # longer rows: float64 normal equations on the device instead of the CPU oracle
+
+
+def ratings_by_item_lengths(torch, users, items, seed, dev):
+    """By-item rows of every length class -- thirds of 1..100, 100..3000 and 3000..30000 ratings, three rows of
+    500 K -- with user ids uniform over ALL users (a fixed matrix beyond 2 / 4 GB is gathered from end to end),
+    and the same ratings by user.  Integer ratings 1..10."""
+    from ycnr_als.data import Csr, csr_from_coo
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    third = items // 3
+    lens = torch.cat([torch.randint(1, 101, (third,), generator=g, device=dev),
+                      torch.randint(100, 3001, (third,), generator=g, device=dev),
+                      torch.randint(3000, 30001, (items - 2 * third,), generator=g, device=dev)])
+    lens = lens[torch.randperm(items, generator=g, device=dev)]
+    lens[:3] = 500_000
+    item = torch.repeat_interleave(torch.arange(items, device=dev, dtype=torch.int64), lens)
+    user = torch.randint(0, users, (int(lens.sum()),), generator=g, device=dev, dtype=torch.int64)
+    key = torch.unique(item * users + user)  # sorted by (item, user), duplicate pairs dropped
+    item, user = key // users, key % users
+    del key
+    vals = torch.randint(1, 11, (item.numel(),), generator=g, device=dev).to(torch.float32)
+    ptr = torch.zeros(items + 1, dtype=torch.int64, device=dev)
+    ptr[1:] = torch.cumsum(torch.bincount(item, minlength=items), 0)
+    by_item = Csr(items, users, ptr, user.to(torch.int32).contiguous(), vals)
+    by_user = csr_from_coo(users, items, user, item, vals)
+    return by_user, by_item
 
 
 def sample_by_class(lens, per_class, longest, seed, dual_max, chunk):
@@ -183,25 +221,32 @@ def backward_errors(torch, csr, vals, fixed, solved, rows, k):
     out = []
     for r in rows.tolist():
         b0, e0 = int(csr.rowPtr[r]), int(csr.rowPtr[r + 1])
-        Y = fixed[csr.indx[b0:e0].long()].double()
-        A = Y.T @ Y + LAM * (e0 - b0) * torch.eye(k, dtype=torch.float64, device=Y.device)
-        b = Y.T @ vals[b0:e0].double()
+        A = LAM * (e0 - b0) * torch.eye(k, dtype=torch.float64, device=fixed.device)
+        b = torch.zeros(k, dtype=torch.float64, device=fixed.device)
+        for c0 in range(b0, e0, 1 << 20):  # in slices: a row of the full C5 gathers up to 10 M x 256 doubles
+            c1 = min(e0, c0 + (1 << 20))
+            Y = fixed[csr.indx[c0:c1].long()].double()
+            A += Y.T @ Y
+            b += Y.T @ vals[c0:c1].double()
         x = solved[r].double()
         out.append(float(torch.linalg.norm(A @ x - b) / (torch.linalg.norm(A) * torch.linalg.norm(x) + torch.linalg.norm(b))))
     return np.array(out)
 
 
-@pytest.mark.parametrize("name", ["c3", "c5shard"])
+@pytest.mark.parametrize("name", ["c3", "c5shard", "big2g", "big4g", "c5"])
 def test_full_size_iteration(als, oracle, name):
     import torch
     from ycnr_als.data import synth_ratings
     users, items, nnz, k, max_rating, zipf_a, sigma = CONFIGS[name]
     dev = torch.device("cuda", 0)
-    bu, bi = synth_ratings(users, items, nnz, max_rating=max_rating, seed=20260004, device=dev,
-                           degree_sigma=sigma, zipf_a=zipf_a)
+    if nnz is None:
+        bu, bi = ratings_by_item_lengths(torch, users, items, 20260009, dev)
+    else:
+        bu, bi = synth_ratings(users, items, nnz, max_rating=max_rating, seed=20260004, device=dev,
+                               degree_sigma=sigma, zipf_a=zipf_a)
+    torch.cuda.empty_cache()
     g = torch.Generator(device=dev)
     g.manual_seed(21)
-    U0 = torch.randn(users, k, generator=g, device=dev) / k ** 0.5
     V0 = torch.randn(items, k, generator=g, device=dev) / k ** 0.5
     U, V = torch.full((users, k), 7.0, device=dev), V0.clone()
     h = als.AlsDevice(k, users, items, userFactReg=LAM, itemFactReg=LAM)
@@ -222,9 +267,15 @@ def test_full_size_iteration(als, oracle, name):
         assert bool((U1[lu == 0] == 7.0).all())  # rows without ratings untouched
     rec = {"config": name, "k": k, "nnz": bu.nnz, "byUser_ms": iu.totalMs, "byItem_ms": ii.totalMs,
            "splitRows": [int(iu.splitRows), int(ii.splitRows)], "dualRows": [int(iu.dualRows), int(ii.dualRows)]}
-    dual_max = 160 if k > 128 else 96
-    ru = sample_by_class(lu.cpu().numpy(), 60 if k <= 128 else 24, 8, 5, dual_max, 1024)
-    ri = sample_by_class(li.cpu().numpy(), 40 if k <= 128 else 12, 4, 6, dual_max, 1024)
+    # one sampling bucket per dual-form class of the library (16-rating blocks up to 176 ratings for k > 128, up to 80
+    # below; als_dual_quad for <= 16), whole rows, split rows, the longest rows
+    dual_max = 176 if k > 128 else 80
+    lun, lin = lu.cpu().numpy(), li.cpu().numpy()
+    ru = sample_by_class(lun, 60 if k <= 128 else 24, 8, 5, dual_max, 1024)
+    ri = sample_by_class(lin, 40 if k <= 128 else 12, 4, 6, dual_max, 1024)
+    ru, ri = ru[lun[ru] <= ORACLE_ROW_CAP], ri[lin[ri] <= ORACLE_ROW_CAP]
+    rec["classes_sampled"] = {"byUser_blocks": sorted(set(np.minimum((lun[ru] + 15) // 16, 12).tolist())),
+                              "byItem_blocks": sorted(set(np.minimum((lin[ri] + 15) // 16, 12).tolist()))}
     check_sample(oracle, torch, bu, ru, V0, U1, k, "byUser_sample", rec)
     check_sample(oracle, torch, bi, ri, U1, V, k, "byItem_sample", rec)
     # normal equations in float64 on other rows of every class
@@ -245,10 +296,13 @@ def test_full_size_iteration(als, oracle, name):
         xs.append(X)
     h.destroy()
     x1, x2, x3 = xs
-    diff = torch.linalg.norm((x3 - x1 - 2.0 * x2).double(), dim=1)
-    scale = (torch.linalg.norm(x1.double(), dim=1) + 2.0 * torch.linalg.norm(x2.double(), dim=1)
-             + torch.linalg.norm(x3.double(), dim=1))
-    ratio = torch.where(lu == 0, torch.zeros_like(diff), diff / scale.clamp_min(1e-30))
+    ratio = torch.zeros(users, dtype=torch.float64, device=dev)
+    for r0 in range(0, users, 1 << 20):  # in slices: the float64 temporaries of 10 M x 256 rows would be 20 GB each
+        sl = slice(r0, min(users, r0 + (1 << 20)))
+        a, b2, c3 = x1[sl].double(), x2[sl].double(), x3[sl].double()
+        diff = torch.linalg.norm(c3 - a - 2.0 * b2, dim=1)
+        scale = torch.linalg.norm(a, dim=1) + 2.0 * torch.linalg.norm(b2, dim=1) + torch.linalg.norm(c3, dim=1)
+        ratio[sl] = torch.where(lu[sl] == 0, torch.zeros_like(diff), diff / scale.clamp_min(1e-30))
     assert bool(torch.isfinite(ratio).all())
     rec["linearity_worst"] = float(ratio.max())
     report(rec)

@@ -20,6 +20,16 @@
 //   YCNR_COMM_SHM   functional stand-in for tests: ranks on ONE node stage their rows through a POSIX
 //                   shared-memory segment (synchronous, host barriers).  It exists so that several
 //                   ranks can share one GPU (RCCL refuses duplicate devices) -- what gloo is to nccl.
+//   YCNR_COMM_IPC   device-to-device without RCCL: every rank maps its peers' replicas (hipIpcOpenMemHandle;
+//                   the handles travel through the same shared-memory segment, which is its control plane)
+//                   and PUSHES its solved rows into them with hipMemcpyAsync on the communicator's stream --
+//                   copy engines over xGMI, no compute units taken from the solve -- piece by piece behind
+//                   the kernels that produced them; one host barrier at the end of the half-step says
+//                   "every push has landed everywhere".  Unlike RCCL it runs with several ranks on one
+//                   device, so the pipelined path (events, piece overlap, exposed-exchange accounting) is
+//                   covered by the one-GPU tests.
+//   YCNR_COMM_STUB  rank r of a world of N with the exchange left out: one GPU solves the shard of every
+//                   rank in turn (bench.py --emulate-world), which gives the compute time per rank.
 #pragma once
 #include <rccl/rccl.h>
 
@@ -112,6 +122,14 @@ struct Comm {
   ShmHeader *hdr = nullptr;
   char *data = nullptr;
   size_t dataBytes = 0, mapBytes = 0;
+  // IPC: peers' replicas of both factor matrices, mapped into this process
+  struct IpcPeer {
+    void *base[2] = {nullptr, nullptr};  // what hipIpcOpenMemHandle returned (closed with the communicator)
+    char *fac[2] = {nullptr, nullptr};   // the peer's matrix of each side
+  };
+  std::vector<IpcPeer> peers;
+  const void *mapped[2] = {nullptr, nullptr};  // this rank's matrices as the peers know them (re-published when rebound)
+  bool pendingFinish = false;                 // pushes enqueued since the last end-of-step barrier
 
   bool active() const { return transport != YCNR_COMM_NONE && world > 1; }
 };
@@ -134,7 +152,21 @@ int shm_barrier(Comm &c) {
   return YCNR_OK;
 }
 
+void ipc_close_peers(Comm &c) {
+  for (Comm::IpcPeer &p : c.peers)
+    for (int s = 0; s < 2; ++s) {
+      if (p.base[s]) (void)hipIpcCloseMemHandle(p.base[s]);
+      p.base[s] = nullptr;
+      p.fac[s] = nullptr;
+    }
+  c.mapped[0] = c.mapped[1] = nullptr;
+}
+
 void comm_release(Comm &c) {
+  if (c.stream) (void)hipStreamSynchronize(c.stream);
+  ipc_close_peers(c);
+  c.peers.clear();
+  c.pendingFinish = false;
   if (c.nccl && c.api) (void)c.api->CommDestroy(c.nccl);
   c.nccl = nullptr;
   if (c.dScratch) (void)hipFree(c.dScratch);
@@ -170,7 +202,13 @@ int comm_setup(Comm &c, const void *id, int transport, int rank, int world, size
     c.transport = YCNR_COMM_RCCL;
     return YCNR_OK;
   }
-  if (transport == YCNR_COMM_SHM) {
+  if (transport == YCNR_COMM_STUB) {
+    c.transport = YCNR_COMM_STUB;
+    return YCNR_OK;
+  }
+  if (transport == YCNR_COMM_SHM || transport == YCNR_COMM_IPC) {
+    // (IPC: the segment is the control plane -- handles and barriers -- and carries the all-reduce / broadcast)
+    if (transport == YCNR_COMM_IPC) dataBytes = std::max<size_t>((size_t)16 << 20, (size_t)world * 256);
     const unsigned char *b = (const unsigned char *)id;
     snprintf(c.name, sizeof c.name, "/ycnr_%02x%02x%02x%02x%02x%02x%02x%02x%02x%02x%02x%02x", b[0], b[1], b[2], b[3], b[4], b[5], b[6],
              b[7], b[8], b[9], b[10], b[11]);
@@ -183,7 +221,8 @@ int comm_setup(Comm &c, const void *id, int transport, int rank, int world, size
     if (p == MAP_FAILED) return fail(YCNR_ERR_NOMEM, "mmap(%s, %zu) failed: %s", c.name, c.mapBytes, strerror(errno));
     c.hdr = (ShmHeader *)p;
     c.data = (char *)p + sizeof(ShmHeader);
-    c.transport = YCNR_COMM_SHM;
+    c.transport = transport;
+    if (transport == YCNR_COMM_IPC) c.peers.assign((size_t)world, Comm::IpcPeer());
     // the name can go once everybody has mapped the segment
     c.hdr->attached.fetch_add(1, std::memory_order_acq_rel);
     int rc = shm_barrier(c);
@@ -194,11 +233,75 @@ int comm_setup(Comm &c, const void *id, int transport, int rank, int world, size
   return fail(YCNR_ERR_INVALID, "comm_init: unknown transport %d", transport);
 }
 
+// IPC: every rank publishes the handle of the allocation its two matrices live in (and their offsets inside it:
+// a matrix may be a slice of a caching allocator's block) and maps its peers'.  Collective; called when a
+// matrix has been (re)bound since the last publication.
+struct IpcSlot {
+  hipIpcMemHandle_t handle[2];
+  uint64_t offset[2];
+  int32_t device, pad;
+};
+int ipc_publish(Comm &c, void *const fac[2]) {
+  if ((size_t)c.world * sizeof(IpcSlot) > c.dataBytes) return fail(YCNR_ERR_STATE, "ipc: control segment too small for %d ranks", c.world);
+  if (c.stream) HIP_TRY(hipStreamSynchronize(c.stream));
+  ipc_close_peers(c);
+  IpcSlot mine;
+  memset(&mine, 0, sizeof mine);
+  HIP_TRY(hipGetDevice(&mine.device));
+  for (int s = 0; s < 2; ++s) {
+    hipDeviceptr_t base = nullptr;
+    size_t size = 0;
+    HIP_TRY(hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)fac[s]));
+    HIP_TRY(hipIpcGetMemHandle(&mine.handle[s], (void *)base));
+    mine.offset[s] = (uint64_t)((const char *)fac[s] - (const char *)base);
+  }
+  IpcSlot *slots = (IpcSlot *)c.data;
+  memcpy(&slots[c.rank], &mine, sizeof mine);
+  int rc = shm_barrier(c);
+  if (rc) return rc;
+  for (int p = 0; p < c.world; ++p) {
+    if (p == c.rank) continue;
+    IpcSlot theirs;
+    memcpy(&theirs, &slots[p], sizeof theirs);
+    for (int s = 0; s < 2; ++s) {
+      // both matrices of a peer may sit in ONE allocation (two slices of one block): map it once
+      if (s == 1 && memcmp(&theirs.handle[0], &theirs.handle[1], sizeof(hipIpcMemHandle_t)) == 0) {
+        c.peers[(size_t)p].fac[1] = (char *)c.peers[(size_t)p].base[0] + theirs.offset[1];
+        continue;
+      }
+      void *base = nullptr;
+      hipError_t e = hipIpcOpenMemHandle(&base, theirs.handle[s], hipIpcMemLazyEnablePeerAccess);
+      if (e != hipSuccess) {
+        (void)hipGetLastError();
+        (void)shm_barrier(c);  // keep the ranks in step: everybody leaves through the second barrier
+        return fail(YCNR_ERR_HIP, "ipc: hipIpcOpenMemHandle of rank %d's matrix %d failed: %s", p, s, hipGetErrorString(e));
+      }
+      c.peers[(size_t)p].base[s] = base;
+      c.peers[(size_t)p].fac[s] = (char *)base + theirs.offset[s];
+    }
+  }
+  rc = shm_barrier(c);  // the slots may be overwritten again
+  if (rc) return rc;
+  c.mapped[0] = fac[0];
+  c.mapped[1] = fac[1];
+  return YCNR_OK;
+}
+
+// IPC, end of a half-step: this rank's pushes have drained, then everybody's have (host barrier)
+int ipc_finish(Comm &c) {
+  if (c.transport != YCNR_COMM_IPC || !c.pendingFinish) return YCNR_OK;
+  c.pendingFinish = false;
+  HIP_TRY(hipStreamSynchronize(c.stream));
+  return shm_barrier(c);
+}
+
 // Rows [begin[r], end[r]) of `fac` ([rows x k] elements of ts bytes) are current on rank r; bring
 // every replica up to date.  `ready` has been recorded on the compute stream after the kernels
 // that produced this rank's rows.  RCCL: enqueued on c.stream (returns at once; `done` is recorded
 // behind it); SHM: synchronous.
-int comm_exchange(Comm &c, void *fac, int64_t k, size_t ts, const int64_t *begin, const int64_t *end, hipStream_t compute,
+// IPC: enqueued on c.stream like RCCL; ipc_finish (ycnr_als_sync) completes the half-step.  `side` selects the
+// peers' mapping of this matrix.
+int comm_exchange(Comm &c, void *fac, int side, int64_t k, size_t ts, const int64_t *begin, const int64_t *end, hipStream_t compute,
                   hipEvent_t ready, hipEvent_t t0, hipEvent_t t1, int64_t *bytesMoved) {
   const size_t rowBytes = (size_t)k * ts;
   int64_t moved = 0;
@@ -224,6 +327,28 @@ int comm_exchange(Comm &c, void *fac, int64_t k, size_t ts, const int64_t *begin
     }
     NCCL_TRY(c.api, c.api->GroupEnd());
     HIP_TRY(hipEventRecord(t1, c.stream));
+    return YCNR_OK;
+  }
+  if (c.transport == YCNR_COMM_STUB) {  // timing only: where the exchange would start and end
+    HIP_TRY(hipEventRecord(ready, compute));
+    HIP_TRY(hipStreamWaitEvent(c.stream, ready, 0));
+    HIP_TRY(hipEventRecord(t0, c.stream));
+    HIP_TRY(hipEventRecord(t1, c.stream));
+    return YCNR_OK;
+  }
+  if (c.transport == YCNR_COMM_IPC) {
+    if (c.mapped[side] != fac) return fail(YCNR_ERR_STATE, "ipc exchange: the matrix of side %d was rebound after it was published", side);
+    HIP_TRY(hipEventRecord(ready, compute));
+    HIP_TRY(hipStreamWaitEvent(c.stream, ready, 0));
+    HIP_TRY(hipEventRecord(t0, c.stream));
+    const size_t off = (size_t)begin[c.rank] * rowBytes, mine = (size_t)(end[c.rank] - begin[c.rank]) * rowBytes;
+    if (mine > 0)
+      for (int d = 1; d < c.world; ++d) {  // "distance" order, as the RCCL group: every link busy at once
+        const int to = (c.rank + d) % c.world;
+        HIP_TRY(hipMemcpyAsync(c.peers[(size_t)to].fac[side] + off, (const char *)fac + off, mine, hipMemcpyDeviceToDevice, c.stream));
+      }
+    HIP_TRY(hipEventRecord(t1, c.stream));
+    c.pendingFinish = true;
     return YCNR_OK;
   }
   if (c.transport == YCNR_COMM_SHM) {
@@ -253,7 +378,7 @@ int comm_exchange(Comm &c, void *fac, int64_t k, size_t ts, const int64_t *begin
 
 // vals[i] <- sum over ranks, in rank order (SHM) / RCCL's order
 int comm_allreduce_sum(Comm &c, double *vals, int64_t n) {
-  if (n <= 0 || !c.active()) return YCNR_OK;
+  if (n <= 0 || !c.active() || c.transport == YCNR_COMM_STUB) return YCNR_OK;
   if (c.transport == YCNR_COMM_RCCL) {
     if (c.scratchCount < (size_t)n) {
       if (c.dScratch) (void)hipFree(c.dScratch);
@@ -282,14 +407,22 @@ int comm_allreduce_sum(Comm &c, double *vals, int64_t n) {
 }
 
 // the whole matrix of `root` to every rank (a joining node's copy, lib/emf/EmfChief.js:55-71)
-int comm_broadcast(Comm &c, void *fac, size_t bytes, int root, hipStream_t compute) {
-  if (!c.active()) return YCNR_OK;
+int comm_broadcast(Comm &c, void *fac, int side, size_t bytes, int root, hipStream_t compute) {
+  if (!c.active() || c.transport == YCNR_COMM_STUB) return YCNR_OK;
   if (root < 0 || root >= c.world) return fail(YCNR_ERR_INVALID, "broadcast: root %d of %d", root, c.world);
   HIP_TRY(hipStreamSynchronize(compute));
   if (c.transport == YCNR_COMM_RCCL) {
     NCCL_TRY(c.api, c.api->Broadcast(fac, fac, bytes, ncclChar, root, c.nccl, c.stream));
     HIP_TRY(hipStreamSynchronize(c.stream));
     return YCNR_OK;
+  }
+  if (c.transport == YCNR_COMM_IPC) {  // the root pushes into every replica
+    if (c.mapped[side] != fac) return fail(YCNR_ERR_STATE, "ipc broadcast: the matrix of side %d was rebound after it was published", side);
+    if (c.rank == root)
+      for (int p = 0; p < c.world; ++p)
+        if (p != root) HIP_TRY(hipMemcpyAsync(c.peers[(size_t)p].fac[side], fac, bytes, hipMemcpyDeviceToDevice, c.stream));
+    HIP_TRY(hipStreamSynchronize(c.stream));
+    return shm_barrier(c);
   }
   if (bytes > c.dataBytes) return fail(YCNR_ERR_STATE, "broadcast: %zu bytes exceed the shared segment", bytes);
   if (c.rank == root) HIP_TRY(hipMemcpy(c.data, fac, bytes, hipMemcpyDeviceToHost));

@@ -1323,7 +1323,13 @@ int ycnr_als_set_ratings_sharded(ycnr_als *h, int side, const int64_t *rowPtr, c
   int rc = set_ratings_parts(h, side, rowPtr, indx, vals, memKind, nChunks, bounds + (size_t)rank * (nChunks + 1));
   if (rc) return rc;
   h->bounds[side].assign(bounds, bounds + n);
-  return YCNR_OK;
+  // IPC: the peers map this rank's matrices; a matrix bound (ycnr_als_bind_factors) since the communicator was made is
+  // published here -- this call is collective, every rank passes through
+  if (h->comm.transport == YCNR_COMM_IPC && h->comm.world > 1) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    rc = ipc_publish(h->comm, h->factors);
+  }
+  return rc;
 }
 
 int ycnr_als_set_rmse_ratings(ycnr_als *h, int which, const int64_t *rowPtr, const int32_t *indx,
@@ -1486,14 +1492,14 @@ int ycnr_als_step_async(ycnr_als *h, int side) {
     if (rc) return rc;
     if (exchange) {
       part_ranges(h, side, (int)c, xb, xe);
-      rc = comm_exchange(h->comm, h->factors[side], h->opt.factorsCount, h->ts(), xb.data(), xe.data(), h->stream, parts[c].ready,
+      rc = comm_exchange(h->comm, h->factors[side], side, h->opt.factorsCount, h->ts(), xb.data(), xe.data(), h->stream, parts[c].ready,
                          parts[c].x0, parts[c].x1, &h->info.exchangeBytes);
       if (rc) return rc;
     }
   }
   if (exchange) {
     HIP_TRY(hipEventRecord(h->evComputeEnd, h->stream));
-    if (h->comm.transport == YCNR_COMM_RCCL) HIP_TRY(hipStreamWaitEvent(h->stream, parts.back().x1, 0));
+    if (h->comm.transport != YCNR_COMM_SHM) HIP_TRY(hipStreamWaitEvent(h->stream, parts.back().x1, 0));  // (SHM is synchronous)
   }
   h->info.struct_size = (int32_t)sizeof(ycnr_als_step_info);
   h->info.side = side;
@@ -1525,6 +1531,7 @@ int ycnr_als_sync(ycnr_als *h) {
   if (!h) return fail(YCNR_ERR_INVALID, "null handle");
   HIP_TRY(hipSetDevice(h->opt.device));
   HIP_TRY(hipStreamSynchronize(h->stream));
+  if (int rcf = ipc_finish(h->comm)) return rcf;  // IPC: every rank's pushes have landed everywhere
   if (h->infoPending) {
     h->infoPending = false;
     const std::vector<Part> &parts = h->parts[h->infoSide];
@@ -1547,7 +1554,7 @@ int ycnr_als_sync(ycnr_als *h) {
       HIP_TRY(hipEventElapsedTime(&ms, parts.front().ev[0], parts.back().ev[4]));
       h->info.totalMs = ms;
       if (h->exchangedInStep) {
-        if (h->comm.transport == YCNR_COMM_RCCL) {
+        if (h->comm.transport != YCNR_COMM_SHM) {
           // what the step's stream still had to wait for after its own last kernel
           HIP_TRY(hipEventElapsedTime(&ms, h->evComputeEnd, parts.back().x1));
           h->info.exposedExchangeMs = ms > 0 ? ms : 0;
@@ -1679,7 +1686,8 @@ int ycnr_comm_unique_id(int transport, void *id) {
     memcpy(id, &uid, sizeof uid);
     return YCNR_OK;
   }
-  if (transport == YCNR_COMM_SHM) {
+  if (transport == YCNR_COMM_STUB) return YCNR_OK;
+  if (transport == YCNR_COMM_SHM || transport == YCNR_COMM_IPC) {
     FILE *f = fopen("/dev/urandom", "rb");
     if (!f || fread(id, 1, 16, f) != 16) {
       if (f) fclose(f);
@@ -1698,6 +1706,7 @@ int ycnr_als_comm_init(ycnr_als *h, int transport, const void *id, int rank, int
   // the staged stand-in needs room for the larger matrix (an exchange never stages more than one side)
   const size_t big = (size_t)std::max(h->opt.totalUsersCount, h->opt.totalItemsCount) * h->opt.factorsCount * h->ts();
   int rc = comm_setup(h->comm, id, transport, rank, world, std::max<size_t>(big, (size_t)1 << 20));
+  if (!rc && transport == YCNR_COMM_IPC) rc = ipc_publish(h->comm, h->factors);
   if (rc) comm_release(h->comm);
   return rc;
 }
@@ -1727,10 +1736,10 @@ int ycnr_als_exchange(ycnr_als *h, int side) {
     e[(size_t)r] = h->bounds[side][(size_t)r * (np + 1) + np];
   }
   Part &p0 = h->parts[side][0];
-  int rc = comm_exchange(h->comm, h->factors[side], h->opt.factorsCount, h->ts(), b.data(), e.data(), h->stream, p0.ready, p0.x0, p0.x1, nullptr);
+  int rc = comm_exchange(h->comm, h->factors[side], side, h->opt.factorsCount, h->ts(), b.data(), e.data(), h->stream, p0.ready, p0.x0, p0.x1, nullptr);
   if (rc) return rc;
-  if (h->comm.transport == YCNR_COMM_RCCL) HIP_TRY(hipStreamSynchronize(h->comm.stream));
-  return YCNR_OK;
+  if (h->comm.transport != YCNR_COMM_SHM) HIP_TRY(hipStreamSynchronize(h->comm.stream));
+  return ipc_finish(h->comm);
 }
 
 int ycnr_als_allreduce_sum(ycnr_als *h, double *vals, int64_t n) {
@@ -1743,7 +1752,7 @@ int ycnr_als_broadcast_factors(ycnr_als *h, int side, int root) {
   if (!h) return fail(YCNR_ERR_INVALID, "null handle");
   if (side != 0 && side != 1) return fail(YCNR_ERR_INVALID, "bad side %d", side);
   HIP_TRY(hipSetDevice(h->opt.device));
-  return comm_broadcast(h->comm, h->factors[side], (size_t)h->rows(side) * h->opt.factorsCount * h->ts(), root, h->stream);
+  return comm_broadcast(h->comm, h->factors[side], side, (size_t)h->rows(side) * h->opt.factorsCount * h->ts(), root, h->stream);
 }
 
 // One self-addressed send / receive pair and one all-reduce through the handle's communicator:

@@ -68,8 +68,9 @@ class EmfBase extends EventEmitter {
       rank: 0,
       world: 1,
       commId: null,
-      commTransport: 'rccl', // 'rccl' | 'shm' (functional stand-in: several ranks on one GPU)
+      commTransport: 'rccl', // 'rccl' | 'ipc' (mapped peer replicas + copy engines; also several ranks on one GPU) | 'shm' (host-staged stand-in)
       exchangeChunks: 4,
+      rebalanceAfterIters: 1,   // multi-GPU: cut the row shards again from the measured compute times after this many iterations (0 = never)
       gpuDevices: 0,            // devices the per-GPU processes are spread over (0 = what the library reports)
       gpuProcessScript: null,   // entry point of a per-GPU process (default lib/emf/EmfGpuProcess.js)
       gpuProcessTimeoutMs: 0,   // trainOnGpus gives up after this long (0 = no limit)

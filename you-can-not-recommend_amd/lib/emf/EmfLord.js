@@ -231,7 +231,11 @@ class EmfLord extends EmfMaster {
   /** 2 steps - first fix item vectors and calc user vectors, then vice versa (EmfLord.js:954-958) */
   alsTrainIter() {
     return this.alsTrainStep('byUser')
-      .then(() => this.alsTrainStep('byItem'));
+      .then(() => this.alsTrainStep('byItem'))
+      .then(() => {
+        // feedback for the static shards (options.rebalanceAfterIters, EmfMaster.rebalance)
+        if (this.options.world > 1 && ++this.itersRun == this.options.rebalanceAfterIters) this.rebalance();
+      });
   }
 
   /** @param string stepType 'byUser', 'byItem' (EmfLord.js:963-984) */

@@ -15,6 +15,9 @@ class EmfMaster extends EmfManager {
     this.stepType = null;
     this.trainIter = 0;
     this.lastStepInfo = null;
+    this.lastStepInfoBySide = {};
+    this.itersRun = 0;
+    this.rebalanced = null;
   }
 
   /** prepareSharedFactors (EmfMaster.js:347-358) */
@@ -62,6 +65,73 @@ class EmfMaster extends EmfManager {
     return b;
   }
 
+  /**
+   * Row ranges for the iterations that follow, from the time every rank's shard just took (same rule as
+   * rebalanced_ranges of the Python mirror): the modelled cost of the rows of shard r is scaled by
+   * ms[r] / (modelled cost of r) and the ranges are cut again at equal scaled cost.  The feedback that stands in
+   * for the reference's work-stealing portion dispenser (EmfLord.m_incrNextPortion, lib/emf/EmfLord.js:996-1006).
+   */
+  static rebalancedRanges(rowPtr, bounds, ms, k, double) {
+    const world = bounds.length - 1, rows = bounds[world];
+    for (let r = 0; r < world; r++) if (!(ms[r] > 0) || !isFinite(ms[r])) return bounds.slice();
+    const cum = new Float64Array(rows + 1);
+    for (let r = 0; r < world; r++) {
+      let c = 0;
+      for (let i = bounds[r]; i < bounds[r + 1]; i++) c += EmfMaster.rowCost(rowPtr[i + 1] - rowPtr[i], k, double);
+      const scale = c > 0 ? ms[r] / c : 1;
+      for (let i = bounds[r]; i < bounds[r + 1]; i++) cum[i + 1] = cum[i] + EmfMaster.rowCost(rowPtr[i + 1] - rowPtr[i], k, double) * scale;
+    }
+    const b = [0];
+    for (let p = 1; p < world; p++) {
+      const target = cum[rows] * p / world;
+      let lo = 0, hi = rows + 1;
+      while (lo < hi) {
+        const mid = (lo + hi) >> 1;
+        if (cum[mid] < target) lo = mid + 1; else hi = mid;
+      }
+      b.push(Math.max(b[b.length - 1], Math.min(lo, rows)));
+    }
+    b.push(rows);
+    return b;
+  }
+
+  /** sharded upload of one side for the row ranges `shards` (world + 1 ascending ids), in pipelined pieces */
+  _uploadSharded(side, csr, rows, shards) {
+    const n = als.native, o = this.options, k = this.factorsCount, dbl = o.useDoublePrecision, s1 = this.TypedArraySize1;
+    const nch = rows * k * s1 / o.world >= (8 << 20) ? Math.max(1, o.exchangeChunks) : 1;
+    const bounds = new Float64Array(o.world * (nch + 1));
+    for (let r = 0; r < o.world; r++)
+      bounds.set(EmfMaster.shardRanges(csr.rowPtr, shards[r], shards[r + 1], nch, k, dbl), r * (nch + 1));
+    n.setRatingsSharded(this.handle, side, csr.rowPtr, csr.indx, csr.vals, nch, bounds);
+  }
+
+  /**
+   * Cut both sides' shards again from the compute time every rank measured in its last half-steps and upload
+   * the ratings for the new cuts.  Collective (every per-GPU process calls it after the same iteration).
+   */
+  rebalance() {
+    const n = als.native, o = this.options, ds = this.dataset;
+    const out = {};
+    for (const [name, side, csr, rows] of [['byUser', als.BY_USER, ds.trainByUser, this.totalUsersCount],
+      ['byItem', als.BY_ITEM, ds.trainByItem, this.totalItemsCount]]) {
+      const info = this.lastStepInfoBySide[name];
+      if (!info) continue;
+      const ms = new Float64Array(o.world);
+      ms[o.rank] = info.totalMs;
+      n.allreduceSum(this.handle, ms);
+      const nb = EmfMaster.rebalancedRanges(csr.rowPtr, this.shards[side], ms, this.factorsCount, o.useDoublePrecision);
+      let mx = 0, mean = 0;
+      for (let r = 0; r < o.world; r++) { mx = Math.max(mx, ms[r]); mean += ms[r] / o.world; }
+      out[name] = { msByRank: Array.from(ms), bounds: nb };
+      if (mx > 1.03 * mean && nb.some((v, i) => v != this.shards[side][i])) {
+        this.shards[side] = nb;
+        this._uploadSharded(side, csr, rows, nb);
+      }
+    }
+    this.rebalanced = out;
+    return out;
+  }
+
   /** Upload the ratings once: replaces createWorkPortionBuffers + per-portion fetches (EmfMaster.js:156-234,501-614) */
   prepareWorkersToTrain() {
     const ds = this.dataset, n = als.native, o = this.options;
@@ -69,18 +139,18 @@ class EmfMaster extends EmfManager {
     if (o.world > 1) {
       // one process per GPU: this rank's place in the exchange, then the sharded upload of both sides
       n.commInit(this.handle, als.commTransport[o.commTransport], Uint8Array.from(Buffer.from(o.commId, 'base64')), o.rank, o.world);
-      const k = this.factorsCount, dbl = o.useDoublePrecision, s1 = this.TypedArraySize1;
+      const k = this.factorsCount, dbl = o.useDoublePrecision;
+      this.shards = {};
       const sharded = (side, csr, rows) => {
         const shards = EmfMaster.shardRanges(csr.rowPtr, 0, rows, o.world, k, dbl);
-        const nch = rows * k * s1 / o.world >= (8 << 20) ? Math.max(1, o.exchangeChunks) : 1;
-        const bounds = new Float64Array(o.world * (nch + 1));
-        for (let r = 0; r < o.world; r++)
-          bounds.set(EmfMaster.shardRanges(csr.rowPtr, shards[r], shards[r + 1], nch, k, dbl), r * (nch + 1));
-        n.setRatingsSharded(this.handle, side, csr.rowPtr, csr.indx, csr.vals, nch, bounds);
+        this.shards[side] = shards;
+        this._uploadSharded(side, csr, rows, shards);
         return shards;
       };
       const su = sharded(als.BY_USER, ds.trainByUser, this.totalUsersCount);
       sharded(als.BY_ITEM, ds.trainByItem, this.totalItemsCount);
+      // the RMSE sets keep this cut of the users whatever rebalance() does later: their partial sums are added
+      // over the ranks, any tiling of the rows will do
       this.shardUsers = [su[o.rank], su[o.rank + 1]];
     } else {
       n.setRatings(this.handle, als.BY_USER, ds.trainByUser.rowPtr, ds.trainByUser.indx, ds.trainByUser.vals);
@@ -97,6 +167,7 @@ class EmfMaster extends EmfManager {
     this.workType = 'train';
     this.stepType = stepType;
     this.lastStepInfo = als.native.step(this.handle, als.stepSide[stepType]);
+    this.lastStepInfoBySide[stepType] = this.lastStepInfo;
     this.emit('stepComplete');
   }
 

@@ -23,8 +23,8 @@
     BY_USER: 0, BY_ITEM: 1,
     RMSE_VALIDATE: 0, RMSE_TEST: 1,
     FLAG_LDS_SOLVER: 1, FLAG_NO_DUAL: 2,
-    COMM_RCCL: 1, COMM_SHM: 2,
-    commTransport: { rccl: 1, shm: 2 },
+    COMM_RCCL: 1, COMM_SHM: 2, COMM_IPC: 3, COMM_STUB: 4,
+    commTransport: { rccl: 1, shm: 2, ipc: 3, stub: 4 },
     stepSide: { byUser: 0, byItem: 1 },
     rmseSet: { rmseValidate: 0, rmseTest: 1 },
   };

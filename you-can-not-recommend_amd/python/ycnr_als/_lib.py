@@ -34,7 +34,7 @@ EXPORTS = [
     "ycnr_comm_unique_id", "ycnr_als_comm_init", "ycnr_als_comm_destroy", "ycnr_als_set_ratings_sharded",
     "ycnr_als_exchange", "ycnr_als_broadcast_factors", "ycnr_als_allreduce_sum", "ycnr_als_comm_selftest",
 ]
-COMM_NONE, COMM_RCCL, COMM_SHM = 0, 1, 2
+COMM_NONE, COMM_RCCL, COMM_SHM, COMM_IPC, COMM_STUB = 0, 1, 2, 3, 4
 COMM_ID_BYTES = 128
 ABI_VERSION = 3
 

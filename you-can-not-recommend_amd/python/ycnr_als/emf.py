@@ -45,9 +45,15 @@ def default_options():
         # multi-GPU only: a side whose matrix is large is solved in this many pieces per rank, so that
         # the exchange of one piece overlaps with the solve of the next (1 = solve, then exchange)
         "exchangeChunks": 4,
-        # multi-GPU only: "rccl" (the product path) or "shm" (functional stand-in: ranks of one node,
-        # possibly sharing one GPU, stage rows through POSIX shared memory)
+        # multi-GPU only: "rccl" (the product path), "ipc" (peers' replicas mapped through hipIpc, rows pushed by
+        # the copy engines; also runs with several ranks on one GPU) or "shm" (functional stand-in: ranks of
+        # one node stage rows through POSIX shared memory)
         "commTransport": "rccl",
+        # multi-GPU only: after this many iterations (counted from the first one this Lord runs) the row shards
+        # are cut again from the compute time every rank measured (0 = never); the static cut comes from a cost
+        # model (row_cost), this is the feedback that corrects it -- the role of the reference's work-stealing
+        # portion dispenser (EmfLord.m_incrNextPortion, lib/emf/EmfLord.js:996-1006)
+        "rebalanceAfterIters": 1,
     }
 
 
@@ -138,6 +144,34 @@ def shard_ranges(counts, world, k=None, double=False):
     b.append(len(counts))
     b = np.maximum.accumulate(np.asarray(b, np.int64))
     return b
+
+
+def rebalanced_ranges(counts, bounds, ms_by_rank, k=None, double=False):
+    """Row ranges for the iterations that follow, from the time every rank's shard of this side just took.
+
+    The reference hands portions to whichever node asks next (EmfLord.m_incrNextPortion, lib/emf/EmfLord.js:996-1006;
+    EmfChief._incrNextPortion, lib/emf/EmfChief.js:308-318), so a slow node simply takes fewer.  Shards here are
+    static within a half-step, so the feedback acts between iterations: the modelled cost of the rows of shard r
+    is scaled by (measured ms of r) / (modelled cost of r) and the ranges are cut again at equal scaled cost --
+    a shard that ran long gives rows away.  Results do not depend on the cuts (every row is solved by one wave
+    / workgroup or a fixed slab order)."""
+    counts = np.asarray(counts, np.int64)
+    bounds = np.asarray(bounds, np.int64)
+    world = len(bounds) - 1
+    ms = np.asarray(ms_by_rank, np.float64)
+    w = counts.astype(np.float64) if k is None else row_cost(counts, k, double)
+    if len(ms) != world or not np.all(np.isfinite(ms)) or not np.all(ms > 0):
+        return bounds.copy()
+    w = w.copy()
+    for r in range(world):
+        lo, hi = int(bounds[r]), int(bounds[r + 1])
+        c = float(w[lo:hi].sum())
+        if c > 0:
+            w[lo:hi] *= ms[r] / c
+    cum = np.concatenate([[0.0], np.cumsum(w)])
+    total = cum[-1]
+    b = [0] + [int(np.searchsorted(cum, total * r / world, side="left")) for r in range(1, world)] + [len(counts)]
+    return np.maximum.accumulate(np.asarray(b, np.int64))
 
 
 class Dataset:
@@ -286,7 +320,7 @@ class EmfLord:
         return os.path.join(self.options["dataDir"], self.options["dbType"] + "_factors_tmp")
 
     # -- prepareToTrain (EmfLord.js:617-653, without the db) ---------------------------
-    def prepareToTrain(self, dataset, userFactors=None, itemFactors=None, seed=1, device=0):
+    def prepareToTrain(self, dataset, userFactors=None, itemFactors=None, seed=1, device=0, shards=None):
         """Upload the ratings (sharded by row over the ranks), build the RMSE portions and
         create / load the factor matrices (prepareSharedFactors, EmfMaster.js:347-358)."""
         if self.options["alg"] != "als":
@@ -300,7 +334,9 @@ class EmfLord:
         ci = _to_np(ds.train_by_item.counts())
         self.ratingsCntPerUser, self.ratingsCntPerItem = cu, ci
         k, dbl = self.factorsCount, self.options["useDoublePrecision"]
-        self.shards = {0: shard_ranges(cu, self.world, k, dbl), 1: shard_ranges(ci, self.world, k, dbl)}
+        # shards: {side: int64[world + 1]} overrides the cost-model cut (bench.py --emulate-world replays measured cuts)
+        self.shards = shards or {0: shard_ranges(cu, self.world, k, dbl), 1: shard_ranges(ci, self.world, k, dbl)}
+        self._itersRun, self.rebalanced = 0, None
         self.backend = self._backend_factory(self.options, self.totalUsersCount, self.totalItemsCount, device)
         ub, ue = self.shards[0][self.rank], self.shards[0][self.rank + 1]
         ib, ie = self.shards[1][self.rank], self.shards[1][self.rank + 1]
@@ -332,20 +368,7 @@ class EmfLord:
                 self.native_exchange = False
         self.exchangePath = ("libycnr_als:" + self.options.get("commTransport", "rccl")) if self.native_exchange else \
             ("torch.distributed" if self.world > 1 else "none")
-        if self.native_exchange:
-            # pieces per rank: a side whose shard is large is pipelined against its own exchange
-            s = 8 if dbl else 4
-            self.pieceBounds = {}
-            for side, cnt, rows in ((0, cu, self.totalUsersCount), (1, ci, self.totalItemsCount)):
-                nch = int(self.options.get("exchangeChunks", 4)) if rows * k * s / self.world >= (8 << 20) else 1
-                b = self.shards[side]
-                self.pieceBounds[side] = np.stack([b[r] + shard_ranges(cnt[b[r]:b[r + 1]], max(nch, 1), k, dbl)
-                                                   for r in range(self.world)])
-            self.backend.set_ratings(0, ds.train_by_user, int(ub), int(ue), bounds=self.pieceBounds[0])
-            self.backend.set_ratings(1, ds.train_by_item, int(ib), int(ie), bounds=self.pieceBounds[1])
-        else:
-            self.backend.set_ratings(0, ds.train_by_user, int(ub), int(ue))
-            self.backend.set_ratings(1, ds.train_by_item, int(ib), int(ie))
+        self._upload_shards((0, 1))
         self.trainRatingsCount = int(cu.sum())
         # portions of the RMSE passes (EmfLord.js:523-598); kept as exclusive 0-based row ends
         self.portionsRowIdTo = {}
@@ -406,6 +429,67 @@ class EmfLord:
         self.backend.set_factors(1, itemFactors)
         self._status = "ready"
 
+    def _upload_shards(self, sides):
+        """(Re)upload the train ratings of `sides` for the current self.shards: this rank's rows, in pieces when
+        the side's matrix is large (the exchange of one piece overlaps with the solve of the next)."""
+        ds, k, dbl = self.dataset, self.factorsCount, self.options["useDoublePrecision"]
+        cnts = {0: self.ratingsCntPerUser, 1: self.ratingsCntPerItem}
+        csrs = {0: ds.train_by_user, 1: ds.train_by_item}
+        rows = {0: self.totalUsersCount, 1: self.totalItemsCount}
+        if self.native_exchange:
+            s = 8 if dbl else 4
+            self.pieceBounds = getattr(self, "pieceBounds", {})
+            for side in sides:
+                nch = int(self.options.get("exchangeChunks", 4)) if rows[side] * k * s / self.world >= (8 << 20) else 1
+                b = self.shards[side]
+                self.pieceBounds[side] = np.stack([b[r] + shard_ranges(cnts[side][b[r]:b[r + 1]], max(nch, 1), k, dbl)
+                                                   for r in range(self.world)])
+                self.backend.set_ratings(side, csrs[side], int(b[self.rank]), int(b[self.rank + 1]), bounds=self.pieceBounds[side])
+        else:
+            for side in sides:
+                b = self.shards[side]
+                self.backend.set_ratings(side, csrs[side], int(b[self.rank]), int(b[self.rank + 1]))
+
+    def _gather_ms(self, ms):
+        """ms of this rank -> float64[world] on every rank, over whatever carries the RMSE partial sums"""
+        v = np.zeros(self.world, np.float64)
+        v[self.rank] = ms
+        if self.native_exchange:
+            return self.backend.allreduce_sum(v)
+        torch = _torch()
+        dev = self.backend.factors(0).device if hasattr(self.backend, "factors") else "cpu"
+        t = torch.from_numpy(v).to(dev)
+        self._dist.all_reduce(t)
+        return t.cpu().numpy()
+
+    def rebalance(self):
+        """Cut both sides' row shards again from the compute time every rank measured in the last iteration
+        (rebalanced_ranges) and upload the ratings for the new cuts.  Collective.  Returns {side: new bounds}."""
+        last = {}
+        for st in self.stepTimes[::-1]:
+            if st["stepType"] not in last:
+                last[st["stepType"]] = st
+            if len(last) == 2:
+                break
+        k, dbl = self.factorsCount, self.options["useDoublePrecision"]
+        cnts = {0: self.ratingsCntPerUser, 1: self.ratingsCntPerItem}
+        out, changed = {}, []
+        for name, side in self.STEP_SIDE.items():
+            if name not in last:
+                continue
+            info = last[name]["info"]
+            ms = self._gather_ms(float(getattr(info, "totalMs", 0.0) or last[name]["wall"] * 1e3))
+            nb = rebalanced_ranges(cnts[side], self.shards[side], ms, k, dbl)
+            out[side] = {"ms_by_rank": ms.tolist(), "bounds": nb.tolist()}
+            # leave a side alone when it is within 3 % of balanced already: a re-upload is not free
+            if ms.max() > 1.03 * ms.mean() and not np.array_equal(nb, self.shards[side]):
+                self.shards[side] = nb
+                changed.append(side)
+        if changed:
+            self._upload_shards(changed)
+        self.rebalanced = out
+        return out
+
     # -- training ----------------------------------------------------------------------
     def getCanTrainError(self):
         if self._status == "training":
@@ -446,6 +530,9 @@ class EmfLord:
         """2 steps - first fix item vectors and calc user vectors, then vice versa (EmfLord.js:954-958)."""
         self.alsTrainStep("byUser")
         self.alsTrainStep("byItem")
+        self._itersRun = getattr(self, "_itersRun", 0) + 1
+        if self.world > 1 and self._itersRun == int(self.options.get("rebalanceAfterIters", 0) or 0):
+            self.rebalance()
 
     def alsTrainStep(self, stepType):
         """EmfLord.alsTrainStep (lib/emf/EmfLord.js:963-984): resolves once every row of the side

@@ -11,7 +11,8 @@ from . import _lib
 from ._lib import BY_ITEM, BY_USER, F32, F64, MEM_DEVICE, MEM_HOST, RMSE_TEST, RMSE_VALIDATE, check
 
 SIDES = {"byUser": BY_USER, "byItem": BY_ITEM, BY_USER: BY_USER, BY_ITEM: BY_ITEM}
-TRANSPORTS = {"rccl": _lib.COMM_RCCL, "shm": _lib.COMM_SHM, _lib.COMM_RCCL: _lib.COMM_RCCL, _lib.COMM_SHM: _lib.COMM_SHM}
+TRANSPORTS = {"rccl": _lib.COMM_RCCL, "shm": _lib.COMM_SHM, "ipc": _lib.COMM_IPC, "stub": _lib.COMM_STUB,
+              _lib.COMM_RCCL: _lib.COMM_RCCL, _lib.COMM_SHM: _lib.COMM_SHM, _lib.COMM_IPC: _lib.COMM_IPC, _lib.COMM_STUB: _lib.COMM_STUB}
 RMSE_SETS = {"rmseValidate": RMSE_VALIDATE, "rmseTest": RMSE_TEST, RMSE_VALIDATE: RMSE_VALIDATE,
              RMSE_TEST: RMSE_TEST}
 
