@@ -389,7 +389,7 @@ def emulate_world(args, local_rank):
     names = ("byUser", "byItem")
 
     def run(shards):
-        per = {n: {"compute_ms": [], "wall_ms": [], "pieces": 0, "exchange_bytes": []} for n in names}
+        per = {n: {"compute_ms": [], "wall_ms": [], "pieces": 0, "exchange_bytes": [], "kernel_ms": []} for n in names}
         used = None
         for r in range(W):
             lord = EmfLord(options={"factorsCount": k, "trainIters": args.steps, "useDoublePrecision": args.double,
@@ -409,6 +409,9 @@ def emulate_world(args, local_rank):
                 per[n]["wall_ms"].append(round(float(np.mean([s["wall"] for s in st])) * 1e3, 4))
                 per[n]["pieces"] = int(st[0]["info"].parts)
                 per[n]["exchange_bytes"].append(int(st[0]["info"].exchangeBytes))
+                # sums over the pieces: chunk Gramians, row kernel (+ dual classes when they share its interval), dual, reduce
+                per[n]["kernel_ms"].append([round(float(np.mean([getattr(s["info"], f) for s in st])), 3)
+                                            for f in ("gramSlabMs", "gramSolveMs", "dualSolveMs", "reduceSolveMs")])
             lord.destroy()
             del lord
             torch.cuda.empty_cache()

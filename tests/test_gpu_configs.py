@@ -218,6 +218,9 @@ def check_sample(oracle, torch, csr, rows, fixed, solved, k, what, rec):
 
 
 def backward_errors(torch, csr, vals, fixed, solved, rows, k):
+    """Normwise backward error of the normal equations in float64, per sampled row, divided by its gate: 2e-6 for
+    rows up to a million ratings, growing like sqrt(n) beyond (the rounding of a float32 sum over n terms; an item
+    of the full C5 has 10 M ratings -- its float32 ORACLE is 1e-4 from float64)."""
     out = []
     for r in rows.tolist():
         b0, e0 = int(csr.rowPtr[r]), int(csr.rowPtr[r + 1])
@@ -229,7 +232,8 @@ def backward_errors(torch, csr, vals, fixed, solved, rows, k):
             A += Y.T @ Y
             b += Y.T @ vals[c0:c1].double()
         x = solved[r].double()
-        out.append(float(torch.linalg.norm(A @ x - b) / (torch.linalg.norm(A) * torch.linalg.norm(x) + torch.linalg.norm(b))))
+        gate = 2e-6 * max(1.0, ((e0 - b0) / 1e6) ** 0.5)
+        out.append(float(torch.linalg.norm(A @ x - b) / (torch.linalg.norm(A) * torch.linalg.norm(x) + torch.linalg.norm(b))) / gate)
     return np.array(out)
 
 
@@ -281,8 +285,8 @@ def test_full_size_iteration(als, oracle, name):
     # normal equations in float64 on other rows of every class
     eu = backward_errors(torch, bu, bu.vals, V0, U1, sample_by_class(lu.cpu().numpy(), 30, 8, 7, dual_max, 1024), k)
     ei = backward_errors(torch, bi, bi.vals, U1, V, sample_by_class(li.cpu().numpy(), 10, 4, 8, dual_max, 1024), k)
-    rec["backward_error"] = {"byUser_worst": float(eu.max()), "byItem_worst": float(ei.max())}
-    assert eu.max() <= 2e-6 and ei.max() <= 2e-6, rec["backward_error"]
+    rec["backward_error_over_gate"] = {"byUser_worst": float(eu.max()), "byItem_worst": float(ei.max())}
+    assert eu.max() <= 1.0 and ei.max() <= 1.0, rec["backward_error_over_gate"]
     # linearity of the user half-step in the ratings, all rows
     r2 = torch.randn(bu.nnz, generator=g, device=dev) * 3.0
     xs = [U1]

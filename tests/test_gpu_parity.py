@@ -590,7 +590,8 @@ def test_full_iterations_ml100k_shape(als, oracle, double):
     for a, b in zip(h1, h2):
         for key in ("rmseValidate", "rmseTest", "rmseTestShifted"):
             assert abs(a[key] - b[key]) <= 1e-6, (key, a[key], b[key])
-    assert abs(c1["globalAvgShift"] - c2["globalAvgShift"]) <= 1e-6
+    # (the shift is totalRatingsAvg - predAvg of the LAST portion, a float32 mean over a few hundred predictions)
+    assert abs(c1["globalAvgShift"] - c2["globalAvgShift"]) <= (1e-6 if double else 1e-5)
     assert h1[-1]["rmseValidate"] < h1[0]["rmseValidate"]  # it learns
 
 

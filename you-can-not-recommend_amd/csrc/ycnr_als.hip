@@ -355,12 +355,12 @@ int launch_nb(const StepArgs<T> &args, int64_t nUnits, int64_t nSplitUnits, int6
 // k > 128 with k % 4 != 0: the kernels of that path need 16-byte rows, so the half-step runs on copies of
 // both matrices with the rows padded to kp = 4 ceil(k / 4) zero columns.  A zero column adds nothing
 // to the Gramian or to b, its diagonal entry is lambda n and its solution component exactly 0.
-__global__ void pad_rows_kernel(const float *src, float *dst, int64_t rows, int k, int kp) {
+__global__ void pad_rows_kernel(const float *src, float *dst, int64_t rowBegin, int64_t rows, int k, int kp) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * kp) return;
-  const int64_t r = i / kp;
-  const int c = (int)(i - r * kp);
-  dst[i] = c < k ? src[r * k + c] : 0.0f;
+  const int64_t r = rowBegin + i / kp;
+  const int c = (int)(i % kp);
+  dst[r * kp + c] = c < k ? src[r * k + c] : 0.0f;
 }
 __global__ void unpad_rows_kernel(const float *src, float *dst, int64_t rowBegin, int64_t rows, int k, int kp) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1472,13 +1472,20 @@ int ycnr_als_step_async(ycnr_als *h, int side) {
   // c travel (on the communicator's stream) while piece c + 1 is being solved, and the step's
   // stream waits for the last piece to land -- the next half-step reads the whole matrix.
   if (h->kPad) {
-    // only the FIXED side is read: the solved rows are written whole (x of a zero column is exactly 0) and
-    // copied back piece by piece (launch_part)
+    // the FIXED side in full; of the solved side only this rank's rows (launch_part copies them back piece by
+    // piece, the rows without ratings among them unchanged)
     const int s = 1 - side;
     const int64_t n = h->rows(s) * h->kPad;
     hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, (const float *)h->factors[s],
-                       h->padded[s], h->rows(s), h->opt.factorsCount, h->kPad);
+                       h->padded[s], (int64_t)0, h->rows(s), h->opt.factorsCount, h->kPad);
     HIP_TRY(hipGetLastError());
+    for (const Part &p : parts) {
+      const int64_t nr = p.R.rowEnd - p.R.rowBegin, m = nr * h->kPad;
+      if (m <= 0) continue;
+      hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, h->stream, (const float *)h->factors[side],
+                         h->padded[side], p.R.rowBegin, nr, h->opt.factorsCount, h->kPad);
+      HIP_TRY(hipGetLastError());
+    }
   }
   const bool exchange = h->comm.active() && !h->bounds[side].empty();
   if (exchange && h->bounds[side].size() != (size_t)h->comm.world * (parts.size() + 1))
