@@ -94,6 +94,11 @@ def main():
     tj = json.load(open(tpath)) if os.path.exists(tpath) else {"workloads": {}}
     tj.setdefault("sources", {})[workload] = (f"profiles/{tag}_{workload}_pmc_by_kernel.json: (2 x FETCH_SIZE + WRITE_SIZE) KB per launch, "
                                               "rocprofv3 --pmc, own passes")
+    try:  # which tree the counters were measured on (bench.py prints it beside roofline.traffic)
+        import subprocess
+        tj.setdefault("commits", {})[workload] = subprocess.check_output(["git", "-C", here, "rev-parse", "--short", "HEAD"], text=True).strip()
+    except Exception:  # noqa: BLE001
+        pass
     tj["workloads"][workload] = {k: {"hbm_bytes_per_launch": round(v["kb"] * 1024.0 / v["launches"])} for k, v in traffic.items()}
     json.dump(tj, open(tpath, "w"), indent=1)
     for k, v in tj["workloads"][workload].items():

@@ -1974,7 +1974,20 @@ __global__ __launch_bounds__(64) void als_dual_solve_kernel(StepArgs<float> a) {
 #endif
     typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    const int ksteps32 = (k + 31) >> 5;
+    // k = 32 m + 4 or + 8 (k = 100!): the last 4 / 8 factors would cost a whole K = 32 step of six bf16 MFMAs per
+    // tile and the split of eight mostly-zero values per lane; they go through ONE / TWO exact float32 MFMAs of
+    // K = 4 per tile instead (lane (g, c): factor 32 m + 4 q + g of rating 16 ba + c -- one dword, no split)
+    const int krem = k & 31;
+    const bool remF32 = krem == 4 || krem == 8;
+    const int ksteps32 = remF32 ? (k >> 5) : ((k + 31) >> 5);
+    float yr[NBN][2];
+    if (remF32) {
+#pragma unroll
+      for (int ba = 0; ba < NBN; ++ba) {
+        yr[ba][0] = rowp[ba][(k & ~31) + g];
+        yr[ba][1] = krem == 8 ? rowp[ba][(k & ~31) + 4 + g] : 0.0f;
+      }
+    }
     float4 za[NBN][2], zb[NBN][2];
     auto load8 = [&](float4 (&y)[NBN][2], int s) {
       const int f = 32 * s + 8 * g;
@@ -1987,7 +2000,9 @@ __global__ __launch_bounds__(64) void als_dual_solve_kernel(StepArgs<float> a) {
     // NBN <= 6: the next K-step's rows are loaded while this one is split and multiplied.  Larger
     // classes (k > 128 only) have no registers for that: each block is loaded just before its split.
     constexpr bool AHEAD = NBN <= 6;
-    if constexpr (AHEAD) load8(za, 0);
+    if constexpr (AHEAD) {
+      if (ksteps32 > 0) load8(za, 0);
+    }
     for (int s = 0; s < ksteps32; ++s) {
       if constexpr (AHEAD) {
         if (s + 1 < ksteps32) load8(zb, s + 1);
@@ -2038,6 +2053,17 @@ __global__ __launch_bounds__(64) void als_dual_solve_kernel(StepArgs<float> a) {
         for (int ba = 0; ba < NBN; ++ba) {
           za[ba][0] = zb[ba][0];
           za[ba][1] = zb[ba][1];
+        }
+      }
+    }
+    if (remF32) {
+#pragma unroll
+      for (int ba = 0; ba < NBN; ++ba) {
+#pragma unroll
+        for (int bb = ba; bb < NBN; ++bb) {
+          acc_t t = Tr::mma(yr[ba][0], yr[bb][0], acc[tile_index(ba, bb, NBN)]);
+          if (krem == 8) t = Tr::mma(yr[ba][1], yr[bb][1], t);
+          acc[tile_index(ba, bb, NBN)] = t;
         }
       }
     }
@@ -2119,7 +2145,10 @@ __global__ __launch_bounds__(64) void als_dual_quad_kernel(StepArgs<float> a, in
   constexpr int KS = 4;  // K-steps of 32 factors: k <= 128
   const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
   const int k = a.k, kq = k >> 2;
-  const int ksteps32 = (k + 31) >> 5;
+  // (k = 32 m + 4 / + 8: the remainder through exact float32 MFMAs of K = 4, as in als_dual_solve_kernel)
+  const int krem = k & 31;
+  const bool remF32 = krem == 4 || krem == 8;
+  const int ksteps32 = remF32 ? (k >> 5) : ((k + 31) >> 5);
   const int first = 4 * (int)blockIdx.x;
   // the four rows (a short last quad repeats its last row; only valid groups store)
   Unit us[4];
@@ -2151,6 +2180,14 @@ __global__ __launch_bounds__(64) void als_dual_quad_kernel(StepArgs<float> a, in
       z[kk][1] = *reinterpret_cast<const float4 *>(f + 4 < k ? rowp + f + 4 : a.zeros);
     }
     acc_t t = acc_t{0.0f, 0.0f, 0.0f, 0.0f};
+    if (remF32) {  // wave-uniform
+      const float y0 = rowp[(k & ~31) + g];
+      t = Tr::mma(y0, y0, t);
+      if (krem == 8) {
+        const float y1 = rowp[(k & ~31) + 4 + g];
+        t = Tr::mma(y1, y1, t);
+      }
+    }
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
       if (kk < ksteps32) {  // wave-uniform

@@ -287,6 +287,15 @@ int ipc_publish(Comm &c, void *const fac[2]) {
   return YCNR_OK;
 }
 
+// IPC, before the first push of a collective call: every rank has entered it.  A push lands in the PEER's replica at
+// the pusher's pace; whatever a peer's host did to its replica before it entered the call (ycnr_als_set_factors,
+// a torch copy into the bound tensor) must be ordered before that -- with receives posted by the receiver (RCCL, SHM)
+// this is implied, with pushes it is this barrier.
+int ipc_enter(Comm &c) {
+  if (c.transport != YCNR_COMM_IPC || c.world < 2) return YCNR_OK;
+  return shm_barrier(c);
+}
+
 // IPC, end of a half-step: this rank's pushes have drained, then everybody's have (host barrier)
 int ipc_finish(Comm &c) {
   if (c.transport != YCNR_COMM_IPC || !c.pendingFinish) return YCNR_OK;
@@ -418,6 +427,7 @@ int comm_broadcast(Comm &c, void *fac, int side, size_t bytes, int root, hipStre
   }
   if (c.transport == YCNR_COMM_IPC) {  // the root pushes into every replica
     if (c.mapped[side] != fac) return fail(YCNR_ERR_STATE, "ipc broadcast: the matrix of side %d was rebound after it was published", side);
+    if (int rcb = ipc_enter(c)) return rcb;
     if (c.rank == root)
       for (int p = 0; p < c.world; ++p)
         if (p != root) HIP_TRY(hipMemcpyAsync(c.peers[(size_t)p].fac[side], fac, bytes, hipMemcpyDeviceToDevice, c.stream));

@@ -590,9 +590,15 @@ struct Part {
   Schedule S;
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ready = nullptr, x0 = nullptr, x1 = nullptr;
+  // fork / join of the piece's dual-class launches on the handle's side streams, and "all kernels of the piece done":
+  // per piece, because two pieces are in flight at a time (on the handle's two piece streams)
+  hipEvent_t fork = nullptr, join[kSideStreams] = {}, done = nullptr;
   hipError_t create_events() {
     hipError_t e = hipSuccess;
     for (int i = 0; i < 5 && e == hipSuccess; ++i) e = hipEventCreate(&ev[i]);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&fork, hipEventDisableTiming);
+    for (int i = 0; i < kSideStreams && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&join[i], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&done, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ready, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreate(&x0);
     if (e == hipSuccess) e = hipEventCreate(&x1);
@@ -606,8 +612,14 @@ struct Part {
     if (ready) (void)hipEventDestroy(ready);
     if (x0) (void)hipEventDestroy(x0);
     if (x1) (void)hipEventDestroy(x1);
+    if (fork) (void)hipEventDestroy(fork);
+    if (done) (void)hipEventDestroy(done);
+    for (int i = 0; i < kSideStreams; ++i) {
+      if (join[i]) (void)hipEventDestroy(join[i]);
+      join[i] = nullptr;
+    }
     for (int i = 0; i < 5; ++i) ev[i] = nullptr;
-    ready = x0 = x1 = nullptr;
+    ready = x0 = x1 = fork = done = nullptr;
   }
 };
 
@@ -618,7 +630,12 @@ struct ycnr_als {
   hipStream_t ownStream = nullptr;
   hipStream_t stream = nullptr;
   hipStream_t sideStream[kSideStreams] = {};  // dual classes next to the row kernel (DualPlan)
-  hipEvent_t evFork = nullptr, evJoin[kSideStreams] = {};
+  // A sharded side is solved in pieces (the exchange of one travels while the next is solved).  The pieces are
+  // independent (different rows of the solved matrix), so they alternate over two streams that fork from and join the
+  // step's stream: the kernels of piece c + 1 fill the tails of piece c's (one GPU's eighth of the MAL-scale user side,
+  // 4 pieces in stream order: 2.5 ms against 2.0 ms in one piece).
+  hipStream_t pieceStream[2] = {};
+  hipEvent_t evStepStart = nullptr;
   void *factors[2] = {nullptr, nullptr};
   bool ownFactors[2] = {false, false};
   int kPad = 0;                          // != 0: factorsCount padded to a multiple of 4 (k > 128, k % 4 != 0)
@@ -631,6 +648,12 @@ struct ycnr_als {
   bool exchangedInStep = false;
   Ratings rmse[2];
   ErrInfo *dErr = nullptr;
+  // The error record is never reset on the device: its count only grows, the host remembers what it has seen
+  // (errSeen) and gets the record through an 8-byte copy into page-locked memory at the end of every half-step
+  // (before: a memset kernel in front of every half-step and a synchronous copy behind it -- 30 us of a 90 us
+  // half-step at the ML-100k shape).
+  ErrInfo *hErr = nullptr;
+  int32_t errSeen = 0;
   void *dZeros = nullptr;  // the zero "factor row" read for ratings past a unit's end
   ycnr_als_step_info info{};
   bool infoPending = false;
@@ -1008,11 +1031,9 @@ int ycnr_als_create(const ycnr_als_options *o, ycnr_als **out) {
   h->opt.chunkRatings = (h->opt.chunkRatings + 3) & ~3;
   hipError_t e = hipStreamCreateWithFlags(&h->ownStream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreate(&h->evComputeEnd);
-  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->evFork, hipEventDisableTiming);
-  for (int i = 0; i < kSideStreams && e == hipSuccess; ++i) {
-    e = hipStreamCreateWithFlags(&h->sideStream[i], hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->evJoin[i], hipEventDisableTiming);
-  }
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->evStepStart, hipEventDisableTiming);
+  for (int i = 0; i < kSideStreams && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&h->sideStream[i], hipStreamNonBlocking);
+  for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&h->pieceStream[i], hipStreamNonBlocking);
   for (int s = 0; s < 2 && e == hipSuccess; ++s) {
     e = hipMalloc(&h->factors[s], (size_t)h->rows(s) * o->factorsCount * h->ts());
     if (e == hipSuccess) {
@@ -1026,6 +1047,8 @@ int ycnr_als_create(const ycnr_als_options *o, ycnr_als **out) {
   }
   if (e == hipSuccess) e = hipMalloc(&h->dErr, kErrBytes);  // ErrInfo + room for in-kernel stamps of diagnostic builds
   if (e == hipSuccess) e = hipMemsetAsync(h->dErr, 0, kErrBytes, h->ownStream);
+  if (e == hipSuccess) e = hipHostMalloc((void **)&h->hErr, sizeof(ErrInfo), hipHostMallocDefault);
+  if (e == hipSuccess) memset(h->hErr, 0, sizeof(ErrInfo));
   if (e == hipSuccess) e = hipMalloc(&h->dZeros, kZeroRowBytes);
   if (e == hipSuccess) e = hipMemsetAsync(h->dZeros, 0, kZeroRowBytes, h->ownStream);
   if (e == hipSuccess) e = hipStreamSynchronize(h->ownStream);
@@ -1053,15 +1076,21 @@ int ycnr_als_destroy(ycnr_als *h) {
     if (h->padded[s]) (void)hipFree(h->padded[s]);
   }
   if (h->dErr) (void)hipFree(h->dErr);
+  if (h->hErr) (void)hipHostFree(h->hErr);
   if (h->dZeros) (void)hipFree(h->dZeros);
   if (h->evComputeEnd) (void)hipEventDestroy(h->evComputeEnd);
-  if (h->evFork) (void)hipEventDestroy(h->evFork);
+  if (h->evStepStart) (void)hipEventDestroy(h->evStepStart);
   for (int i = 0; i < kSideStreams; ++i) {
     if (h->sideStream[i]) {
       (void)hipStreamSynchronize(h->sideStream[i]);
       (void)hipStreamDestroy(h->sideStream[i]);
     }
-    if (h->evJoin[i]) (void)hipEventDestroy(h->evJoin[i]);
+  }
+  for (int i = 0; i < 2; ++i) {
+    if (h->pieceStream[i]) {
+      (void)hipStreamSynchronize(h->pieceStream[i]);
+      (void)hipStreamDestroy(h->pieceStream[i]);
+    }
   }
   if (h->ownStream) (void)hipStreamDestroy(h->ownStream);
   delete h;
@@ -1401,7 +1430,7 @@ int ycnr_als_bind_factors(ycnr_als *h, int side, void *p) {
 }
 
 // kernels of one piece of the shard, on the handle's stream, timed by the piece's events
-static int launch_part(ycnr_als *h, int side, Part &part) {
+static int launch_part(ycnr_als *h, int side, Part &part, hipStream_t stream) {
   const Ratings &R = part.R;
   const Schedule &S = part.S;
   const double lambda = side == YCNR_BY_USER ? h->opt.userFactReg : h->opt.itemFactReg;
@@ -1423,31 +1452,31 @@ static int launch_part(ycnr_als *h, int side, Part &part) {
       // where the half-step is bound by the launches themselves, they made it slower)
       if (S.dualRows >= kMinOverlapDualRows && !(h->opt.flags & YCNR_FLAG_NO_OVERLAP) && !env_flags().noOverlap) {
         dp.nSide = kSideStreams;
-        dp.fork = h->evFork;
+        dp.fork = part.fork;
         for (int i = 0; i < kSideStreams; ++i) {
           dp.side[i] = h->sideStream[i];
-          dp.join[i] = h->evJoin[i];
+          dp.join[i] = part.join[i];
         }
       }
     }
     if (h->opt.factorsCount > kMaxFactors) {
-      int rc = launch_step_big(a, S.nUnits, S.nSlabs, S.nSplit, h->stream, part.ev, dp);
+      int rc = launch_step_big(a, S.nUnits, S.nSlabs, S.nSplit, stream, part.ev, dp);
       if (rc || !h->kPad) return rc;
       // the piece's solved rows back into the caller's matrix (before its exchange)
       const int64_t nr = R.rowEnd - R.rowBegin, n = nr * h->opt.factorsCount;
       if (n > 0) {
-        hipLaunchKernelGGL(unpad_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, (const float *)h->padded[side],
+        hipLaunchKernelGGL(unpad_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const float *)h->padded[side],
                            (float *)h->factors[side], R.rowBegin, nr, h->opt.factorsCount, h->kPad);
         HIP_TRY(hipGetLastError());
       }
       return YCNR_OK;
     }
-    return launch_step<float>(a, S.nUnits, S.nSlabs, S.nSplit, h->stream, part.ev, (h->opt.flags & YCNR_FLAG_LDS_SOLVER) != 0, dp,
+    return launch_step<float>(a, S.nUnits, S.nSlabs, S.nSplit, stream, part.ev, (h->opt.flags & YCNR_FLAG_LDS_SOLVER) != 0, dp,
                               use_valu_edge(h->opt), use_slab_x6(h->opt, side));
   }
   StepArgs<double> a{S.dUnits, S.dSplit, R.dIndx, (const double *)R.dVals, (const double *)h->factors[1 - side],
                      (const double *)h->dZeros, (double *)h->factors[side], (double *)S.dSlabs, h->dErr, lambda, h->opt.factorsCount, 0, 0, 0u};
-  return launch_step<double>(a, S.nUnits, S.nSlabs, S.nSplit, h->stream, part.ev, (h->opt.flags & YCNR_FLAG_LDS_SOLVER) != 0);
+  return launch_step<double>(a, S.nUnits, S.nSlabs, S.nSplit, stream, part.ev, (h->opt.flags & YCNR_FLAG_LDS_SOLVER) != 0);
 }
 
 // row ranges of piece c of every rank (sharded upload)
@@ -1467,7 +1496,6 @@ int ycnr_als_step_async(ycnr_als *h, int side) {
   std::vector<Part> &parts = h->parts[side];
   if (parts.empty()) return fail(YCNR_ERR_STATE, "step: set_ratings was not called for this side");
   HIP_TRY(hipSetDevice(h->opt.device));
-  HIP_TRY(hipMemsetAsync(h->dErr, 0, sizeof(ErrInfo), h->stream));
   // With a communicator and a sharded upload the half-step includes its exchange: the rows of piece
   // c travel (on the communicator's stream) while piece c + 1 is being solved, and the step's
   // stream waits for the last piece to land -- the next half-step reads the whole matrix.
@@ -1492,22 +1520,38 @@ int ycnr_als_step_async(ycnr_als *h, int side) {
     return fail(YCNR_ERR_STATE, "step: the sharded upload of this side was made for another communicator (bounds of %zu values, world %d x %zu pieces)",
                 h->bounds[side].size(), h->comm.world, parts.size());
   h->exchangedInStep = exchange;
+  if (exchange)
+    if (int rcb = ipc_enter(h->comm)) return rcb;  // push transport: no peer is still preparing its replica
   memset(&h->info, 0, sizeof h->info);
   std::vector<int64_t> xb, xe;
+  // several pieces: alternating over the two piece streams (unless YCNR_FLAG_NO_OVERLAP / the staged SHM stand-in,
+  // whose exchange blocks the host); one piece: on the step's stream itself
+  const bool twoStreams = parts.size() > 1 && !(h->opt.flags & YCNR_FLAG_NO_OVERLAP) && !env_flags().noOverlap &&
+                          !(exchange && h->comm.transport == YCNR_COMM_SHM);
+  if (twoStreams) {
+    HIP_TRY(hipEventRecord(h->evStepStart, h->stream));
+    for (int i = 0; i < 2; ++i) HIP_TRY(hipStreamWaitEvent(h->pieceStream[i], h->evStepStart, 0));
+  }
   for (size_t c = 0; c < parts.size(); ++c) {
-    int rc = launch_part(h, side, parts[c]);
+    hipStream_t ps = twoStreams ? h->pieceStream[c & 1] : h->stream;
+    int rc = launch_part(h, side, parts[c], ps);
     if (rc) return rc;
     if (exchange) {
       part_ranges(h, side, (int)c, xb, xe);
-      rc = comm_exchange(h->comm, h->factors[side], side, h->opt.factorsCount, h->ts(), xb.data(), xe.data(), h->stream, parts[c].ready,
+      rc = comm_exchange(h->comm, h->factors[side], side, h->opt.factorsCount, h->ts(), xb.data(), xe.data(), ps, parts[c].ready,
                          parts[c].x0, parts[c].x1, &h->info.exchangeBytes);
       if (rc) return rc;
+    }
+    if (twoStreams && c + 2 >= parts.size()) {  // the last piece of each stream joins the step's stream
+      HIP_TRY(hipEventRecord(parts[c].done, ps));
+      HIP_TRY(hipStreamWaitEvent(h->stream, parts[c].done, 0));
     }
   }
   if (exchange) {
     HIP_TRY(hipEventRecord(h->evComputeEnd, h->stream));
     if (h->comm.transport != YCNR_COMM_SHM) HIP_TRY(hipStreamWaitEvent(h->stream, parts.back().x1, 0));  // (SHM is synchronous)
   }
+  HIP_TRY(hipMemcpyAsync(h->hErr, h->dErr, sizeof(ErrInfo), hipMemcpyDeviceToHost, h->stream));
   h->info.struct_size = (int32_t)sizeof(ycnr_als_step_info);
   h->info.side = side;
   h->info.parts = (int32_t)parts.size();
@@ -1558,8 +1602,11 @@ int ycnr_als_sync(ycnr_als *h) {
       }
     }
     if (!parts.empty()) {
-      HIP_TRY(hipEventElapsedTime(&ms, parts.front().ev[0], parts.back().ev[4]));
-      h->info.totalMs = ms;
+      h->info.totalMs = 0;
+      for (const Part &p : parts) {  // (pieces run two at a time: the last one need not end last)
+        HIP_TRY(hipEventElapsedTime(&ms, parts.front().ev[0], p.ev[4]));
+        h->info.totalMs = std::max(h->info.totalMs, ms);
+      }
       if (h->exchangedInStep) {
         if (h->comm.transport != YCNR_COMM_SHM) {
           // what the step's stream still had to wait for after its own last kernel
@@ -1572,8 +1619,9 @@ int ycnr_als_sync(ycnr_als *h) {
         }
       }
     }
-    ErrInfo ei{};
-    HIP_TRY(hipMemcpy(&ei, h->dErr, sizeof ei, hipMemcpyDeviceToHost));
+    ErrInfo ei = *h->hErr;  // copied by the step's stream, which has drained
+    ei.count -= h->errSeen;
+    h->errSeen += ei.count;
     h->info.numericErrors = ei.count;
 #ifdef YCNR_WG_STAMPS
     if (const char *path = getenv("YCNR_DUMP_STAMPS")) {
@@ -1743,6 +1791,7 @@ int ycnr_als_exchange(ycnr_als *h, int side) {
     e[(size_t)r] = h->bounds[side][(size_t)r * (np + 1) + np];
   }
   Part &p0 = h->parts[side][0];
+  if (int rcb = ipc_enter(h->comm)) return rcb;
   int rc = comm_exchange(h->comm, h->factors[side], side, h->opt.factorsCount, h->ts(), b.data(), e.data(), h->stream, p0.ready, p0.x0, p0.x1, nullptr);
   if (rc) return rc;
   if (h->comm.transport != YCNR_COMM_SHM) HIP_TRY(hipStreamSynchronize(h->comm.stream));
