@@ -33,6 +33,9 @@ WORKLOADS = {
     "mal": (1_750_000, 12_700, 121_000_000, 100, 10, 0.6, 1.2, "MAL-scale synthetic 1.75Mx12.7K, 121M nnz, k=100"),
     "mal96": (1_750_000, 12_700, 121_000_000, 96, 10, 0.6, 1.2, "MAL-scale synthetic 1.75Mx12.7K, 121M nnz, k=96 (kernel experiments)"),
     "c3": (200_000, 20_000, 20_000_000, 64, 10, 0.8, 1.0, "synthetic 200Kx20K, 20M nnz, k=64"),
+    # the any-k path (als_gen_kernels.hip.h): float32 beyond 256 factors; with --double, float64 beyond 128
+    "c3k512": (200_000, 20_000, 20_000_000, 512, 10, 0.8, 1.0, "synthetic 200Kx20K, 20M nnz, k=512 (any-k path)"),
+    "c3k256": (200_000, 20_000, 20_000_000, 256, 10, 0.8, 1.0, "synthetic 200Kx20K, 20M nnz, k=256 (with --double: any-k path)"),
     "c5": (10_000_000, 100_000, 1_000_000_000, 256, 10, 0.7, 1.0, "synthetic 10Mx100K, 1B nnz, k=256"),
     "c5shard": (1_250_000, 100_000, 125_000_000, 256, 10, 0.7, 1.0, "one GPU's eighth of the 10Mx100K, 1B nnz, k=256 config (1.25Mx100K, 125M nnz)"),
     "ml1m": (6040, 3883, 1_000_209, 100, 5, 0.9, 0.9, "MovieLens-1M-shaped synthetic 6040x3883, 1M nnz, k=100"),
@@ -180,7 +183,7 @@ def main():
         # bf16x6 Gramian: the LDS-DMA kernels (k % 4 == 0, k <= 112, fixed matrix < 2 GB) and the
         # workgroup-per-row kernels of k > 128 (als_wg_*, any fixed matrix size)
         fixed_rows = items if side == "byUser" else users
-        return (not args.double) and (k > 128 or (k % 4 == 0 and k <= 112 and fixed_rows * k * 4 < 2 ** 31))
+        return (not args.double) and (128 < k <= 256 or (k % 4 == 0 and k <= 112 and fixed_rows * k * 4 < 2 ** 31))
 
     for st in lord.stepTimes:
         i = st["info"]

@@ -227,6 +227,66 @@ def test_every_row_length_class(als, k):
         assert (err <= np.maximum(16 * conds * EPS32, 2e-6)).all()
 
 
+@pytest.mark.parametrize("k,dt", [(129, np.float64), (200, np.float64), (256, np.float64), (320, np.float64), (512, np.float64),
+                                  (257, np.float32), (320, np.float32), (333, np.float32), (512, np.float32)])
+def test_any_factors_count(als, oracle, k, dt, monkeypatch):
+    """The reference accepts any factorsCount in either precision (lib/emf/EmfBase.js:112, config/config-base.js:31;
+    lib/emf/EmfWorker.js:200-246).  Beyond what registers and LDS hold -- float64 above 128 factors, float32 above
+    256 -- the normal matrix lives in global memory (als_gen_kernels.hip.h): rows of every kind (empty, 1 rating,
+    fewer ratings than factors -- the float32 dual classes --, more, split over several chunks and several
+    BATCHES of the slab arena) against the float64 oracle, both half-steps, the level-1 portion op, bitwise
+    repeatability."""
+    monkeypatch.setenv("YCNR_GEN_ARENA_MB", "8")  # a k = 512 image is 0.5 / 1 MB: several batches
+    users, items = 60, 400
+    # (float32: rows of at most 176 ratings take the dual classes, whatever k; the longer ones the any-k kernels)
+    lens = [0, 1, 2, 15, 16, 17, 40, 90, 33, 64, 5, 77, 176, 177, 200, 260, 333] + [int(x) for x in np.random.default_rng(k).integers(1, 91, users - 17)]
+    rng = np.random.default_rng(5 * k)
+    rowPtr = np.zeros(users + 1, np.int64)
+    rowPtr[1:] = np.cumsum(lens)
+    indx = np.concatenate([np.sort(rng.choice(items, n, replace=False)) for n in lens]).astype(np.int32)
+    vals = rng.integers(1, 11, rowPtr[-1]).astype(dt)
+    bu = Csr(users, items, rowPtr, indx, vals)
+    # the same ratings by item
+    order = np.lexsort((np.repeat(np.arange(users), lens), indx))
+    bi = Csr(items, users, np.concatenate([[0], np.cumsum(np.bincount(indx, minlength=items))]).astype(np.int64),
+             np.repeat(np.arange(users), lens)[order].astype(np.int32), vals[order])
+    U = (rng.standard_normal((users, k)) / k).astype(dt)
+    V = (rng.standard_normal((items, k)) / np.sqrt(k)).astype(dt)
+    dbl = dt == np.float64
+    dev = als.AlsDevice(k, users, items, useDoublePrecision=dbl, chunkRatings=32)  # rows above 32 ratings: several chunks
+    dev.set_ratings("byUser", bu.rowPtr, bu.indx, bu.vals)
+    dev.set_ratings("byItem", bi.rowPtr, bi.indx, bi.vals)
+    dev.set_factors("byUser", U)
+    dev.set_factors("byItem", V)
+    iu = dev.step("byUser")
+    assert iu.numericErrors == 0 and iu.rows == users - 1 and iu.ratings == bu.nnz
+    U1 = dev.get_factors("byUser")
+    assert np.array_equal(U1[0], U[0])  # the row without ratings
+    Uo = U.astype(np.float64)
+    oracle.als_step_csr(0.05, k, bu.rowPtr, bu.indx, bu.vals.astype(np.float64), V.astype(np.float64), Uo)
+    want, conds = numpy_step(0.05, k, bu, V, U)
+    assert row_rel_err(want, Uo).max() < 1e-9          # the two float64 references agree
+    check_rows(U1, want, conds, dt)
+    ii = dev.step("byItem")  # sees the new user factors
+    assert ii.numericErrors == 0
+    V1 = dev.get_factors("byItem")
+    want_i, conds_i = numpy_step(0.05, k, bi, U1, V)
+    check_rows(V1, want_i, conds_i, dt)
+    # repeat from the same start: bitwise the same (fixed slab order, fixed tile ownership)
+    dev.set_factors("byUser", U)
+    dev.set_factors("byItem", V)
+    dev.step("byUser")
+    assert np.array_equal(dev.get_factors("byUser"), U1)
+    dev.destroy()
+    # level 1: the same rows through the portion op
+    from ycnr_als.data import csr_to_portion
+    rows, pi, pv = csr_to_portion(bu, 0, users)
+    s2 = U.copy()
+    assert als.als_calc_portion(0.05, k, rows, pi, pv, V, s2) == bu.nnz
+    check_rows(s2, want, conds, dt)
+    assert np.array_equal(s2[0], U[0])
+
+
 @pytest.mark.parametrize("k", [4, 8, 12, 16, 24, 32, 48, 52, 80, 96, 108, 112])
 def test_lds_dma_gramian_every_block_count(als, k):
     """The LDS-DMA staged bf16x6 Gramian (k % 4 == 0, k <= 112) at every block count, with the
@@ -530,10 +590,7 @@ def test_rmse_portions(als, oracle, dt):
 def test_errors_are_reported_not_fatal(als):
     from ycnr_als import YcnrError, _lib
     with pytest.raises(YcnrError) as e:
-        als.AlsDevice(257, 10, 10)
-    assert e.value.code == _lib.ERR_UNSUPPORTED
-    with pytest.raises(YcnrError) as e:
-        als.AlsDevice(129, 10, 10, useDoublePrecision=True)  # float64 stops at 128
+        als.AlsDevice(4097, 10, 10)  # any factorsCount up to 4096 (test_any_factors_count), in either precision
     assert e.value.code == _lib.ERR_UNSUPPORTED
     dev = als.AlsDevice(8, 4, 5)
     with pytest.raises(YcnrError) as e:

@@ -7,6 +7,7 @@
 #include "../../include/ycnr_als.h"
 #include "als_kernels.hip.h"
 #include "als_wg_kernels.hip.h"
+#include "als_gen_kernels.hip.h"
 #include "prep_kernels.hip.h"
 #include <hipcub/hipcub.hpp>
 #include "prep_kernels.hip.h"
@@ -50,13 +51,16 @@ int fail(int code, const char *fmt, ...) {
 
 constexpr int kMaxFactors = 128;     // float64, and the one-wave-per-row float32 kernels
 constexpr int kMaxFactorsBig = 256;  // float32 through the workgroup-per-row kernels of als_wg_kernels.hip.h
+constexpr int kMaxFactorsAny = 4096; // beyond kMaxFactorsBig (float64: kMaxFactors): the any-k path of als_gen_kernels.hip.h
+constexpr int kGenChunk = 4096;      // ratings per unit of the any-k path (als_gen_kernels.hip.h): every row goes through slabs there
+constexpr int64_t kGenArenaBytes = (int64_t)2 << 30;  // slab arena of that path: rows are solved in batches that fit it
 constexpr int kWgChunk = 8192;       // ratings per chunk of a row that is split over workgroups (k > 128)
 constexpr int kWgFusedMax = 16384;   // longest row one workgroup takes whole (k > 128)
 constexpr int kDefaultChunk = 1024;  // ratings per split unit (and the largest fused row)
 constexpr int kMaxSlabsPerRow = 64;  // heavier rows get proportionally longer chunks
 constexpr int64_t kBandBytes = (int64_t)96 << 20;  // slice of the fixed matrix one band of chunks gathers from (cache-sized)
 constexpr size_t kErrBytes = 65536;
-constexpr size_t kZeroRowBytes = 2048;  // >= kMaxFactors doubles
+constexpr size_t kZeroRowBytes = 32768 + 64;  // >= kMaxFactorsAny doubles: the "row" the dual kernels gather for ratings past a row's end
 constexpr int kMaxDualBlocks = 11;       // dual-form kernels exist for 1..11 blocks of 16 ratings (12 spills 1452 bytes per lane)
 constexpr int kMaxDualBlocksSmallK = 5;  // k <= 128: beyond 80 ratings the row kernel (k x k) is cheaper (MAL scale, k = 100: 6 -> 5 blocks took 0.2 ms off the user half-step once the solve had lost its readlanes and transposes; 4 was slower)
 
@@ -80,7 +84,32 @@ struct Ratings {
   }
 };
 
+// a batch of the any-k path: split rows [firstSplit, +nSplit) with their units = slabs [slabBase, +nSlabs)
+struct GenBatch {
+  int32_t firstSplit, nSplit, slabBase, nSlabs;
+};
+
+// the any-k path (als_gen_kernels.hip.h): float32 beyond 256 factors, float64 beyond 128
+bool is_gen(int dtype, int k) { return k > (dtype == YCNR_F32 ? kMaxFactorsBig : kMaxFactors); }
+
+// Batches of consecutive split rows whose slabs fit `arenaSlabs` (at least one row per batch).
+std::vector<GenBatch> gen_batches(const std::vector<SplitRow> &split, int64_t arenaSlabs) {
+  std::vector<GenBatch> out;
+  size_t i = 0;
+  while (i < split.size()) {
+    GenBatch b{(int32_t)i, 0, split[i].slab0, 0};
+    while (i < split.size() && (b.nSplit == 0 || b.nSlabs + split[i].nslabs <= arenaSlabs)) {
+      b.nSlabs += split[i].nslabs;
+      ++b.nSplit;
+      ++i;
+    }
+    out.push_back(b);
+  }
+  return out;
+}
+
 struct Schedule {
+  std::vector<GenBatch> genBatches;
   Unit *dUnits = nullptr;
   SplitRow *dSplit = nullptr;
   void *dSlabs = nullptr;
@@ -98,6 +127,7 @@ struct Schedule {
     dSlabs = nullptr;
     nUnits = nSplit = nSlabs = solvedRows = fusedRatings = nPrimal = dualRows = dualRatings = 0;
     dualFlops = 0;
+    genBatches.clear();
     for (int m = 0; m <= kMaxDualBlocks; ++m) dualFirst[m] = dualCount[m] = 0;
   }
 };
@@ -440,6 +470,45 @@ int launch_step_big(const StepArgs<float> &args, int64_t nUnits, int64_t nSplitU
     case 16: return launch_wg_nb<16>(args, nSplitUnits, nPrimal, nSplit, stream, ev, dp);
     default: return fail(YCNR_ERR_UNSUPPORTED, "factorsCount %d is outside the workgroup-per-row path", args.k);
   }
+}
+
+// any factorsCount (als_gen_kernels.hip.h): batches of [Gramians -> slabs] [slabs -> solve], then the dual classes
+// (float32: rows of at most 176 ratings, whose n x n form does not depend on k)
+template <typename T>
+int launch_step_gen(const StepArgs<T> &args, const std::vector<GenBatch> &batches, hipStream_t stream, hipEvent_t *ev, const DualPlan &dp) {
+  GenArgs<T> ga{args, (args.k + 15) / 16, 0, 0, 0};
+  const size_t lds = gen_solve_lds_bytes(ga.nb, sizeof(T));
+  if (lds > 160 * 1024) return fail(YCNR_ERR_UNSUPPORTED, "factorsCount %d: the right-hand side does not fit a CU's LDS", args.k);
+  if (int rc = set_max_lds(reinterpret_cast<const void *>(als_gen_solve_kernel<T>), lds)) return rc;
+  if (ev) HIP_TRY(hipEventRecord(ev[0], stream));
+  for (const GenBatch &b : batches) {
+    ga.slabBase = b.slabBase;
+    ga.firstUnit = b.slabBase;  // units of split rows are numbered like their slabs
+    ga.firstSplit = b.firstSplit;
+    hipLaunchKernelGGL(als_gen_gram_kernel<T>, dim3((unsigned)b.nSlabs), dim3(kGenThreads), 0, stream, ga);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(als_gen_solve_kernel<T>, dim3((unsigned)b.nSplit), dim3(kGenThreads), lds, stream, ga);
+    HIP_TRY(hipGetLastError());
+  }
+  if (ev) {
+    HIP_TRY(hipEventRecord(ev[1], stream));
+    HIP_TRY(hipEventRecord(ev[2], stream));
+  }
+  if constexpr (std::is_same<T, float>::value) {
+    if (dp.nPrimal >= 0) {
+      DualPlan serial = dp;
+      serial.nSide = 0;
+      StepArgs<float> a2 = args;
+      a2.firstFused = 0;
+      int rc = launch_duals<float>(a2, serial, stream);
+      if (rc) return rc;
+    }
+  }
+  if (ev) {
+    HIP_TRY(hipEventRecord(ev[3], stream));
+    HIP_TRY(hipEventRecord(ev[4], stream));
+  }
+  return YCNR_OK;
 }
 
 template <typename T>
@@ -1009,9 +1078,8 @@ int ycnr_als_create(const ycnr_als_options *o, ycnr_als **out) {
                 sizeof(ycnr_als_options));
   if (o->dtype != YCNR_F32 && o->dtype != YCNR_F64) return fail(YCNR_ERR_INVALID, "bad dtype %d", o->dtype);
   if (o->factorsCount < 1) return fail(YCNR_ERR_INVALID, "factorsCount must be >= 1");
-  if (o->factorsCount > (o->dtype == YCNR_F32 ? kMaxFactorsBig : kMaxFactors))
-    return fail(YCNR_ERR_UNSUPPORTED, "factorsCount %d > %d is not supported by this build for %s", o->factorsCount,
-                o->dtype == YCNR_F32 ? kMaxFactorsBig : kMaxFactors, o->dtype == YCNR_F32 ? "float32" : "float64");
+  if (o->factorsCount > kMaxFactorsAny)
+    return fail(YCNR_ERR_UNSUPPORTED, "factorsCount %d > %d is not supported by this build", o->factorsCount, kMaxFactorsAny);
   if (o->totalUsersCount < 1 || o->totalItemsCount < 1 || o->totalUsersCount > 0x7fffffffLL ||
       o->totalItemsCount > 0x7fffffffLL)
     return fail(YCNR_ERR_INVALID, "totalUsersCount / totalItemsCount must be in [1, 2^31)");
@@ -1041,7 +1109,7 @@ int ycnr_als_create(const ycnr_als_options *o, ycnr_als **out) {
       e = hipMemsetAsync(h->factors[s], 0, (size_t)h->rows(s) * o->factorsCount * h->ts(), h->ownStream);
     }
   }
-  if (o->factorsCount > kMaxFactors && o->factorsCount % 4 != 0) {
+  if (o->dtype == YCNR_F32 && o->factorsCount > kMaxFactors && o->factorsCount % 4 != 0) {
     h->kPad = (o->factorsCount + 3) & ~3;
     for (int s = 0; s < 2 && e == hipSuccess; ++s) e = hipMalloc(&h->padded[s], (size_t)h->rows(s) * h->kPad * sizeof(float));
   }
@@ -1160,12 +1228,16 @@ static int build_part(ycnr_als *h, int side, const int64_t *rowPtr, const int32_
   std::vector<Unit> units;
   std::vector<SplitRow> split;
   int64_t nSlabs = 0, solved = 0;
-  const bool big = h->opt.factorsCount > kMaxFactors;
+  const bool gen = is_gen(h->opt.dtype, h->opt.factorsCount);  // any-k path: every primal row through slabs, in row order
+  const bool big = !gen && h->opt.factorsCount > kMaxFactors;
   // k > 128: a unit is a whole workgroup's work, so chunks are long (a slab is 140 KB at k = 256)
   // (an explicit options.chunkRatings is honoured there too: tests cut short rows into chunks with it)
-  const int chunkRatings = h->autoChunk ? (big ? kWgChunk : auto_chunk(hp[rowEnd - rowBegin] - hp[0])) : h->opt.chunkRatings;
-  build_schedule(hp.data(), rowBegin, rowEnd - rowBegin, chunkRatings, units, split, nSlabs, solved, -1,
-                 big && h->autoChunk ? kWgFusedMax : std::min(chunkRatings, h->opt.chunkRatings));
+  const int chunkRatings = h->autoChunk ? (gen ? kGenChunk : big ? kWgChunk : auto_chunk(hp[rowEnd - rowBegin] - hp[0])) : h->opt.chunkRatings;
+  if (gen)
+    build_schedule(hp.data(), rowBegin, rowEnd - rowBegin, chunkRatings, units, split, nSlabs, solved, dual_max_ratings(h->opt), 0);
+  else
+    build_schedule(hp.data(), rowBegin, rowEnd - rowBegin, chunkRatings, units, split, nSlabs, solved, -1,
+                   big && h->autoChunk ? kWgFusedMax : std::min(chunkRatings, h->opt.chunkRatings));
   int64_t arenaSlabs = nSlabs;
   // Band-major chunks (unless YCNR_FLAG_NO_BANDS): when the fixed matrix is far larger than the
   // last-level cache, cut every split row at the same column-id boundaries ("bands" of
@@ -1178,7 +1250,7 @@ static int build_part(ycnr_als *h, int side, const int64_t *rowPtr, const int32_
     const int64_t rowBytes = (int64_t)h->opt.factorsCount * (int64_t)h->ts();
     int64_t bandBytes = kBandBytes;
     if (const char *e = getenv("YCNR_BAND_MB")) bandBytes = (int64_t)atoi(e) << 20;  // per upload, not per half-step: read live (tests set it)
-    if (!big && nSlabs > 1 && !(h->opt.flags & YCNR_FLAG_NO_BANDS) && bandBytes > 0 && fixedRows * rowBytes > 2 * bandBytes) {
+    if (!big && !gen && nSlabs > 1 && !(h->opt.flags & YCNR_FLAG_NO_BANDS) && bandBytes > 0 && fixedRows * rowBytes > 2 * bandBytes) {
       // at most kMaxSlabsPerRow / 2 bands, so that a row present in every band still has chunks to
       // spare (very large fixed matrices get wider bands instead of a failed upload)
       const int64_t W = std::max<int64_t>(std::max<int64_t>(1, bandBytes / rowBytes), (fixedRows + kMaxSlabsPerRow / 2 - 1) / (kMaxSlabsPerRow / 2));
@@ -1278,11 +1350,21 @@ static int build_part(ycnr_als *h, int side, const int64_t *rowPtr, const int32_
   if (S.nSplit) {
     // the reduce kernel takes the rows in this order, one wave each: rows with the most slabs first, so that
     // the 64-slab rows of the most popular items do not start when everything else has finished
-    if (!big)
+    if (!big && !gen)
       std::stable_sort(split.begin(), split.end(), [](const SplitRow &x, const SplitRow &y) { return x.nslabs > y.nslabs; });
     HIP_TRY(hipMalloc(&S.dSplit, sizeof(SplitRow) * split.size()));
     HIP_TRY(hipMemcpy(S.dSplit, split.data(), sizeof(SplitRow) * split.size(), hipMemcpyHostToDevice));
-    const size_t slabElems = big ? (size_t)wg_slab_floats(slab_nb(h->opt.factorsCount)) : (size_t)slab_regs(h->opt, side) * 64;
+    const size_t slabElems = gen ? (size_t)gen_slab_elems(slab_nb(h->opt.factorsCount))
+                                 : big ? (size_t)wg_slab_floats(slab_nb(h->opt.factorsCount)) : (size_t)slab_regs(h->opt, side) * 64;
+    if (gen) {
+      // rows are solved in batches whose slabs fit the arena (a k = 512 float32 image is 541 KB)
+      int64_t arenaBytes = kGenArenaBytes;
+      if (const char *e = getenv("YCNR_GEN_ARENA_MB")) arenaBytes = (int64_t)std::max(1, atoi(e)) << 20;  // tests force several batches
+      const int64_t fit = std::max<int64_t>(1, arenaBytes / (int64_t)(slabElems * h->ts()));
+      S.genBatches = gen_batches(split, fit);
+      arenaSlabs = 0;
+      for (const GenBatch &b : S.genBatches) arenaSlabs = std::max<int64_t>(arenaSlabs, b.nSlabs);
+    }
     HIP_TRY(hipMalloc(&S.dSlabs, (size_t)arenaSlabs * slabElems * h->ts()));
   }
   return YCNR_OK;
@@ -1460,7 +1542,8 @@ static int launch_part(ycnr_als *h, int side, Part &part, hipStream_t stream) {
       }
     }
     if (h->opt.factorsCount > kMaxFactors) {
-      int rc = launch_step_big(a, S.nUnits, S.nSlabs, S.nSplit, stream, part.ev, dp);
+      int rc = is_gen(YCNR_F32, h->opt.factorsCount) ? launch_step_gen<float>(a, S.genBatches, stream, part.ev, dp)
+                                                     : launch_step_big(a, S.nUnits, S.nSlabs, S.nSplit, stream, part.ev, dp);
       if (rc || !h->kPad) return rc;
       // the piece's solved rows back into the caller's matrix (before its exchange)
       const int64_t nr = R.rowEnd - R.rowBegin, n = nr * h->opt.factorsCount;
@@ -1476,6 +1559,7 @@ static int launch_part(ycnr_als *h, int side, Part &part, hipStream_t stream) {
   }
   StepArgs<double> a{S.dUnits, S.dSplit, R.dIndx, (const double *)R.dVals, (const double *)h->factors[1 - side],
                      (const double *)h->dZeros, (double *)h->factors[side], (double *)S.dSlabs, h->dErr, lambda, h->opt.factorsCount, 0, 0, 0u};
+  if (is_gen(YCNR_F64, h->opt.factorsCount)) return launch_step_gen<double>(a, S.genBatches, stream, part.ev, DualPlan());
   return launch_step<double>(a, S.nUnits, S.nSlabs, S.nSplit, stream, part.ev, (h->opt.flags & YCNR_FLAG_LDS_SOLVER) != 0);
 }
 
@@ -1962,10 +2046,10 @@ int64_t als_calc_portion(double lambda, int k, const int32_t *alsRows, const int
   if (!alsRows || !alsIndx || !alsVals || !fixedFactors || !solvedFactors)
     return fail(YCNR_ERR_INVALID, "AlsCalcPortion: null argument");
   if (k < 1) return fail(YCNR_ERR_INVALID, "AlsCalcPortion: k < 1");
-  const bool big = k > kMaxFactors;
-  if (k > (dtype == YCNR_F32 ? kMaxFactorsBig : kMaxFactors) || (big && k % 4 != 0))
-    return fail(YCNR_ERR_UNSUPPORTED, "factorsCount %d is not supported for %s by this build (float32: <= %d, multiples of 4 above %d; float64: <= %d)",
-                k, dtype == YCNR_F32 ? "float32" : "float64", kMaxFactorsBig, kMaxFactors, kMaxFactors);
+  if (k > kMaxFactorsAny) return fail(YCNR_ERR_UNSUPPORTED, "factorsCount %d > %d is not supported by this build", k, kMaxFactorsAny);
+  // the any-k path also takes float32 rows that are not 16-byte multiples above 128 factors (the resident trainer pads those)
+  const bool gen = is_gen(dtype, k) || (k > kMaxFactors && k % 4 != 0);
+  const bool big = !gen && k > kMaxFactors;
   if (!(lambda >= 0)) return fail(YCNR_ERR_INVALID, "AlsCalcPortion: negative lambda");
   const int nRows = alsRows[0];
   if (nRows < 0) return fail(YCNR_ERR_INVALID, "AlsCalcPortion: alsRows[0] < 0");
@@ -2018,10 +2102,11 @@ int64_t als_calc_portion(double lambda, int k, const int32_t *alsRows, const int
   std::vector<Unit> units;
   std::vector<SplitRow> split;
   int64_t nSlabs = 0, solved = 0;
-  build_schedule(rowPtr.data(), 0, nRows, big ? kWgChunk : kDefaultChunk, units, split, nSlabs, solved, -1, big ? kWgFusedMax : 0);
+  build_schedule(rowPtr.data(), 0, nRows, gen ? kGenChunk : big ? kWgChunk : kDefaultChunk, units, split, nSlabs, solved, gen ? 0 : -1,
+                 big ? kWgFusedMax : 0);
 
   const int nb = slab_nb(k);
-  const size_t slabElems = big ? (size_t)wg_slab_floats(nb) : (size_t)slab_elems(nb);
+  const size_t slabElems = gen ? (size_t)gen_slab_elems(nb) : big ? (size_t)wg_slab_floats(nb) : (size_t)slab_elems(nb);
 #define L1_TRY(expr)                                                                                  \
   do {                                                                                                \
     hipError_t e_ = (expr);                                                                           \
@@ -2067,7 +2152,9 @@ int64_t als_calc_portion(double lambda, int k, const int32_t *alsRows, const int
     const T *dFixed = pinned ? (const T *)C.pinned.p : (const T *)(db + oFixed);
     StepArgs<T> a{(const Unit *)(db + oUnits), (const SplitRow *)(db + oSplit), (const int32_t *)(db + oIndx), (const T *)(db + oVals), dFixed, dZeros,
                   (T *)(db + oSolved), (T *)C.slabs.p, dErr, lambda, k, 0, 0, 0u};
-    if constexpr (std::is_same<T, float>::value) {
+    if (gen) {
+      rc = launch_step_gen<T>(a, gen_batches(split, std::max<int64_t>(1, nSlabs)), stream, nullptr, DualPlan());
+    } else if constexpr (std::is_same<T, float>::value) {
       if (big) rc = launch_step_big(a, (int64_t)units.size(), nSlabs, (int64_t)split.size(), stream, nullptr, DualPlan());
       else rc = launch_step<T>(a, (int64_t)units.size(), nSlabs, (int64_t)split.size(), stream, nullptr);
     } else {
