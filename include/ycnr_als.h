@@ -154,6 +154,11 @@ typedef struct ycnr_als_options {
  * of the handle, next to the row kernel, when a half-step has at least 1024 such rows; they fork
  * from and join the handle's stream, so the half-step still begins and ends in stream order. */
 #define YCNR_FLAG_NO_OVERLAP 64
+/* options.flags: launch every half-step kernel by kernel.  Default: uploads below 2 M ratings (the ML-100k / ML-1M
+ * shapes), whose half-step is a dozen launches of kernels that each fill a fraction of the chip, are captured
+ * once into a hipGraph -- chunk Gramians -> reduce, the row kernel and the dual classes as parallel branches -- and
+ * replayed with one launch per half-step; ycnr_als_step_info then reports one interval (gramSolveMs, dualOverlapped). */
+#define YCNR_FLAG_NO_GRAPH 128
 
 /* Timing / accounting of the last ycnr_als_step, measured with HIP events on the
  * handle's stream around each kernel (DESIGN.md "Measurement"). */

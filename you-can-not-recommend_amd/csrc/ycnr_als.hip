@@ -196,12 +196,13 @@ void build_schedule(const int64_t *rowPtr, int64_t rowBegin, int64_t nRows, int 
 
 // environment toggles for A/B experiments from unmodified hosts, read once per process
 struct EnvFlags {
-  bool noDualX6, noX6d, noFusedX6d, noOverlap, ignoreNumeric, noDualQuad;
+  bool noDualX6, noX6d, noFusedX6d, noOverlap, ignoreNumeric, noDualQuad, noGraph;
   size_t k1LdsPad;
 };
 const EnvFlags &env_flags() {
   static const EnvFlags f = {getenv("YCNR_NO_DUAL_X6") != nullptr, getenv("YCNR_NO_X6D") != nullptr, getenv("YCNR_NO_FUSED_X6D") != nullptr,
                              getenv("YCNR_NO_OVERLAP") != nullptr, getenv("YCNR_IGNORE_NUMERIC") != nullptr, getenv("YCNR_NO_DUAL_QUAD") != nullptr,
+                             getenv("YCNR_NO_GRAPH") != nullptr,
                              getenv("YCNR_K1_LDSPAD") ? (size_t)atoi(getenv("YCNR_K1_LDSPAD")) : 0};
   return f;
 }
@@ -221,6 +222,9 @@ int set_max_lds(const void *fn, size_t bytes) {
 }
 
 constexpr int kSideStreams = 2;
+constexpr int64_t kGraphMaxRatings = 2 * 1024 * 1024;  // uploads below this replay their half-step as a captured hipGraph ...
+constexpr int64_t kGraphMinRatings = 256 * 1024;       // ... unless they are so small that the graph launch itself costs more than four
+                                                        // kernel launches (ML-100k shape: 0.124 ms per iteration launch by launch, 0.174 as graphs)
 constexpr int64_t kMinOverlapDualRows = 1024;  // fewer dual-form rows than this: everything in stream order
 
 struct DualPlan {
@@ -236,6 +240,12 @@ struct DualPlan {
   hipStream_t side[kSideStreams] = {};
   hipEvent_t fork = nullptr, join[kSideStreams] = {};
   mutable int nextSide = 0;
+  // Small uploads (a half-step of a few kernels that each fill a fraction of the chip): the chunk Gramians and the
+  // reduce that consumes their slabs go to a branch of their own, next to the row kernel and the dual classes
+  // -- only the reduce depends on the chunks.  The whole half-step is then captured once into a hipGraph and
+  // replayed (ycnr_als_step_async), so the forks and joins cost nothing per half-step.
+  hipStream_t slabStream = nullptr;
+  hipEvent_t slabJoin = nullptr;
 };
 
 template <int M>
@@ -333,15 +343,25 @@ int launch_nbe(StepArgs<T> args, int64_t nUnits, int64_t nSplitUnits, int64_t nS
   if (int rcl = set_max_lds(reinterpret_cast<const void *>(k2), lds)) return rcl;
   args.firstFused = (int32_t)nSplitUnits;
   if (ev) HIP_TRY(hipEventRecord(ev[0], stream));
-  if (nSplitUnits > 0) {
+  const bool branch = dp.slabStream != nullptr && nSplitUnits > 0;  // chunks -> reduce on their own branch
+  const int64_t nPrimal = dp.nPrimal >= 0 ? dp.nPrimal : nUnits - nSplitUnits;
+  const bool overlap = dp.nPrimal >= 0 && dp.nSide > 0;
+  if (branch || overlap) HIP_TRY(hipEventRecord(dp.fork, stream));
+  if (branch) {
+    HIP_TRY(hipStreamWaitEvent(dp.slabStream, dp.fork, 0));
+    hipLaunchKernelGGL(k0, dim3((unsigned)nSplitUnits), dim3(64), 0, dp.slabStream, args);
+    HIP_TRY(hipGetLastError());
+    if (nSplit > 0) {
+      hipLaunchKernelGGL(k2, dim3((unsigned)nSplit), dim3(64), lds, dp.slabStream, args);
+      HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(dp.slabJoin, dp.slabStream));
+  } else if (nSplitUnits > 0) {
     hipLaunchKernelGGL(k0, dim3((unsigned)nSplitUnits), dim3(64), 0, stream, args);
     HIP_TRY(hipGetLastError());
   }
   if (ev) HIP_TRY(hipEventRecord(ev[1], stream));
-  const int64_t nPrimal = dp.nPrimal >= 0 ? dp.nPrimal : nUnits - nSplitUnits;
-  const bool overlap = dp.nPrimal >= 0 && dp.nSide > 0;
   if (overlap) {  // dual classes first, on the side streams; then the row kernel on this one
-    HIP_TRY(hipEventRecord(dp.fork, stream));
     for (int i = 0; i < dp.nSide; ++i) HIP_TRY(hipStreamWaitEvent(dp.side[i], dp.fork, 0));
     dp.nextSide = 0;
     int rc = launch_duals<T>(args, dp, stream);
@@ -360,7 +380,9 @@ int launch_nbe(StepArgs<T> args, int64_t nUnits, int64_t nSplitUnits, int64_t nS
     if (rc) return rc;
   }
   if (ev) HIP_TRY(hipEventRecord(ev[3], stream));
-  if (nSplit > 0) {
+  if (branch) {
+    HIP_TRY(hipStreamWaitEvent(stream, dp.slabJoin, 0));
+  } else if (nSplit > 0) {
     hipLaunchKernelGGL(k2, dim3((unsigned)nSplit), dim3(64), lds, stream, args);
     HIP_TRY(hipGetLastError());
   }
@@ -661,13 +683,14 @@ struct Part {
   hipEvent_t ready = nullptr, x0 = nullptr, x1 = nullptr;
   // fork / join of the piece's dual-class launches on the handle's side streams, and "all kernels of the piece done":
   // per piece, because two pieces are in flight at a time (on the handle's two piece streams)
-  hipEvent_t fork = nullptr, join[kSideStreams] = {}, done = nullptr;
+  hipEvent_t fork = nullptr, join[kSideStreams] = {}, done = nullptr, slabJoin = nullptr;
   hipError_t create_events() {
     hipError_t e = hipSuccess;
     for (int i = 0; i < 5 && e == hipSuccess; ++i) e = hipEventCreate(&ev[i]);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&fork, hipEventDisableTiming);
     for (int i = 0; i < kSideStreams && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&join[i], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&done, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&slabJoin, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ready, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreate(&x0);
     if (e == hipSuccess) e = hipEventCreate(&x1);
@@ -683,12 +706,13 @@ struct Part {
     if (x1) (void)hipEventDestroy(x1);
     if (fork) (void)hipEventDestroy(fork);
     if (done) (void)hipEventDestroy(done);
+    if (slabJoin) (void)hipEventDestroy(slabJoin);
     for (int i = 0; i < kSideStreams; ++i) {
       if (join[i]) (void)hipEventDestroy(join[i]);
       join[i] = nullptr;
     }
     for (int i = 0; i < 5; ++i) ev[i] = nullptr;
-    ready = x0 = x1 = fork = done = nullptr;
+    ready = x0 = x1 = fork = done = slabJoin = nullptr;
   }
 };
 
@@ -705,6 +729,22 @@ struct ycnr_als {
   // 4 pieces in stream order: 2.5 ms against 2.0 ms in one piece).
   hipStream_t pieceStream[2] = {};
   hipEvent_t evStepStart = nullptr;
+  // Small uploads: the launches of a half-step captured once and replayed (hipGraph).  state: 0 = not run yet (the
+  // first half-step runs launch by launch: it sets function attributes), 1 = capture at the next one, 2 = exec is
+  // valid, -1 = capture failed once, stay with launches.  Dropped whenever something a kernel argument points
+  // at changes (upload, bound matrix, stream).
+  struct GraphSlot {
+    hipGraphExec_t exec = nullptr;
+    int state = 0;
+  } graph[2];
+  bool graphRun = false;  // the half-step in flight was a graph launch: only ev[0] / ev[4] of its piece are recorded
+  void drop_graphs() {
+    for (GraphSlot &g : graph) {
+      if (g.exec) (void)hipGraphExecDestroy(g.exec);
+      g.exec = nullptr;
+      g.state = 0;
+    }
+  }
   void *factors[2] = {nullptr, nullptr};
   bool ownFactors[2] = {false, false};
   int kPad = 0;                          // != 0: factorsCount padded to a multiple of 4 (k > 128, k % 4 != 0)
@@ -1135,6 +1175,7 @@ int ycnr_als_destroy(ycnr_als *h) {
   if (!h) return YCNR_OK;
   (void)hipSetDevice(h->opt.device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  h->drop_graphs();
   comm_release(h->comm);
   for (int s = 0; s < 2; ++s) {
     for (Part &p : h->parts[s]) p.release();
@@ -1169,6 +1210,7 @@ int ycnr_als_set_stream(ycnr_als *h, void *s) {
   if (!h) return fail(YCNR_ERR_INVALID, "null handle");
   HIP_TRY(hipSetDevice(h->opt.device));
   HIP_TRY(hipStreamSynchronize(h->stream));
+  h->drop_graphs();
   h->stream = s == YCNR_OWN_STREAM ? h->ownStream : (hipStream_t)s;  // NULL = the null (default) stream
   return YCNR_OK;
 }
@@ -1393,6 +1435,7 @@ static int set_ratings_parts(ycnr_als *h, int side, const int64_t *rowPtr, const
   }
   HIP_TRY(hipStreamSynchronize(h->stream));  // nothing in flight still reads the previous upload
   for (Part &p : h->parts[side]) p.release();
+  h->drop_graphs();
   h->parts[side].swap(pend.parts);
   pend.parts.clear();
   pend.keep = true;
@@ -1506,15 +1549,19 @@ int ycnr_als_bind_factors(ycnr_als *h, int side, void *p) {
   }
   HIP_TRY(hipStreamSynchronize(h->stream));
   if (h->ownFactors[side] && h->factors[side]) (void)hipFree(h->factors[side]);
+  h->drop_graphs();
   h->factors[side] = p;
   h->ownFactors[side] = false;
   return YCNR_OK;
 }
 
 // kernels of one piece of the shard, on the handle's stream, timed by the piece's events
-static int launch_part(ycnr_als *h, int side, Part &part, hipStream_t stream) {
+// branches: the small-upload form (chunks -> reduce, row kernel and dual classes as parallel branches, no per-kernel
+// timing events) that ycnr_als_step_async captures into a hipGraph
+static int launch_part(ycnr_als *h, int side, Part &part, hipStream_t stream, bool branches = false) {
   const Ratings &R = part.R;
   const Schedule &S = part.S;
+  hipEvent_t *ev = branches ? nullptr : part.ev;
   const double lambda = side == YCNR_BY_USER ? h->opt.userFactReg : h->opt.itemFactReg;
   if (h->opt.dtype == YCNR_F32) {
     const int kk = h->kPad ? h->kPad : h->opt.factorsCount;
@@ -1532,18 +1579,22 @@ static int launch_part(ycnr_als *h, int side, Part &part, hipStream_t stream) {
       dp.count = S.dualCount;
       // (the fork and join cost nine more runtime calls per half-step: with a few hundred rows,
       // where the half-step is bound by the launches themselves, they made it slower)
-      if (S.dualRows >= kMinOverlapDualRows && !(h->opt.flags & YCNR_FLAG_NO_OVERLAP) && !env_flags().noOverlap) {
+      if ((S.dualRows >= kMinOverlapDualRows || (branches && S.dualRows > 0)) && !(h->opt.flags & YCNR_FLAG_NO_OVERLAP) && !env_flags().noOverlap) {
         dp.nSide = kSideStreams;
-        dp.fork = part.fork;
         for (int i = 0; i < kSideStreams; ++i) {
           dp.side[i] = h->sideStream[i];
           dp.join[i] = part.join[i];
         }
       }
     }
+    dp.fork = part.fork;
+    if (branches) {
+      dp.slabStream = h->pieceStream[0];
+      dp.slabJoin = part.slabJoin;
+    }
     if (h->opt.factorsCount > kMaxFactors) {
-      int rc = is_gen(YCNR_F32, h->opt.factorsCount) ? launch_step_gen<float>(a, S.genBatches, stream, part.ev, dp)
-                                                     : launch_step_big(a, S.nUnits, S.nSlabs, S.nSplit, stream, part.ev, dp);
+      int rc = is_gen(YCNR_F32, h->opt.factorsCount) ? launch_step_gen<float>(a, S.genBatches, stream, ev, dp)
+                                                     : launch_step_big(a, S.nUnits, S.nSlabs, S.nSplit, stream, ev, dp);
       if (rc || !h->kPad) return rc;
       // the piece's solved rows back into the caller's matrix (before its exchange)
       const int64_t nr = R.rowEnd - R.rowBegin, n = nr * h->opt.factorsCount;
@@ -1554,13 +1605,19 @@ static int launch_part(ycnr_als *h, int side, Part &part, hipStream_t stream) {
       }
       return YCNR_OK;
     }
-    return launch_step<float>(a, S.nUnits, S.nSlabs, S.nSplit, stream, part.ev, (h->opt.flags & YCNR_FLAG_LDS_SOLVER) != 0, dp,
+    return launch_step<float>(a, S.nUnits, S.nSlabs, S.nSplit, stream, ev, (h->opt.flags & YCNR_FLAG_LDS_SOLVER) != 0, dp,
                               use_valu_edge(h->opt), use_slab_x6(h->opt, side));
   }
   StepArgs<double> a{S.dUnits, S.dSplit, R.dIndx, (const double *)R.dVals, (const double *)h->factors[1 - side],
                      (const double *)h->dZeros, (double *)h->factors[side], (double *)S.dSlabs, h->dErr, lambda, h->opt.factorsCount, 0, 0, 0u};
-  if (is_gen(YCNR_F64, h->opt.factorsCount)) return launch_step_gen<double>(a, S.genBatches, stream, part.ev, DualPlan());
-  return launch_step<double>(a, S.nUnits, S.nSlabs, S.nSplit, stream, part.ev, (h->opt.flags & YCNR_FLAG_LDS_SOLVER) != 0);
+  if (is_gen(YCNR_F64, h->opt.factorsCount)) return launch_step_gen<double>(a, S.genBatches, stream, ev, DualPlan());
+  DualPlan dpd;  // float64 has no dual classes; the chunk branch of the small-upload form applies
+  dpd.fork = part.fork;
+  if (branches) {
+    dpd.slabStream = h->pieceStream[0];
+    dpd.slabJoin = part.slabJoin;
+  }
+  return launch_step<double>(a, S.nUnits, S.nSlabs, S.nSplit, stream, ev, (h->opt.flags & YCNR_FLAG_LDS_SOLVER) != 0, dpd);
 }
 
 // row ranges of piece c of every rank (sharded upload)
@@ -1607,6 +1664,37 @@ int ycnr_als_step_async(ycnr_als *h, int side) {
   if (exchange)
     if (int rcb = ipc_enter(h->comm)) return rcb;  // push transport: no peer is still preparing its replica
   memset(&h->info, 0, sizeof h->info);
+  // Small uploads (the ML-100k / ML-1M shapes): ~15 launches, forks and joins of a half-step whose kernels each fill a
+  // fraction of the chip.  Captured once in the branch form (launch_part) and replayed: one launch per half-step.
+  h->graphRun = false;
+  {
+    ycnr_als::GraphSlot &gs = h->graph[side];
+    const bool graphable = !exchange && parts.size() == 1 && !h->kPad && h->opt.factorsCount <= kMaxFactors &&
+                           parts[0].R.nnz < kGraphMaxRatings && parts[0].R.nnz >= kGraphMinRatings && h->stream == h->ownStream &&
+                           !(h->opt.flags & (YCNR_FLAG_NO_OVERLAP | YCNR_FLAG_NO_GRAPH)) && !env_flags().noOverlap && !env_flags().noGraph;
+    if (graphable && gs.state == 1) {
+      gs.state = -1;
+      hipGraph_t g = nullptr;
+      if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed) == hipSuccess) {
+        int rc = launch_part(h, side, parts[0], h->stream, true);
+        hipError_t ce = hipMemcpyAsync(h->hErr, h->dErr, sizeof(ErrInfo), hipMemcpyDeviceToHost, h->stream);
+        hipError_t ee = hipStreamEndCapture(h->stream, &g);
+        if (rc == YCNR_OK && ce == hipSuccess && ee == hipSuccess && g && hipGraphInstantiate(&gs.exec, g, nullptr, nullptr, 0) == hipSuccess)
+          gs.state = 2;
+        if (g) (void)hipGraphDestroy(g);
+      }
+      (void)hipGetLastError();
+    } else if (graphable && gs.state == 0) {
+      gs.state = 1;
+    }
+    if (graphable && gs.state == 2) {
+      Part &p = parts[0];
+      HIP_TRY(hipEventRecord(p.ev[0], h->stream));
+      HIP_TRY(hipGraphLaunch(gs.exec, h->stream));
+      HIP_TRY(hipEventRecord(p.ev[4], h->stream));
+      h->graphRun = true;
+    }
+  }
   std::vector<int64_t> xb, xe;
   // several pieces: alternating over the two piece streams (unless YCNR_FLAG_NO_OVERLAP / the staged SHM stand-in,
   // whose exchange blocks the host); one piece: on the step's stream itself
@@ -1616,7 +1704,7 @@ int ycnr_als_step_async(ycnr_als *h, int side) {
     HIP_TRY(hipEventRecord(h->evStepStart, h->stream));
     for (int i = 0; i < 2; ++i) HIP_TRY(hipStreamWaitEvent(h->pieceStream[i], h->evStepStart, 0));
   }
-  for (size_t c = 0; c < parts.size(); ++c) {
+  for (size_t c = 0; c < parts.size() && !h->graphRun; ++c) {
     hipStream_t ps = twoStreams ? h->pieceStream[c & 1] : h->stream;
     int rc = launch_part(h, side, parts[c], ps);
     if (rc) return rc;
@@ -1635,7 +1723,7 @@ int ycnr_als_step_async(ycnr_als *h, int side) {
     HIP_TRY(hipEventRecord(h->evComputeEnd, h->stream));
     if (h->comm.transport != YCNR_COMM_SHM) HIP_TRY(hipStreamWaitEvent(h->stream, parts.back().x1, 0));  // (SHM is synchronous)
   }
-  HIP_TRY(hipMemcpyAsync(h->hErr, h->dErr, sizeof(ErrInfo), hipMemcpyDeviceToHost, h->stream));
+  if (!h->graphRun) HIP_TRY(hipMemcpyAsync(h->hErr, h->dErr, sizeof(ErrInfo), hipMemcpyDeviceToHost, h->stream));
   h->info.struct_size = (int32_t)sizeof(ycnr_als_step_info);
   h->info.side = side;
   h->info.parts = (int32_t)parts.size();
@@ -1671,7 +1759,14 @@ int ycnr_als_sync(ycnr_als *h) {
     h->infoPending = false;
     const std::vector<Part> &parts = h->parts[h->infoSide];
     float ms = 0;
+    if (h->graphRun && !parts.empty()) {
+      // one interval for the whole half-step: chunks -> reduce, the row kernel and the dual classes ran as branches of one graph
+      HIP_TRY(hipEventElapsedTime(&ms, parts[0].ev[0], parts[0].ev[4]));
+      h->info.gramSolveMs = ms;
+      h->info.dualOverlapped = 1;
+    }
     for (const Part &p : parts) {
+      if (h->graphRun) break;
       HIP_TRY(hipEventElapsedTime(&ms, p.ev[0], p.ev[1]));
       h->info.gramSlabMs += ms;
       HIP_TRY(hipEventElapsedTime(&ms, p.ev[1], p.ev[2]));

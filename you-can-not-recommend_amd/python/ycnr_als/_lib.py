@@ -19,6 +19,7 @@ MEM_HOST, MEM_DEVICE = 0, 1
 RMSE_VALIDATE, RMSE_TEST = 0, 1
 FLAG_LDS_SOLVER, FLAG_NO_DUAL, FLAG_LOCALITY_SORT, FLAG_NO_VALU_EDGE, FLAG_NO_BF16X6, FLAG_NO_BANDS = 1, 2, 4, 8, 16, 32
 FLAG_NO_OVERLAP = 64
+FLAG_NO_GRAPH = 128
 
 # every symbol include/ycnr_als.h declares (checked by tests/test_abi.py)
 EXPORTS = [
