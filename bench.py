@@ -185,6 +185,7 @@ def main():
         fixed_rows = items if side == "byUser" else users
         return (not args.double) and (128 < k <= 256 or (k % 4 == 0 and k <= 112 and fixed_rows * k * 4 < 2 ** 31))
 
+    gen_path = k > (128 if args.double else 256)  # als_gen_kernels.hip.h: float32 / float64 MFMA, matrix in global memory
     for st in lord.stepTimes:
         i = st["info"]
         side = st["stepType"]
@@ -212,9 +213,14 @@ def main():
                            row_k[4] + dual_by),)
         else:
             whole_rows = (row_k, dual_k)
-        for name, ms, fg, fs, by in whole_rows + (
-                ("als_gram_slab_kernel", i.gramSlabMs, chunk_ratings * gram_rating, 0.0, chunk_ratings * bytes_rating),
-                ("als_reduce_solve_kernel", i.reduceSolveMs, 0.0, i.splitRows * solve_row, i.splitRows * (k * s + 8))):
+        if gen_path:
+            # the any-k path reports its Gramian -> slab and slab -> solve kernels (batches of both) as one interval
+            split_k = (("als_gen_gram_kernel+als_gen_solve_kernel", i.gramSlabMs + i.reduceSolveMs, 0.0,
+                        chunk_ratings * gram_rating + i.splitRows * solve_row, chunk_ratings * bytes_rating + i.splitRows * (k * s + 8)),)
+        else:
+            split_k = (("als_gram_slab_kernel", i.gramSlabMs, chunk_ratings * gram_rating, 0.0, chunk_ratings * bytes_rating),
+                       ("als_reduce_solve_kernel", i.reduceSolveMs, 0.0, i.splitRows * solve_row, i.splitRows * (k * s + 8)))
+        for name, ms, fg, fs, by in whole_rows + split_k:
             if fg + fs > 0:
                 d = kern.setdefault(f"{name}[{side}]", {"ms": 0.0, "fg": 0.0, "fs": 0.0, "bytes": 0.0, "launches": 0, "x6": x6})
                 d["ms"] += ms

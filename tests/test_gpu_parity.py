@@ -294,8 +294,9 @@ def test_graph_replay_does_not_change_results(als, dt):
     classes as parallel branches.  Three iterations with and without (YCNR_FLAG_NO_GRAPH) must agree bit for bit,
     numeric errors must still be reported through a replayed graph, and a new upload must drop the graph."""
     from ycnr_als import YcnrError, _lib
-    k, users, items = 36, 700, 300
-    bu, bi, U, V = make_problem(users, items, k, density=0.15, seed=77, dtype=dt, empty_rows=(4,))
+    k, users, items = 36, 3000, 1200   # 360 K ratings: between the graph path's bounds (256 K ... 2 M per side)
+    bu, bi, U, V = make_problem(users, items, k, density=0.1, seed=77, dtype=dt, empty_rows=(4,))
+    assert 256 * 1024 <= bu.nnz < 2 * 1024 * 1024
     res = {}
     for name, flags in (("graph", 0), ("launches", _lib.FLAG_NO_GRAPH)):
         dev = als.AlsDevice(k, users, items, useDoublePrecision=(dt == np.float64), flags=flags, chunkRatings=32)  # split rows too

@@ -546,6 +546,9 @@ struct WgSolve {
 #endif
       }
 #ifndef YCNR_WG_ABLATE_TRAIL
+      // (Tried in round 3: keeping the wave that shares wave 0's SIMD -- or any other single wave -- out of the trailing
+      // update while wave 0 factors the next diagonal tile: 1.5 ms SLOWER per C5 shard whichever wave it was; the
+      // pivot chain is not stretched by the partner's MFMAs.)
       {
         auto next_row = [&]() {
           int r = 0;
