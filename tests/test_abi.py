@@ -71,6 +71,7 @@ def test_argument_validation_happens_before_the_device_is_touched():
         ycnr_als.als_calc_portion(0.05, 4, rows, np.zeros(1, np.int32), np.ones(1, np.int16),
                                   np.ones((1, 4), np.float32), np.zeros((1, 4), np.float32))
     with pytest.raises(ycnr_als.YcnrError) as e:
-        ycnr_als.als_calc_portion(0.05, 300, np.array([1, 0, 1], np.int32), np.zeros(1, np.int32),
-                                  np.ones(1, np.float32), np.ones((1, 300), np.float32), np.zeros((1, 300), np.float32))
+        # (any factorsCount up to 4096 is served; beyond that the right-hand side would no longer fit a CU's LDS)
+        ycnr_als.als_calc_portion(0.05, 5000, np.array([1, 0, 1], np.int32), np.zeros(1, np.int32),
+                                  np.ones(1, np.float32), np.ones((1, 5000), np.float32), np.zeros((1, 5000), np.float32))
     assert e.value.code == _lib.ERR_UNSUPPORTED

@@ -21,8 +21,10 @@ def load_lint():
 
 GOOD = """
 _ZN4ycnr4goodEv: ; @good
+	;;#ASMSTART
 	ds_read2_b32 v[2:3], v10 offset1:32
 	ds_read_b32 v4, v10 offset:256
+	;;#ASMEND
 	v_mfma_f32_16x16x4_f32 v[20:23], v30, v31, v[20:23]
 	s_waitcnt lgkmcnt(1)
 	v_add_f32_e32 v5, v2, v3
@@ -33,8 +35,10 @@ _ZN4ycnr4goodEv: ; @good
 
 BAD = """
 _ZN4ycnr3badEv: ; @bad
+	;;#ASMSTART
 	ds_read2_b32 v[2:3], v10 offset1:32
 	ds_read_b32 v4, v10 offset:256
+	;;#ASMEND
 	v_mov_b32_e32 v8, v3
 	s_waitcnt lgkmcnt(1)
 	v_add_f32_e32 v5, v2, v4

@@ -7,6 +7,7 @@
 #include "../../include/ycnr_als.h"
 #include "als_kernels.hip.h"
 #include "als_wg_kernels.hip.h"
+#include "als_pair_kernels.hip.h"
 #include "als_gen_kernels.hip.h"
 #include "prep_kernels.hip.h"
 #include <hipcub/hipcub.hpp>
@@ -54,6 +55,8 @@ constexpr int kMaxFactorsBig = 256;  // float32 through the workgroup-per-row ke
 constexpr int kMaxFactorsAny = 4096; // beyond kMaxFactorsBig (float64: kMaxFactors): the any-k path of als_gen_kernels.hip.h
 constexpr int kGenChunk = 4096;      // ratings per unit of the any-k path (als_gen_kernels.hip.h): every row goes through slabs there
 constexpr int64_t kGenArenaBytes = (int64_t)2 << 30;  // slab arena of that path: rows are solved in batches that fit it
+constexpr int kPairNB = 16;           // block count whose whole rows go Gramian -> slab -> two-wave solve (als_pair_kernels.hip.h): 240 < k <= 256
+constexpr int64_t kPairBatchRows = 12288;  // rows per batch of that path (a slab is 140 KB: 1.7 GB of arena)
 constexpr int kWgChunk = 8192;       // ratings per chunk of a row that is split over workgroups (k > 128)
 constexpr int kWgFusedMax = 16384;   // longest row one workgroup takes whole (k > 128)
 constexpr int kDefaultChunk = 1024;  // ratings per split unit (and the largest fused row)
@@ -113,6 +116,8 @@ struct Schedule {
   Unit *dUnits = nullptr;
   SplitRow *dSplit = nullptr;
   void *dSlabs = nullptr;
+  float *dRowSlabs = nullptr;  // k > 240: the images of a batch of whole rows between their Gramian and their two-wave solve
+  int64_t rowSlabRows = 0;
   int64_t nUnits = 0, nSplit = 0, nSlabs = 0, solvedRows = 0, fusedRatings = 0;
   // whole-row units: [nSlabs, nSlabs + nPrimal) primal form, then dual classes m = kMaxDualBlocks..1
   int64_t nPrimal = 0, dualFirst[kMaxDualBlocks + 1] = {}, dualCount[kMaxDualBlocks + 1] = {};
@@ -122,6 +127,9 @@ struct Schedule {
     if (dUnits) (void)hipFree(dUnits);
     if (dSplit) (void)hipFree(dSplit);
     if (dSlabs) (void)hipFree(dSlabs);
+    if (dRowSlabs) (void)hipFree(dRowSlabs);
+    dRowSlabs = nullptr;
+    rowSlabRows = 0;
     dUnits = nullptr;
     dSplit = nullptr;
     dSlabs = nullptr;
@@ -196,13 +204,13 @@ void build_schedule(const int64_t *rowPtr, int64_t rowBegin, int64_t nRows, int 
 
 // environment toggles for A/B experiments from unmodified hosts, read once per process
 struct EnvFlags {
-  bool noDualX6, noX6d, noFusedX6d, noOverlap, ignoreNumeric, noDualQuad, noGraph;
+  bool noDualX6, noX6d, noFusedX6d, noOverlap, ignoreNumeric, noDualQuad, noGraph, noPair;
   size_t k1LdsPad;
 };
 const EnvFlags &env_flags() {
   static const EnvFlags f = {getenv("YCNR_NO_DUAL_X6") != nullptr, getenv("YCNR_NO_X6D") != nullptr, getenv("YCNR_NO_FUSED_X6D") != nullptr,
                              getenv("YCNR_NO_OVERLAP") != nullptr, getenv("YCNR_IGNORE_NUMERIC") != nullptr, getenv("YCNR_NO_DUAL_QUAD") != nullptr,
-                             getenv("YCNR_NO_GRAPH") != nullptr,
+                             getenv("YCNR_NO_GRAPH") != nullptr, getenv("YCNR_NO_PAIR") != nullptr,
                              getenv("YCNR_K1_LDSPAD") ? (size_t)atoi(getenv("YCNR_K1_LDSPAD")) : 0};
   return f;
 }
@@ -441,7 +449,7 @@ int device_cus() {
 //   [chunks of heavy rows -> slabs] [whole rows: Gramian + solve] [dual classes] [slabs -> solve]
 template <int NB>
 int launch_wg_nb(StepArgs<float> args, int64_t nSplitUnits, int64_t nPrimal, int64_t nSplit, hipStream_t stream, hipEvent_t *ev,
-                 const DualPlan &dp) {
+                 const DualPlan &dp, float *rowSlabs, int64_t rowSlabRows) {
   auto k0 = als_wg_gram_slab_kernel<NB>;
   auto k1 = als_wg_gram_solve_kernel<NB>;
   auto k2 = als_wg_reduce_solve_kernel<NB>;
@@ -457,7 +465,27 @@ int launch_wg_nb(StepArgs<float> args, int64_t nSplitUnits, int64_t nPrimal, int
     HIP_TRY(hipGetLastError());
   }
   if (ev) HIP_TRY(hipEventRecord(ev[1], stream));
-  if (nPrimal > 0) {
+  bool pairDone = false;
+  if constexpr (NB == kPairNB) {
+    // whole rows: Gramian -> slab by the workgroup kernel, then the solve by two waves per row, batch by batch
+    // (als_pair_kernels.hip.h); YCNR_NO_PAIR=1 keeps the fused workgroup kernel for A/B runs
+    if (nPrimal > 0 && rowSlabs && rowSlabRows > 0 && !env_flags().noPair) {
+      auto kg = als_wg_gram_rowslab_kernel<NB>;
+      auto ks = als_slab_solve2_kernel<NB>;
+      if (int rc = set_max_lds(reinterpret_cast<const void *>(kg), lds)) return rc;
+      if (int rc = set_max_lds(reinterpret_cast<const void *>(ks), (size_t)PairCfg<NB>::LDS_BYTES)) return rc;
+      for (int64_t b0 = 0; b0 < nPrimal; b0 += rowSlabRows) {
+        const int64_t cnt = std::min(rowSlabRows, nPrimal - b0);
+        const int32_t first = (int32_t)(nSplitUnits + b0);
+        hipLaunchKernelGGL(kg, dim3((unsigned)std::min(cnt, cus)), dim3(kWgThreads), lds, stream, args, rowSlabs, first, (int32_t)cnt);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(ks, dim3((unsigned)cnt), dim3(kPairThreads), (size_t)PairCfg<NB>::LDS_BYTES, stream, args, (const float *)rowSlabs, first);
+        HIP_TRY(hipGetLastError());
+      }
+      pairDone = true;
+    }
+  }
+  if (nPrimal > 0 && !pairDone) {
     hipLaunchKernelGGL(k1, dim3((unsigned)std::min(nPrimal, cus)), dim3(kWgThreads), lds, stream, args, (int32_t)nPrimal);
     HIP_TRY(hipGetLastError());
   }
@@ -478,18 +506,18 @@ int launch_wg_nb(StepArgs<float> args, int64_t nSplitUnits, int64_t nPrimal, int
 }
 
 int launch_step_big(const StepArgs<float> &args, int64_t nUnits, int64_t nSplitUnits, int64_t nSplit, hipStream_t stream,
-                    hipEvent_t *ev, const DualPlan &dp) {
+                    hipEvent_t *ev, const DualPlan &dp, float *rowSlabs = nullptr, int64_t rowSlabRows = 0) {
   if (nUnits > 0x7fffffffLL) return fail(YCNR_ERR_UNSUPPORTED, "too many work units for one launch (%lld)", (long long)nUnits);
   const int64_t nPrimal = dp.nPrimal >= 0 ? dp.nPrimal : nUnits - nSplitUnits;
   switch ((args.k + 15) / 16) {
-    case 9: return launch_wg_nb<9>(args, nSplitUnits, nPrimal, nSplit, stream, ev, dp);
-    case 10: return launch_wg_nb<10>(args, nSplitUnits, nPrimal, nSplit, stream, ev, dp);
-    case 11: return launch_wg_nb<11>(args, nSplitUnits, nPrimal, nSplit, stream, ev, dp);
-    case 12: return launch_wg_nb<12>(args, nSplitUnits, nPrimal, nSplit, stream, ev, dp);
-    case 13: return launch_wg_nb<13>(args, nSplitUnits, nPrimal, nSplit, stream, ev, dp);
-    case 14: return launch_wg_nb<14>(args, nSplitUnits, nPrimal, nSplit, stream, ev, dp);
-    case 15: return launch_wg_nb<15>(args, nSplitUnits, nPrimal, nSplit, stream, ev, dp);
-    case 16: return launch_wg_nb<16>(args, nSplitUnits, nPrimal, nSplit, stream, ev, dp);
+    case 9: return launch_wg_nb<9>(args, nSplitUnits, nPrimal, nSplit, stream, ev, dp, rowSlabs, rowSlabRows);
+    case 10: return launch_wg_nb<10>(args, nSplitUnits, nPrimal, nSplit, stream, ev, dp, rowSlabs, rowSlabRows);
+    case 11: return launch_wg_nb<11>(args, nSplitUnits, nPrimal, nSplit, stream, ev, dp, rowSlabs, rowSlabRows);
+    case 12: return launch_wg_nb<12>(args, nSplitUnits, nPrimal, nSplit, stream, ev, dp, rowSlabs, rowSlabRows);
+    case 13: return launch_wg_nb<13>(args, nSplitUnits, nPrimal, nSplit, stream, ev, dp, rowSlabs, rowSlabRows);
+    case 14: return launch_wg_nb<14>(args, nSplitUnits, nPrimal, nSplit, stream, ev, dp, rowSlabs, rowSlabRows);
+    case 15: return launch_wg_nb<15>(args, nSplitUnits, nPrimal, nSplit, stream, ev, dp, rowSlabs, rowSlabRows);
+    case 16: return launch_wg_nb<16>(args, nSplitUnits, nPrimal, nSplit, stream, ev, dp, rowSlabs, rowSlabRows);
     default: return fail(YCNR_ERR_UNSUPPORTED, "factorsCount %d is outside the workgroup-per-row path", args.k);
   }
 }
@@ -1385,6 +1413,10 @@ static int build_part(ycnr_als *h, int side, const int64_t *rowPtr, const int32_
     const double nd = (double)n, kd = (double)h->opt.factorsCount;
     S.dualFlops += nd * (nd + 1) * kd + nd * nd * nd / 3.0 + 2.0 * nd * nd + 2.0 * nd * kd;
   }
+  if (big && slab_nb(h->kPad ? h->kPad : h->opt.factorsCount) == kPairNB && S.nPrimal > 0 && !env_flags().noPair) {
+    S.rowSlabRows = std::min<int64_t>(S.nPrimal, kPairBatchRows);
+    HIP_TRY(hipMalloc(&S.dRowSlabs, (size_t)S.rowSlabRows * (size_t)wg_slab_floats(kPairNB) * sizeof(float)));
+  }
   if (S.nUnits) {
     HIP_TRY(hipMalloc(&S.dUnits, sizeof(Unit) * units.size()));
     HIP_TRY(hipMemcpy(S.dUnits, units.data(), sizeof(Unit) * units.size(), hipMemcpyHostToDevice));
@@ -1594,7 +1626,7 @@ static int launch_part(ycnr_als *h, int side, Part &part, hipStream_t stream, bo
     }
     if (h->opt.factorsCount > kMaxFactors) {
       int rc = is_gen(YCNR_F32, h->opt.factorsCount) ? launch_step_gen<float>(a, S.genBatches, stream, ev, dp)
-                                                     : launch_step_big(a, S.nUnits, S.nSlabs, S.nSplit, stream, ev, dp);
+                                                     : launch_step_big(a, S.nUnits, S.nSlabs, S.nSplit, stream, ev, dp, S.dRowSlabs, S.rowSlabRows);
       if (rc || !h->kPad) return rc;
       // the piece's solved rows back into the caller's matrix (before its exchange)
       const int64_t nr = R.rowEnd - R.rowBegin, n = nr * h->opt.factorsCount;
