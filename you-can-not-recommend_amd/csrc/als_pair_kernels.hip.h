@@ -1,21 +1,25 @@
-// als_pair_kernels.hip.h -- the solve of the 128 < k <= 256 path by TWO waves per row (round 3).
+// als_pair_kernels.hip.h -- the solve of the 240 < k <= 256 path by a FEW waves per row with register-resident tiles (round 3).
 //
 // Why.  The 8-wave workgroup solve of als_wg_kernels.hip.h takes 62 us of a whole CU per 256 x 256 system: per
 // block step a panel phase, a barrier, the 16 sequential pivots of the next diagonal tile on one wave and a second
-// barrier -- its MFMA work is 13 us.  The one-wave solves of the other paths get four times that throughput out of a
-// CU because four independent rows hide each other's pivot chains (the 176 x 176 dual class costs 66 us of ONE SIMD,
-// Gramian included).  A 256 x 256 system does not fit one wave -- 136 tiles are 544 registers, and past ~70 resident
-// tiles hipcc spills by the kilobyte (tried: 105 tiles in registers + 31 parked in LDS: 2.9 KB of scratch per lane) --
-// but it fits TWO: 68 tiles each, the size the 11-block dual class already compiles at.
+// barrier, with the whole matrix going through LDS for every tile update -- its MFMA work is 13 us.  The one-wave solves
+// of the other paths get four times that throughput out of a CU because four independent rows hide each other's pivot
+// chains (the 176 x 176 dual class costs 66 us of ONE SIMD, Gramian included).  A 256 x 256 system does not fit one
+// wave -- 136 tiles are 544 registers, and past ~70 resident tiles hipcc spills by the kilobyte (tried: 105 tiles in
+// registers + 31 parked in LDS: 2.9 KB of scratch per lane) -- but it fits two waves (68 tiles each, one wave per SIMD)
+// or four (34 tiles each in 256 registers, TWO waves per SIMD: the waves of two rows share every SIMD, so a wave
+// waiting for its row's pivot chain leaves the SIMD to the other row -- the shipped form).
 //
-// How.  The Gramian stays with the 8-wave workgroup kernel (bf16 pipe, als_wg_kernels.hip.h), which now writes the
-// row's image to a slab in global memory instead of solving it; rows are processed in batches whose slabs fit an
-// arena.  The solve kernel runs one 128-thread workgroup per row, two workgroups per CU (one wave per SIMD):
-//   * block rows are dealt 0 | 1 2 | 3 4 | 5 6 | ... over the two waves (68 tiles each at NB = 16), all in registers,
-//     every tile index a compile-time constant (the two waves run two specialisations of the same code);
+// How.  The Gramian stays with the 8-wave workgroup kernel (bf16 pipe, als_wg_kernels.hip.h), which writes the row's
+// image to a slab in global memory instead of solving it (als_wg_gram_rowslab_kernel); rows are processed in batches
+// whose slabs fit an arena.  The solve kernel (als_slab_solve2_kernel) runs one workgroup of kPairWaves waves per row,
+// two workgroups per CU:
+//   * block rows are dealt back and forth over the waves (0 1 2 3 3 2 1 0 ...: 34 tiles each at NB = 16), all in
+//     registers, every tile index a compile-time constant (the waves run specialisations of the same code);
 //   * block step J: the OWNER of row J factors its diagonal tile (the pivot sequence of SolveMfmaF32), turns its row
 //     into the panel U[J][.] = W T[J][.] (kept in its registers for the back substitution) and publishes panel and
-//     z_J through LDS (double-buffered: one 2-wave barrier per step); then both waves update the rows they own;
+//     z_J through LDS (double-buffered: ONE workgroup barrier per step); every wave updates the rows it owns; the owner of
+//     row J + 1 updates that row first and factors it while the others are still in the trailing update (look-ahead);
 //   * back substitution: the owner of row J folds the x blocks behind it into x_J and publishes it, one barrier per block.
 // Same arithmetic as the one-wave solve (float32 MFMA tile products, v_rsq pivots), same C/D layout as the image.
 #pragma once
@@ -23,12 +27,18 @@
 
 namespace ycnr {
 
-constexpr int kPairThreads = 128;
+#ifndef YCNR_PAIR_WAVES
+#define YCNR_PAIR_WAVES 4  // waves per row: 2 (one per SIMD, 512 registers each) or 4 (two per SIMD, 256 each; C5 shard 146.7 -> 141.6 ms)
+#endif
+constexpr int kPairWaves = YCNR_PAIR_WAVES;
+constexpr int kPairThreads = 64 * kPairWaves;
 
 template <int NB>
 struct PairCfg {
-  // owner of block row r: rows dealt 0 | 1 2 | 3 4 | ...
-  static __host__ __device__ constexpr int owner(int r) { return ((r + 1) >> 1) & 1; }
+  static constexpr int NW = kPairWaves;
+  // owner of block row r: rows dealt back and forth over the waves (0 1 1 0 0 1 1 0 ... / 0 1 2 3 3 2 1 0 ...), which
+  // balances the tile counts of a triangular matrix (NB = 16: 68 tiles each of two waves, 34 each of four)
+  static __host__ __device__ constexpr int owner(int r) { return (r % (2 * NW)) < NW ? (r % (2 * NW)) : 2 * NW - 1 - (r % (2 * NW)); }
   // position of tile (bi, bj) among the tiles of wave W's rows (row-major over its rows)
   static __host__ __device__ constexpr int idx(int W, int bi, int bj) {
     int n = 0;
@@ -37,14 +47,13 @@ struct PairCfg {
     return n + (bj - bi);
   }
   static __host__ __device__ constexpr int count(int W) { return idx(W, NB, NB); }
-  static constexpr int MAXT = count(0) > count(1) ? count(0) : count(1);
   static constexpr int LDW = 20;
   // LDS (floats): two panel buffers of NB tiles, z, x, one pair of 16 x 16 images per wave, a flag
   static constexpr int PANEL = NB * 256;
   static constexpr int OFF_Z = 2 * PANEL;
   static constexpr int OFF_X = OFF_Z + NB * 16;
   static constexpr int OFF_IMG = OFF_X + NB * 16;
-  static constexpr int OFF_FLAG = OFF_IMG + 2 * 2 * 16 * LDW;
+  static constexpr int OFF_FLAG = OFF_IMG + NW * 2 * 16 * LDW;
   static constexpr int LDS_BYTES = (OFF_FLAG + 4) * 4;
 };
 
@@ -276,7 +285,7 @@ __global__ __launch_bounds__(kWgThreads, 2) void als_wg_gram_rowslab_kernel(Step
 
 // one 2-wave workgroup per row of the batch: slab -> x -> the row of the solved matrix
 template <int NB>
-__global__ __launch_bounds__(kPairThreads, 1) void als_slab_solve2_kernel(StepArgs<float> a, const float *rowSlabs, int32_t first) {
+__global__ __launch_bounds__(kPairThreads, kPairWaves == 2 ? 1 : 2) void als_slab_solve2_kernel(StepArgs<float> a, const float *rowSlabs, int32_t first) {
   extern __shared__ __attribute__((aligned(16))) float ldsp[];
   using PC = PairCfg<NB>;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -288,8 +297,15 @@ __global__ __launch_bounds__(kPairThreads, 1) void als_slab_solve2_kernel(StepAr
   int *flag = reinterpret_cast<int *>(ldsp + PC::OFF_FLAG);
   if (tid == 0) *flag = 0;
   bool bad;
-  if (wave == 0) bad = PairSolve<NB, 0>::run(slab, ldsp, kDiag, lam, lane);
-  else bad = PairSolve<NB, 1>::run(slab, ldsp, kDiag, lam, lane);
+  if constexpr (kPairWaves == 2) {
+    if (wave == 0) bad = PairSolve<NB, 0>::run(slab, ldsp, kDiag, lam, lane);
+    else bad = PairSolve<NB, 1>::run(slab, ldsp, kDiag, lam, lane);
+  } else {
+    if (wave == 0) bad = PairSolve<NB, 0>::run(slab, ldsp, kDiag, lam, lane);
+    else if (wave == 1) bad = PairSolve<NB, 1>::run(slab, ldsp, kDiag, lam, lane);
+    else if (wave == 2) bad = PairSolve<NB, 2 % kPairWaves>::run(slab, ldsp, kDiag, lam, lane);
+    else bad = PairSolve<NB, 3 % kPairWaves>::run(slab, ldsp, kDiag, lam, lane);
+  }
   // (the last barrier of the back substitution lies behind both waves: x is complete in LDS)
   float *out = a.solved + (int64_t)u.row * a.k;
   const float *xb = ldsp + PC::OFF_X;
