@@ -22,7 +22,12 @@ import sys
 
 # kernel name fragment -> bench.py's entry (the workgroup-per-row kernels of k > 128, als_wg_*, fill the same roles)
 BENCH_NAME = (("gram_solve", "als_gram_solve_kernel"), ("dual_solve", "als_dual_solve_kernel"),
-              ("gram_slab", "als_gram_slab_kernel"), ("reduce_solve", "als_reduce_solve_kernel"))
+              ("gram_slab", "als_gram_slab_kernel"), ("reduce_solve", "als_reduce_solve_kernel"),
+              # k > 240: whole rows go Gramian -> slab -> few-wave solve in BATCHES (als_pair_kernels.hip.h); together they
+              # are bench.py's als_gram_solve_kernel entry, one "launch" = all batches of a half-step
+              ("gram_rowslab", "als_gram_solve_kernel"), ("slab_solve2", "als_gram_solve_kernel"))
+BATCHED = ("gram_rowslab", "slab_solve2")
+ITERATIONS = 2  # collect.sh: --steps 1 --warmup 1
 
 
 def main():
@@ -45,6 +50,8 @@ def main():
     half, seen, prev = 1, set(), ""
     for did in order:
         n = rows[did]["name"].split("(")[0]
+        if any(b in n for b in BATCHED):  # the batches of a half-step alternate two kernels: no half-step boundary among them
+            n = "batched_rows"
         slab = "gram_slab" in n
         new_half = False
         if seen:
@@ -52,7 +59,7 @@ def main():
                 new_half = True
             elif slab and "gram_slab" not in prev:
                 new_half = True
-            elif n in seen and not slab:
+            elif n in seen and not slab and n != "batched_rows":
                 new_half = True
         if new_half:
             half += 1
@@ -82,7 +89,7 @@ def main():
             continue
         t = traffic.setdefault(f"{bn}[{d['half_step']}]", {"kb": 0.0, "launches": 0})
         t["kb"] += 2.0 * d["FETCH_SIZE"] + d.get("WRITE_SIZE", 0.0)
-        t["launches"] = max(t["launches"], d["dispatches"])
+        t["launches"] = max(t["launches"], ITERATIONS if any(b in d["kernel"] for b in BATCHED) else d["dispatches"])
     # the whole-row kernels of a half-step as one group (bench.py's entry when the dual kernels run
     # on side streams next to the row kernel)
     for side in ("byUser", "byItem"):
