@@ -130,17 +130,17 @@ def test_js_train_matches_python_host(tmp_path, double):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("double", [False, True])
-def test_js_train_on_per_gpu_processes(tmp_path, double):
-    """The NodeJS Lord forks 2 and 3 per-GPU processes (here sharing cuda:0 through the shared-memory
-    transport): sharded upload, pipelined pieces, exchange and all-reduce through the addon.  Result files
-    and RMSE history must equal the single-process run's."""
+@pytest.mark.parametrize("double,transport", [(False, "shm"), (True, "shm"), (False, "ipc")])
+def test_js_train_on_per_gpu_processes(tmp_path, double, transport):
+    """The NodeJS Lord forks 2 and 3 per-GPU processes (here sharing cuda:0: the host-staged stand-in 'shm' and the
+    device-to-device transport 'ipc'): sharded upload, pipelined pieces, exchange, all-reduce and the re-cut of the
+    shards after the first iteration through the addon.  Result files and RMSE history must equal the single-process run's."""
     dt = np.float64 if double else np.float32
     bu, user, typ, U, V = problem(seed=9, users=120, items=70)
     res = {}
     for world in (1, 2, 3):
         d = tmp_path / f"w{world}"
-        inp = {"dir": str(d), "k": 12, "iters": 3, "rip": 40, "threads": 2, "useDoublePrecision": double, "world": world,
+        inp = {"dir": str(d), "k": 12, "iters": 3, "rip": 40, "threads": 2, "useDoublePrecision": double, "world": world, "transport": transport,
                "users": bu.rows, "items": bu.cols, "user": user.tolist(), "item": bu.indx.tolist(),
                "rating": bu.vals.astype(dt).tolist(), "type": typ.tolist()}
         (tmp_path / f"in{world}.json").write_text(json.dumps(inp))
