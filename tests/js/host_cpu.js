@@ -49,6 +49,12 @@ lord.getStats().then(() => lord.splitToPortions()).then(() => {
   out.shards = {};
   for (const [w, k] of [[2, 8], [3, 100], [8, 256]])
     out.shards[w + '_' + k] = EmfMaster.shardRanges(ds.trainByUser.rowPtr, 0, ds.trainByUser.rows, w, k, false);
+  // the feedback re-cut from measured times (checked against the Python mirror's rebalanced_ranges)
+  out.recut = {};
+  for (const [w, k] of [[2, 8], [3, 100]]) {
+    const b = out.shards[w + '_' + k], ms = b.slice(1).map((_, r) => 1.0 + 0.5 * r);
+    out.recut[w + '_' + k] = EmfMaster.rebalancedRanges(ds.trainByUser.rowPtr, b, ms, k, false);
+  }
   let gpu = true;
   try { n.deviceCount(); } catch (e) { gpu = false; out.deviceCountError = e.message; }
   if (gpu) return;

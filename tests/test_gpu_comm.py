@@ -195,3 +195,25 @@ def test_two_ranks_on_two_gpus(als, transport):
     for rank, (Ug, Vg), s, parts, xu, xi in res:
         assert np.array_equal(Ug, U1) and np.array_equal(Vg, V1), f"rank {rank}: replicas differ from the single-process run"
         assert parts == 3 and xu > 0 and xi > 0
+
+
+def test_emulated_world_reports_every_rank(tmp_path):
+    """bench.py --emulate-world: one GPU solves every rank's shard of a 3-GPU run in turn over the stub transport and
+    reports compute ms per rank before and after the feedback re-cut (the tool behind DESIGN.md's 8-rank table)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "ml1m", "--emulate-world", "3", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["emulated_world"] == 3
+    for cut in ("cost_model_cut", "after_feedback_recut"):
+        for side in ("byUser", "byItem"):
+            c = d[cut][side]
+            assert len(c["compute_ms"]) == 3 and all(x > 0 for x in c["compute_ms"]) and c["imbalance_max_over_mean"] >= 1.0
+            assert len(c["kernel_ms"]) == 3 and sum(c["exchange_bytes"]) > 0
+    for side in (0, 1):
+        b0, b1 = d["shards"]["cost_model"][str(side)], d["shards"]["feedback"][str(side)]
+        assert b0[0] == b1[0] == 0 and b0[-1] == b1[-1] and len(b0) == len(b1) == 4

@@ -207,3 +207,22 @@ def test_init_factors_are_seeded_and_scaled():
     b = init_factors(1000, 50, 3)
     assert np.array_equal(a, b) and a.dtype == np.float32
     assert abs(a.std() - 1 / 50) < 2e-3  # randomNormal(1 / factorsCount), EmfBase.js:486
+
+
+def test_rebalanced_ranges_equalise_measured_times():
+    """The feedback that stands in for the reference's work-stealing portion dispenser (lib/emf/EmfLord.js:996-1006):
+    shards re-cut from measured times converge to equal times when the true cost differs from the model, tile the
+    rows, and stay put when a measurement is missing."""
+    from ycnr_als.emf import rebalanced_ranges, row_cost, shard_ranges
+    rng = np.random.default_rng(3)
+    cnt = rng.integers(0, 300, 50_000)
+    true = row_cost(cnt, 100) * (1.0 + np.arange(len(cnt)) / len(cnt))   # the later rows cost up to twice the model
+    ms = lambda b: np.array([true[b[r]:b[r + 1]].sum() for r in range(len(b) - 1)])
+    b = shard_ranges(cnt, 8, 100)
+    assert ms(b).max() / ms(b).mean() > 1.2
+    for _ in range(3):
+        b = rebalanced_ranges(cnt, b, ms(b), 100)
+        assert b[0] == 0 and b[-1] == len(cnt) and (np.diff(b) >= 0).all()
+    assert ms(b).max() / ms(b).mean() < 1.01
+    assert np.array_equal(rebalanced_ranges(cnt, b, [1.0] * 7 + [0.0], 100), b)     # a rank without a time: no re-cut
+    assert np.array_equal(rebalanced_ranges(cnt, b, [1.0] * 7 + [float("nan")], 100), b)

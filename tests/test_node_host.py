@@ -47,10 +47,16 @@ def test_js_host_on_cpu(tmp_path):
         assert out["portionsRowIdTo"][step] == ends.tolist(), step
         assert out["maxRatingsInPortion"][step] == rip and out["maxRowsInPortion"][step] == mrows
     assert abs(out["totalRatingsAvg"] - float(bu.vals.mean())) < 1e-6
-    from ycnr_als.emf import shard_ranges
+    from ycnr_als.emf import rebalanced_ranges, shard_ranges
     for key, got in out["shards"].items():
         w, k = (int(x) for x in key.split("_"))
         assert got == shard_ranges(cnt_u, w, k).tolist(), key
+    for key, got in out["recut"].items():  # the feedback re-cut: both hosts cut alike from the same measured times
+        w, k = (int(x) for x in key.split("_"))
+        ms = [1.0 + 0.5 * r for r in range(w)]
+        want = rebalanced_ranges(cnt_u, shard_ranges(cnt_u, w, k), ms, k)
+        assert got == want.tolist(), key
+        assert got[1] > shard_ranges(cnt_u, w, k)[1]  # the rank that ran shortest takes rows from the others
     if "prepareError" in out:  # no GPU here: loud failure, carrying the library's message
         assert "hip" in out["prepareError"].lower()
 
