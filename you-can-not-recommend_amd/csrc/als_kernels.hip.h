@@ -1997,62 +1997,96 @@ __global__ __launch_bounds__(64) void als_dual_solve_kernel(StepArgs<float> a) {
         y[ba][1] = *reinterpret_cast<const float4 *>(f + 4 < k ? rowp[ba] + f + 4 : a.zeros);
       }
     };
-    // NBN <= 6: the next K-step's rows are loaded while this one is split and multiplied.  Larger
-    // classes (k > 128 only) have no registers for that: each block is loaded just before its split.
+    // NBN <= 6: the next K-step's rows are loaded while this one is split and multiplied (double-buffered raw values).
+    // Larger classes (k > 128 only) have no registers for that; round 3: they visit the tiles ROW BY ROW with the three
+    // operand planes single-buffered -- after tile row ba nothing reads block ba again, so the next K-step's block ba is
+    // split into the same registers while the rows below still multiply, and its raw values are requested one row
+    // ahead (the scheme of GramX6D).  Before: every block loaded just before its split, one wave per SIMD, nothing to
+    // hide the loads behind.
     constexpr bool AHEAD = NBN <= 6;
+    auto split8 = [&](const float4 &z0, const float4 &z1, u32x4 &o1, u32x4 &o2, u32x4 &o3) {
+      const float x[8] = {z0.x, z0.y, z0.z, z0.w, z1.x, z1.y, z1.z, z1.w};
+      unsigned h[4], m[4], l[4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const float x0 = x[2 * jj], x1 = x[2 * jj + 1];
+        const unsigned u0 = __builtin_bit_cast(unsigned, x0), u1 = __builtin_bit_cast(unsigned, x1);
+        h[jj] = __builtin_amdgcn_perm(u1, u0, 0x07060302);
+        const float s0 = x0 - __builtin_bit_cast(float, u0 & 0xFFFF0000u);
+        const float s1 = x1 - __builtin_bit_cast(float, u1 & 0xFFFF0000u);
+        const unsigned v0 = __builtin_bit_cast(unsigned, s0), v1 = __builtin_bit_cast(unsigned, s1);
+        m[jj] = __builtin_amdgcn_perm(v1, v0, 0x07060302);
+        const float t0 = s0 - __builtin_bit_cast(float, v0 & 0xFFFF0000u);
+        const float t1 = s1 - __builtin_bit_cast(float, v1 & 0xFFFF0000u);
+        l[jj] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, t1), __builtin_bit_cast(unsigned, t0), 0x07060302);
+      }
+      o1 = u32x4{h[0], h[1], h[2], h[3]};
+      o2 = u32x4{m[0], m[1], m[2], m[3]};
+      o3 = u32x4{l[0], l[1], l[2], l[3]};
+    };
     if constexpr (AHEAD) {
       if (ksteps32 > 0) load8(za, 0);
-    }
-    for (int s = 0; s < ksteps32; ++s) {
-      if constexpr (AHEAD) {
+      for (int s = 0; s < ksteps32; ++s) {
         if (s + 1 < ksteps32) load8(zb, s + 1);
-      }
-      u32x4 p1[NBN], p2[NBN], p3[NBN];
+        u32x4 p1[NBN], p2[NBN], p3[NBN];
 #pragma unroll
-      for (int ba = 0; ba < NBN; ++ba) {
-        if constexpr (!AHEAD) {
-          const int f = 32 * s + 8 * g;
-          za[ba][0] = *reinterpret_cast<const float4 *>(f < k ? rowp[ba] + f : a.zeros);
-          za[ba][1] = *reinterpret_cast<const float4 *>(f + 4 < k ? rowp[ba] + f + 4 : a.zeros);
-        }
-        const float x[8] = {za[ba][0].x, za[ba][0].y, za[ba][0].z, za[ba][0].w, za[ba][1].x, za[ba][1].y, za[ba][1].z, za[ba][1].w};
-        unsigned h[4], m[4], l[4];
+        for (int ba = 0; ba < NBN; ++ba) split8(za[ba][0], za[ba][1], p1[ba], p2[ba], p3[ba]);
+        // smallest terms first per tile, product type outermost (consecutive MFMAs hit different tiles)
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          const float x0 = x[2 * jj], x1 = x[2 * jj + 1];
-          const unsigned u0 = __builtin_bit_cast(unsigned, x0), u1 = __builtin_bit_cast(unsigned, x1);
-          h[jj] = __builtin_amdgcn_perm(u1, u0, 0x07060302);
-          const float s0 = x0 - __builtin_bit_cast(float, u0 & 0xFFFF0000u);
-          const float s1 = x1 - __builtin_bit_cast(float, u1 & 0xFFFF0000u);
-          const unsigned v0 = __builtin_bit_cast(unsigned, s0), v1 = __builtin_bit_cast(unsigned, s1);
-          m[jj] = __builtin_amdgcn_perm(v1, v0, 0x07060302);
-          const float t0 = s0 - __builtin_bit_cast(float, v0 & 0xFFFF0000u);
-          const float t1 = s1 - __builtin_bit_cast(float, v1 & 0xFFFF0000u);
-          l[jj] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, t1), __builtin_bit_cast(unsigned, t0), 0x07060302);
-        }
-        p1[ba] = u32x4{h[0], h[1], h[2], h[3]};
-        p2[ba] = u32x4{m[0], m[1], m[2], m[3]};
-        p3[ba] = u32x4{l[0], l[1], l[2], l[3]};
-      }
-      // smallest terms first per tile, product type outermost (consecutive MFMAs hit different tiles)
+        for (int term = 0; term < 6; ++term) {
 #pragma unroll
-      for (int term = 0; term < 6; ++term) {
+          for (int ba = 0; ba < NBN; ++ba) {
 #pragma unroll
-        for (int ba = 0; ba < NBN; ++ba) {
-#pragma unroll
-          for (int bb = ba; bb < NBN; ++bb) {
-            const u32x4 &pa = term == 0 ? p2[ba] : (term == 1 || term == 3 || term == 5) ? p1[ba] : (term == 2 ? p3[ba] : p2[ba]);
-            const u32x4 &pb = term == 0 ? p2[bb] : term == 1 ? p3[bb] : term == 2 ? p1[bb] : term == 3 ? p2[bb] : p1[bb];
-            acc[tile_index(ba, bb, NBN)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                __builtin_bit_cast(bf16x8, pa), __builtin_bit_cast(bf16x8, pb), acc[tile_index(ba, bb, NBN)], 0, 0, 0);
+            for (int bb = ba; bb < NBN; ++bb) {
+              const u32x4 &pa = term == 0 ? p2[ba] : (term == 1 || term == 3 || term == 5) ? p1[ba] : (term == 2 ? p3[ba] : p2[ba]);
+              const u32x4 &pb = term == 0 ? p2[bb] : term == 1 ? p3[bb] : term == 2 ? p1[bb] : term == 3 ? p2[bb] : p1[bb];
+              acc[tile_index(ba, bb, NBN)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                  __builtin_bit_cast(bf16x8, pa), __builtin_bit_cast(bf16x8, pb), acc[tile_index(ba, bb, NBN)], 0, 0, 0);
+            }
           }
         }
-      }
-      if constexpr (AHEAD) {
 #pragma unroll
         for (int ba = 0; ba < NBN; ++ba) {
           za[ba][0] = zb[ba][0];
           za[ba][1] = zb[ba][1];
+        }
+      }
+    } else {
+      u32x4 p1[NBN], p2[NBN], p3[NBN];
+      auto load_block = [&](float4 (&z)[2], int ba, int s) {
+        const int f = 32 * s + 8 * g;
+        z[0] = *reinterpret_cast<const float4 *>(f < k ? rowp[ba] + f : a.zeros);
+        z[1] = *reinterpret_cast<const float4 *>(f + 4 < k ? rowp[ba] + f + 4 : a.zeros);
+      };
+      if (ksteps32 > 0) {
+#pragma unroll
+        for (int ba = 0; ba < NBN; ++ba) {
+          float4 z[2];
+          load_block(z, ba, 0);
+          split8(z[0], z[1], p1[ba], p2[ba], p3[ba]);
+        }
+      }
+      for (int s = 0; s < ksteps32; ++s) {
+        const bool more = s + 1 < ksteps32;  // wave-uniform
+        float4 zn[2];
+        if (more) load_block(zn, 0, s + 1);
+#pragma unroll
+        for (int ba = 0; ba < NBN; ++ba) {
+#pragma unroll
+          for (int term = 0; term < 6; ++term) {
+#pragma unroll
+            for (int bb = ba; bb < NBN; ++bb) {
+              const u32x4 &pa = term == 0 ? p2[ba] : (term == 1 || term == 3 || term == 5) ? p1[ba] : (term == 2 ? p3[ba] : p2[ba]);
+              const u32x4 &pb = term == 0 ? p2[bb] : term == 1 ? p3[bb] : term == 2 ? p1[bb] : term == 3 ? p2[bb] : p1[bb];
+              acc[tile_index(ba, bb, NBN)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                  __builtin_bit_cast(bf16x8, pa), __builtin_bit_cast(bf16x8, pb), acc[tile_index(ba, bb, NBN)], 0, 0, 0);
+            }
+          }
+          if (more) {  // row ba is done with block ba: the next K-step's values go into its registers
+            const float4 zc0 = zn[0], zc1 = zn[1];
+            if (ba + 1 < NBN) load_block(zn, ba + 1, s + 1);
+            split8(zc0, zc1, p1[ba], p2[ba], p3[ba]);
+          }
         }
       }
     }
