@@ -1,5 +1,6 @@
-# Randomised differential run: random k, shapes, chunk sizes and flags, one byUser + one byItem
-# step each, every row against float64.  python fuzz.py [seconds] [seed]
+# Randomised differential run: random k (4 ... 400: every kernel family incl. the two any-k paths), precision, shapes,
+# chunk sizes and flags, one byUser + one byItem step each (three of each on small uploads: launch by launch, graph
+# capture, graph replay), every row against float64.  python fuzz.py [seconds] [seed]
 import sys, time, numpy as np
 sys.path.insert(0, 'you-can-not-recommend_amd/python'); sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
 import ycnr_als
@@ -11,34 +12,42 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 EPS = np.finfo(np.float32).eps
 t0, runs, worst = time.time(), 0, 0.0
 while time.time() - t0 < budget:
-    k = int(rng.choice([4, 8, 12, 16, 20, 28, 32, 36, 48, 52, 64, 68, 80, 96, 100, 108, 112, 116, 128, 132, 160, 200, 256, 7, 33, 101]))
-    users, items = int(rng.integers(50, 4000)), int(rng.integers(30, 1500))
+    k = int(rng.choice([4, 8, 12, 16, 20, 28, 32, 36, 48, 52, 64, 68, 80, 96, 100, 108, 112, 116, 128, 132, 160, 200, 241, 252, 256, 7, 33, 101, 260, 320, 400]))
+    dbl = bool(rng.random() < 0.2)
+    dt = np.float64 if dbl else np.float32
+    users, items = int(rng.integers(50, 4000 if k <= 256 else 600)), int(rng.integers(30, 1500 if k <= 256 else 500))
     mean = float(rng.choice([3, 20, 80, 250]))
     lens = np.clip(rng.lognormal(np.log(mean), 1.0, users).astype(np.int64), 0, items)
     rowPtr = np.zeros(users + 1, np.int64); np.cumsum(lens, out=rowPtr[1:])
     indx = np.concatenate([np.sort(rng.choice(items, n, replace=False)) for n in lens] + [np.zeros(0, np.int64)]).astype(np.int32)
-    vals = rng.integers(1, 11, rowPtr[-1]).astype(np.float32)
+    vals = rng.integers(1, 11, rowPtr[-1]).astype(dt)
     bu = Csr(users, items, rowPtr, indx, vals)
     # by item
     order = np.lexsort((np.repeat(np.arange(users), lens), indx))
     ip = np.zeros(items + 1, np.int64); np.cumsum(np.bincount(indx, minlength=items), out=ip[1:])
     bi = Csr(items, users, ip, np.repeat(np.arange(users), lens)[order].astype(np.int32), vals[order])
-    flags = int(rng.choice([0, 0, 0, _lib.FLAG_NO_DUAL, _lib.FLAG_NO_BF16X6, _lib.FLAG_NO_BANDS, _lib.FLAG_NO_VALU_EDGE, _lib.FLAG_NO_OVERLAP])) if k <= 128 else int(rng.choice([0, _lib.FLAG_NO_DUAL]))
+    flags = int(rng.choice([0, 0, 0, _lib.FLAG_NO_DUAL, _lib.FLAG_NO_BF16X6, _lib.FLAG_NO_BANDS, _lib.FLAG_NO_VALU_EDGE, _lib.FLAG_NO_OVERLAP, _lib.FLAG_NO_GRAPH])) if k <= 128 else int(rng.choice([0, _lib.FLAG_NO_DUAL]))
     chunk = int(rng.choice([0, 0, 32, 100, 512]))
-    U = (rng.standard_normal((users, k)) / np.sqrt(k)).astype(np.float32)
-    V = (rng.standard_normal((items, k)) / np.sqrt(k)).astype(np.float32)
-    d = ycnr_als.AlsDevice(k, users, items, flags=flags, chunkRatings=chunk)
+    U = (rng.standard_normal((users, k)) / np.sqrt(k)).astype(dt)
+    V = (rng.standard_normal((items, k)) / np.sqrt(k)).astype(dt)
+    d = ycnr_als.AlsDevice(k, users, items, useDoublePrecision=dbl, flags=flags, chunkRatings=chunk)
     d.set_ratings('byUser', bu.rowPtr, bu.indx, bu.vals); d.set_ratings('byItem', bi.rowPtr, bi.indx, bi.vals)
     d.set_factors('byUser', U); d.set_factors('byItem', V)
-    d.step('byUser'); U1 = d.get_factors('byUser'); d.step('byItem'); V1 = d.get_factors('byItem'); d.destroy()
+    d.step('byUser'); U1 = d.get_factors('byUser'); d.step('byItem'); V1 = d.get_factors('byItem')
+    if 256 * 1024 <= rowPtr[-1] < 2 * 1024 * 1024 and k <= 128:  # the graph path: capture and replay must reproduce the first run
+        for _ in range(2):
+            d.set_factors('byUser', U); d.set_factors('byItem', V)
+            d.step('byUser'); d.step('byItem')
+            assert np.array_equal(d.get_factors('byUser'), U1) and np.array_equal(d.get_factors('byItem'), V1), 'graph replay differs'
+    d.destroy()
     for got, csr, fixed, old, side in ((U1, bu, V, U, 'U'), (V1, bi, U1, V, 'V')):
         want, amp = numpy_step(0.05, k, csr, fixed, old)
         err = row_rel_err(got, want)
-        bound = np.maximum(8 * amp * EPS, 1e-6)
+        bound = np.full(len(amp), 1e-9) if dbl else np.maximum(8 * amp * EPS, 1e-6)
         worst = max(worst, float((err / bound).max()))
         if not (err <= bound).all():
             r = int(np.argmax(err / bound))
-            print('FAIL', side, 'k', k, 'users', users, 'items', items, 'flags', flags, 'chunk', chunk, 'row', r, 'n', int(np.diff(csr.rowPtr)[r]), 'err', float(err[r]), 'bound', float(bound[r]))
+            print('FAIL', side, 'k', k, 'f64' if dbl else 'f32', 'users', users, 'items', items, 'flags', flags, 'chunk', chunk, 'row', r, 'n', int(np.diff(csr.rowPtr)[r]), 'err', float(err[r]), 'bound', float(bound[r]))
             sys.exit(1)
     runs += 1
 print('ok:', runs, 'random problems, worst err / bound = %.3f' % worst)
