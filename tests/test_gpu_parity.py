@@ -738,3 +738,28 @@ def test_four_rows_per_wave_kernel_against_the_one_row_kernel(tmp_path):
         d = np.abs(a[name].astype(np.float64) - b[name]).max(axis=1) / np.maximum(np.abs(b[name]).max(axis=1), 1e-30)
         assert d.max() <= 2e-5, (name, float(d.max()))
     assert not np.array_equal(a["U"], b["U"])
+
+
+@pytest.mark.gpu
+def test_gram32_kernels_against_the_shipped_gramian(tmp_path):
+    """k = 256: YCNR_G32=1 sends the Gramians of whole rows and of the chunks of heavy rows through
+    als_gram32_kernels.hip.h (32 x 32 x 16 bf16 MFMAs, one wave per SIMD) instead of WgGram (16 x 16 x 32, two waves per
+    SIMD).  Same exact products, a different order of the sums over a row's ratings: the two must agree to float32
+    rounding on every row and differ somewhere (else the toggle did nothing).  The toggle is read once per process, so
+    each result comes from a child process of bench.py."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = [sys.executable, os.path.join(root, "bench.py"), "--workload", "c3k256", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    wg, g32 = str(tmp_path / "wg.npz"), str(tmp_path / "g32.npz")
+    env = dict(os.environ)
+    env.pop("YCNR_G32", None)
+    subprocess.check_call(common + ["--dump-factors", wg], timeout=900, env=env, stdout=subprocess.DEVNULL)
+    env["YCNR_G32"] = "1"
+    subprocess.check_call(common + ["--dump-factors", g32], timeout=900, env=env, stdout=subprocess.DEVNULL)
+    a, b = np.load(wg), np.load(g32)
+    for name in ("U", "V"):
+        d = np.abs(a[name].astype(np.float64) - b[name]).max(axis=1) / np.maximum(np.abs(b[name]).max(axis=1), 1e-30)
+        assert d.max() <= 2e-5, (name, float(d.max()))
+    assert not np.array_equal(a["V"], b["V"])
+    assert abs(float(a["rmse"]) - float(b["rmse"])) < 1e-6

@@ -7,7 +7,7 @@
 #include "../../include/ycnr_als.h"
 #include "als_kernels.hip.h"
 #include "als_wg_kernels.hip.h"
-#include "als_pair_kernels.hip.h"
+#include "als_gram32_kernels.hip.h"
 #include "als_gen_kernels.hip.h"
 #include "prep_kernels.hip.h"
 #include <hipcub/hipcub.hpp>
@@ -204,13 +204,13 @@ void build_schedule(const int64_t *rowPtr, int64_t rowBegin, int64_t nRows, int 
 
 // environment toggles for A/B experiments from unmodified hosts, read once per process
 struct EnvFlags {
-  bool noDualX6, noX6d, noFusedX6d, noOverlap, ignoreNumeric, noDualQuad, noGraph, noPair;
+  bool noDualX6, noX6d, noFusedX6d, noOverlap, ignoreNumeric, noDualQuad, noGraph, noPair, g32;
   size_t k1LdsPad;
 };
 const EnvFlags &env_flags() {
   static const EnvFlags f = {getenv("YCNR_NO_DUAL_X6") != nullptr, getenv("YCNR_NO_X6D") != nullptr, getenv("YCNR_NO_FUSED_X6D") != nullptr,
                              getenv("YCNR_NO_OVERLAP") != nullptr, getenv("YCNR_IGNORE_NUMERIC") != nullptr, getenv("YCNR_NO_DUAL_QUAD") != nullptr,
-                             getenv("YCNR_NO_GRAPH") != nullptr, getenv("YCNR_NO_PAIR") != nullptr,
+                             getenv("YCNR_NO_GRAPH") != nullptr, getenv("YCNR_NO_PAIR") != nullptr, getenv("YCNR_G32") != nullptr,
                              getenv("YCNR_K1_LDSPAD") ? (size_t)atoi(getenv("YCNR_K1_LDSPAD")) : 0};
   return f;
 }
@@ -460,8 +460,19 @@ int launch_wg_nb(StepArgs<float> args, int64_t nSplitUnits, int64_t nPrimal, int
   const int64_t cus = device_cus();
   args.firstFused = (int32_t)nSplitUnits;
   if (ev) HIP_TRY(hipEventRecord(ev[0], stream));
+  // NB = 16, YCNR_G32=1: the Gramians on 32 x 32 MFMAs, one wave per SIMD (als_gram32_kernels.hip.h) -- measured equal to
+  // WgGram on one GPU's eighth of C5 (both are bound by the power the bf16 pipe + the split draw), so off
+  const bool g32 = NB == kPairNB && env_flags().g32;
+  if (g32) {
+    if (int rc = set_max_lds(reinterpret_cast<const void *>(als_g32_slab_kernel), (size_t)G32Cfg::LDS_BYTES)) return rc;
+    if (int rc = set_max_lds(reinterpret_cast<const void *>(als_g32_rowslab_kernel), (size_t)G32Cfg::LDS_BYTES)) return rc;
+  }
   if (nSplitUnits > 0) {
-    hipLaunchKernelGGL(k0, dim3((unsigned)std::min(nSplitUnits, cus)), dim3(kWgThreads), lds, stream, args, (int32_t)nSplitUnits);
+    if (g32)
+      hipLaunchKernelGGL(als_g32_slab_kernel, dim3((unsigned)std::min(nSplitUnits, cus)), dim3(kG32Threads), (size_t)G32Cfg::LDS_BYTES, stream, args,
+                         (int32_t)nSplitUnits);
+    else
+      hipLaunchKernelGGL(k0, dim3((unsigned)std::min(nSplitUnits, cus)), dim3(kWgThreads), lds, stream, args, (int32_t)nSplitUnits);
     HIP_TRY(hipGetLastError());
   }
   if (ev) HIP_TRY(hipEventRecord(ev[1], stream));
@@ -477,7 +488,11 @@ int launch_wg_nb(StepArgs<float> args, int64_t nSplitUnits, int64_t nPrimal, int
       for (int64_t b0 = 0; b0 < nPrimal; b0 += rowSlabRows) {
         const int64_t cnt = std::min(rowSlabRows, nPrimal - b0);
         const int32_t first = (int32_t)(nSplitUnits + b0);
-        hipLaunchKernelGGL(kg, dim3((unsigned)std::min(cnt, cus)), dim3(kWgThreads), lds, stream, args, rowSlabs, first, (int32_t)cnt);
+        if (g32)
+          hipLaunchKernelGGL(als_g32_rowslab_kernel, dim3((unsigned)std::min(cnt, cus)), dim3(kG32Threads), (size_t)G32Cfg::LDS_BYTES, stream, args,
+                             rowSlabs, first, (int32_t)cnt);
+        else
+          hipLaunchKernelGGL(kg, dim3((unsigned)std::min(cnt, cus)), dim3(kWgThreads), lds, stream, args, rowSlabs, first, (int32_t)cnt);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(ks, dim3((unsigned)cnt), dim3(kPairThreads), (size_t)PairCfg<NB>::LDS_BYTES, stream, args, (const float *)rowSlabs, first);
         HIP_TRY(hipGetLastError());
