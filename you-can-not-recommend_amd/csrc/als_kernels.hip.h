@@ -1591,10 +1591,20 @@ __device__ __forceinline__ float bpermute_opaque(int byteAddr, float v) {
 //     its DMA before it ends: LDS is handed to the next workgroup when the wave retires.
 // Needs k % 4 == 0 (16-byte aligned rows) and the fixed matrix < 2 GB.  Results are bitwise
 // those of als_gram_slab_x6_kernel for the tiles; with PADRHS b comes out of the MFMAs.
+//
+// PK3 (k = 16 (NB - 1) + 4 with PADRHS, e.g. k = 20, 100: round 3).  The last block then has five live
+// columns (four of Y and the ratings), so its three bf16 planes fit ONE operand: lanes 0..4 keep the high
+// terms, lanes 5..9 take the middle terms of columns 0..4 and lanes 10..14 the low ones (two v_or_b32_dpp
+// row_shr per register).  A tile of the last block column is then three MFMAs -- A_l, A_m, A_h against the
+// packed operand: all nine products -- instead of six, 147 MFMAs per 32 ratings instead of 168 at k = 100;
+// its accumulator holds three partial columns per live column, folded (row_shl 5 / 10) once per row in
+// extract_rhs.  The chip runs these kernels at its package power limit, so an eighth
+// fewer MFMAs is an eighth less of what bounds them.
 typedef __attribute__((address_space(3))) void *lds_void_ptr;
 
-template <int NB, bool PADRHS>
+template <int NB, bool PADRHS, bool PK3 = false>
 struct GramX6D {
+  static_assert(!PK3 || PADRHS, "the packed last block needs the padded form");
   using acc_t = typename MfmaTraits<float>::acc_t;
   typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -1628,6 +1638,7 @@ struct GramX6D {
     const unsigned rdBase = ldsBase + (unsigned)(g >> 1) * 1024u + (unsigned)((g & 1) * 16 + c) * 4u;
 
     u32x4 p1[NB], p2[NB], p3[NB];
+    [[maybe_unused]] u32x4 pk = {0u, 0u, 0u, 0u};  // PK3: the three planes of the last block's five live columns in one operand
     unsigned offH[2];
     float rr[8];
 
@@ -1659,15 +1670,22 @@ struct GramX6D {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_void_ptr)(lds + (2 * b + 1) * 256), 16, offH[1], b * 64, 0, 0);
     };
     auto mma_row = [&](int bi) {
+      constexpr int NBF = PK3 ? NB - 1 : NB;  // block columns multiplied plane by plane
 #pragma unroll
       for (int term = 0; term < 6; ++term) {
 #pragma unroll
-        for (int bj = bi; bj < NB; ++bj) {
+        for (int bj = bi; bj < NBF; ++bj) {
           const u32x4 &pa = term == 0 ? p2[bi] : (term == 1 || term == 3 || term == 5) ? p1[bi] : (term == 2 ? p3[bi] : p2[bi]);
           const u32x4 &pb = term == 0 ? p2[bj] : term == 1 ? p3[bj] : term == 2 ? p1[bj] : term == 3 ? p2[bj] : p1[bj];
           acc[tile_index(bi, bj, NB)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
               __builtin_bit_cast(bf16x8, pa), __builtin_bit_cast(bf16x8, pb), acc[tile_index(bi, bj, NB)], 0, 0, 0);
         }
+      }
+      if constexpr (PK3) {  // the last block column against the packed operand, smallest terms first
+        acc_t &t = acc[tile_index(bi, NB - 1, NB)];
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, p3[bi]), __builtin_bit_cast(bf16x8, pk), t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, p2[bi]), __builtin_bit_cast(bf16x8, pk), t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, p1[bi]), __builtin_bit_cast(bf16x8, pk), t, 0, 0, 0);
       }
     };
     const float padOne = (PADRHS && c == kr) ? 1.0f : 0.0f;
@@ -1753,6 +1771,14 @@ struct GramX6D {
           p1[bi] = u32x4{h[0], h[1], h[2], h[3]};
           p2[bi] = u32x4{m[0], m[1], m[2], m[3]};
           p3[bi] = u32x4{l[0], l[1], l[2], l[3]};
+          if constexpr (PK3) {
+            if (bi == NB - 1) {  // columns > kr hold zeros in every plane, so the shifted planes land on empty lanes
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                pk[e] = h[e] | (unsigned)__builtin_amdgcn_update_dpp(0, (int)m[e], 0x115, 0xF, 0xF, true) |  // row_shr:5
+                        (unsigned)__builtin_amdgcn_update_dpp(0, (int)l[e], 0x11A, 0xF, 0xF, true);           // row_shr:10
+            }
+          }
         }
       }
     };
@@ -1782,6 +1808,19 @@ struct GramX6D {
 #pragma unroll
     for (int cb = 0; cb < NB; ++cb) {
       acc_t &tl = acc[tile_index(cb, NB - 1, NB)];
+#ifndef YCNR_PK3_NOFOLD  // (devtest/x6many.hip prints the unfolded partial columns with it)
+      if constexpr (PK3) {  // columns c, c + 5, c + 10 are the partial sums of live column c; the rest is emptied
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          float e = tl[t];
+          asm volatile("" : "+v"(e));  // hipcc (ROCm 7.2) otherwise feeds element 0 of the tile to all four shifts (cf. bpermute_opaque)
+          const int v = __builtin_bit_cast(int, e);
+          const float a5 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, v, 0x105, 0xF, 0xF, true));   // row_shl:5
+          const float a10 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, v, 0x10A, 0xF, 0xF, true));  // row_shl:10
+          tl[t] = c <= kr ? (e + a5) + a10 : 0.0f;
+        }
+      }
+#endif
       float w[4];
       bpermute4_opaque(src << 2, tl, w);
       float v = 0.0f;
@@ -1798,9 +1837,9 @@ struct GramX6D {
   }
 };
 
-template <int NB, bool PADRHS>
+template <int NB, bool PADRHS, bool PK3 = false>
 __global__ __launch_bounds__(64, 2) void als_gram_slab_x6d_kernel(StepArgs<float> a) {
-  using G = GramX6D<NB, PADRHS>;
+  using G = GramX6D<NB, PADRHS, PK3>;
   using acc_t = typename G::acc_t;
   constexpr int NT = G::NT;
   __shared__ __attribute__((aligned(16))) unsigned lds[G::LDS_DWORDS];
@@ -1865,10 +1904,10 @@ __global__ __launch_bounds__(64, sizeof(T) == 8 ? 1 : YCNR_FUSED_WAVES_PER_SIMD)
 
 // Kernel 1b': the fused row kernel with the bf16x6 / LDS-DMA Gramian (GramX6D) in place of the
 // float32-MFMA one; the solve is unchanged.  float32, k % 4 == 0, k <= 112, fixed matrix < 2 GB.
-template <int NB, bool PADRHS, bool LDS_SOLVER, bool E4 = false>
+template <int NB, bool PADRHS, bool LDS_SOLVER, bool E4 = false, bool PK3 = false>
 __global__ __launch_bounds__(64, 2) void als_gram_solve_x6d_kernel(StepArgs<float> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  using G = GramX6D<NB, PADRHS>;
+  using G = GramX6D<NB, PADRHS, PK3>;
   using acc_t = typename G::acc_t;
   __shared__ __attribute__((aligned(16))) unsigned ring[G::LDS_DWORDS];
   const int lane = threadIdx.x;

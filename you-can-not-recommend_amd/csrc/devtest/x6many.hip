@@ -1,7 +1,8 @@
 // Many short units at once (8 blocks per CU): als_gram_slab_x6d_kernel against the float32-MFMA
 // slab kernel, unit by unit.  x6many <nb:1..7> <k> <n> <units>     (exit code 1: some unit differs)
 // tests/test_gpu_hazard.py runs the shipped build of it over every block count and both forms of
-// the right-hand side (k = 16 nb: VALU accumulators, k < 16 nb: the padded Gramian column).
+// the right-hand side (k = 16 nb: VALU accumulators, k < 16 nb: the padded Gramian column; k = 16 (nb - 1) + 4: the
+// last block's planes packed into one operand, unless YCNR_NO_PK3 is set).
 // Built with -DYCNR_X6D_ALLOW_PK (the right-hand side's multiply-adds packed across blocks) the
 // k % 16 == 0 form fails for a few per cent of the units at 8 workgroups per CU.
 #include "../als_kernels.hip.h"
@@ -11,7 +12,7 @@
 #include <vector>
 #include <random>
 using namespace ycnr;
-template <int NB, bool PAD>
+template <int NB, bool PAD, bool PK3 = false>
 int run(int k, int n, int units, int items) {
   std::mt19937 rng(7);
   std::normal_distribution<float> nd(0.f, 1.f / std::sqrt((float)k));
@@ -30,11 +31,18 @@ int run(int k, int n, int units, int items) {
   StepArgs<float> a{du, nullptr, dindx, dvals, dV, dz, nullptr, dA, nullptr, 0.05, k, 0, 0, (uint32_t)(V.size() * 4)};
   hipLaunchKernelGGL((als_gram_slab_kernel<float, NB, false>), dim3(units), dim3(64), 0, 0, a);
   a.slabs = dB;
-  hipLaunchKernelGGL((als_gram_slab_x6d_kernel<NB, PAD>), dim3(units), dim3(64), 0, 0, a);
+  hipLaunchKernelGGL((als_gram_slab_x6d_kernel<NB, PAD, PK3>), dim3(units), dim3(64), 0, 0, a);
   hipError_t e = hipDeviceSynchronize();
   std::vector<float> A(se * units), B(se * units);
   hipMemcpy(A.data(), dA, A.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(B.data(), dB, B.size() * 4, hipMemcpyDeviceToHost);
   const size_t ntile = (size_t)tile_count(NB) * 4 * 64;
+  if (getenv("YCNR_X6MANY_DUMP")) {  // rows 0 and 1 of the last tile of unit 0, all 16 columns: lane (g, c) holds rows 4 g + t of column c
+    const int t = tile_count(NB) - 1;
+    for (int r = 0; r < 2; ++r) {
+      printf("ref  row %d:", r); for (int c = 0; c < 16; ++c) printf(" %10.6f", A[(size_t)t * 256 + c * 4 + r]); printf("\n");
+      printf("x6d  row %d:", r); for (int c = 0; c < 16; ++c) printf(" %10.6f", B[(size_t)t * 256 + c * 4 + r]); printf("\n");
+    }
+  }
   int badUnits = 0, shown = 0;
   long badBlock[16] = {0};
   for (int u = 0; u < units; ++u) {
@@ -62,7 +70,7 @@ int main(int argc, char **argv) {
   int bad = 0;
   const int items = 20000;
 #define YCNR_NB(NBV) \
-  if (nb == NBV) bad = k < 16 * NBV ? run<NBV, true>(k, n, units, items) : run<NBV, false>(k, n, units, items);
+  if (nb == NBV) bad = k < 16 * NBV ? (k == 16 * (NBV - 1) + 4 && !getenv("YCNR_NO_PK3") ? run<NBV, true, true>(k, n, units, items) : run<NBV, true>(k, n, units, items)) : run<NBV, false>(k, n, units, items);
   YCNR_NB(1) YCNR_NB(2) YCNR_NB(3) YCNR_NB(4) YCNR_NB(5) YCNR_NB(6) YCNR_NB(7)
 #undef YCNR_NB
   return bad != 0;

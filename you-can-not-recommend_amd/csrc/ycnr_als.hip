@@ -204,13 +204,13 @@ void build_schedule(const int64_t *rowPtr, int64_t rowBegin, int64_t nRows, int 
 
 // environment toggles for A/B experiments from unmodified hosts, read once per process
 struct EnvFlags {
-  bool noDualX6, noX6d, noFusedX6d, noOverlap, ignoreNumeric, noDualQuad, noGraph, noPair, g32;
+  bool noDualX6, noX6d, noFusedX6d, noOverlap, ignoreNumeric, noDualQuad, noGraph, noPair, g32, noPk3;
   size_t k1LdsPad;
 };
 const EnvFlags &env_flags() {
   static const EnvFlags f = {getenv("YCNR_NO_DUAL_X6") != nullptr, getenv("YCNR_NO_X6D") != nullptr, getenv("YCNR_NO_FUSED_X6D") != nullptr,
                              getenv("YCNR_NO_OVERLAP") != nullptr, getenv("YCNR_IGNORE_NUMERIC") != nullptr, getenv("YCNR_NO_DUAL_QUAD") != nullptr,
-                             getenv("YCNR_NO_GRAPH") != nullptr, getenv("YCNR_NO_PAIR") != nullptr, getenv("YCNR_G32") != nullptr,
+                             getenv("YCNR_NO_GRAPH") != nullptr, getenv("YCNR_NO_PAIR") != nullptr, getenv("YCNR_G32") != nullptr, getenv("YCNR_NO_PK3") != nullptr,
                              getenv("YCNR_K1_LDSPAD") ? (size_t)atoi(getenv("YCNR_K1_LDSPAD")) : 0};
   return f;
 }
@@ -305,12 +305,16 @@ void (*slab_x6_kernel())(StepArgs<T>) { return nullptr; }
 YCNR_X6(1) YCNR_X6(2) YCNR_X6(3) YCNR_X6(4) YCNR_X6(5) YCNR_X6(6) YCNR_X6(7) YCNR_X6(8)
 #undef YCNR_X6
 
+// k = 16 (NB - 1) + 4: the last block's planes packed into one operand (GramX6D's PK3); YCNR_NO_PK3=1 for A/B runs
+template <int NB>
+bool pk3_k(int k) { return k == 16 * (NB - 1) + 4 && !env_flags().noPk3; }
+
 // the same Gramian with the gather staged through LDS by LDS-DMA: fits two waves per SIMD up to k = 112
 template <typename T, int NB>
 void (*slab_x6d_kernel(int))(StepArgs<T>) { return nullptr; }
 #define YCNR_X6D(NBV) \
   template <>         \
-  void (*slab_x6d_kernel<float, NBV>(int k))(StepArgs<float>) { return k % 4 ? nullptr : k < 16 * NBV ? als_gram_slab_x6d_kernel<NBV, true> : als_gram_slab_x6d_kernel<NBV, false>; }
+  void (*slab_x6d_kernel<float, NBV>(int k))(StepArgs<float>) { return k % 4 ? nullptr : k < 16 * NBV ? (pk3_k<NBV>(k) ? als_gram_slab_x6d_kernel<NBV, true, true> : als_gram_slab_x6d_kernel<NBV, true, false>) : als_gram_slab_x6d_kernel<NBV, false>; }
 YCNR_X6D(1) YCNR_X6D(2) YCNR_X6D(3) YCNR_X6D(4) YCNR_X6D(5) YCNR_X6D(6) YCNR_X6D(7)
 #undef YCNR_X6D
 
@@ -323,7 +327,7 @@ template <typename T, int NB, bool LDS_SOLVER>
 void (*fused_x6d_kernel(int))(StepArgs<T>) { return nullptr; }
 #define YCNR_X6D(NBV, LDSV) \
   template <>               \
-  void (*fused_x6d_kernel<float, NBV, LDSV>(int k))(StepArgs<float>) { return k % 4 ? nullptr : k < 16 * NBV ? (edge4_k<NBV, LDSV>(k) ? als_gram_solve_x6d_kernel<NBV, true, LDSV, true> : als_gram_solve_x6d_kernel<NBV, true, LDSV, false>) : als_gram_solve_x6d_kernel<NBV, false, LDSV, false>; }
+  void (*fused_x6d_kernel<float, NBV, LDSV>(int k))(StepArgs<float>) { return k % 4 ? nullptr : k < 16 * NBV ? (edge4_k<NBV, LDSV>(k) ? (pk3_k<NBV>(k) ? als_gram_solve_x6d_kernel<NBV, true, LDSV, true, true> : als_gram_solve_x6d_kernel<NBV, true, LDSV, true, false>) : (pk3_k<NBV>(k) ? als_gram_solve_x6d_kernel<NBV, true, LDSV, false, true> : als_gram_solve_x6d_kernel<NBV, true, LDSV, false, false>)) : als_gram_solve_x6d_kernel<NBV, false, LDSV, false>; }
 YCNR_X6D(1, false) YCNR_X6D(2, false) YCNR_X6D(3, false) YCNR_X6D(4, false) YCNR_X6D(5, false) YCNR_X6D(6, false) YCNR_X6D(7, false)
 YCNR_X6D(1, true) YCNR_X6D(2, true) YCNR_X6D(3, true) YCNR_X6D(4, true) YCNR_X6D(5, true) YCNR_X6D(6, true) YCNR_X6D(7, true)
 #undef YCNR_X6D
