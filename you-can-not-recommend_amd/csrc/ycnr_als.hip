@@ -464,6 +464,20 @@ int launch_wg_nb(StepArgs<float> args, int64_t nSplitUnits, int64_t nPrimal, int
   const int64_t cus = device_cus();
   args.firstFused = (int32_t)nSplitUnits;
   if (ev) HIP_TRY(hipEventRecord(ev[0], stream));
+  // The dual classes go to the side streams, in front of the Gramian / solve batches (round 3).  A Gramian or solve workgroup
+  // fills a CU's register file, so the two kinds never share a CU -- but the one-wave dual kernels take the CUs that a
+  // batch kernel's tail has already left: the user half-step of one GPU's eighth of C5 76.5 -> 73.5 ms (interleaved A/B,
+  // YCNR_NO_OVERLAP=1).  (Tried on top and dropped: the solve of batch i on a second stream beside the Gramians of batch
+  // i + 1 on fewer CUs -- 224 / 192 / 160 / 128 CUs for the Gramians: +3.7 / +10 / +20 / +40 ms per iteration.)
+  const bool sideDuals = dp.nPrimal >= 0 && dp.nSide > 0 && dp.fork;
+  if (sideDuals) {
+    HIP_TRY(hipEventRecord(dp.fork, stream));
+    for (int i = 0; i < dp.nSide; ++i) HIP_TRY(hipStreamWaitEvent(dp.side[i], dp.fork, 0));
+    dp.nextSide = 0;
+    int rc = launch_duals<float>(args, dp, stream);
+    if (rc) return rc;
+    for (int i = 0; i < dp.nSide; ++i) HIP_TRY(hipEventRecord(dp.join[i], dp.side[i]));
+  }
   // NB = 16, YCNR_G32=1: the Gramians on 32 x 32 MFMAs, one wave per SIMD (als_gram32_kernels.hip.h) -- measured equal to
   // WgGram on one GPU's eighth of C5 (both are bound by the power the bf16 pipe + the split draw), so off
   const bool g32 = NB == kPairNB && env_flags().g32;
@@ -509,12 +523,14 @@ int launch_wg_nb(StepArgs<float> args, int64_t nSplitUnits, int64_t nPrimal, int
     HIP_TRY(hipGetLastError());
   }
   if (ev) HIP_TRY(hipEventRecord(ev[2], stream));
-  if (dp.nPrimal >= 0) {
-    DualPlan serial = dp;  // these kernels fill the register file: the dual classes follow in stream order
+  if (dp.nPrimal >= 0 && !sideDuals) {  // (YCNR_FLAG_NO_OVERLAP, or too few rows to pay for the fork and the joins)
+    DualPlan serial = dp;
     serial.nSide = 0;
     int rc = launch_duals<float>(args, serial, stream);
     if (rc) return rc;
   }
+  if (sideDuals)
+    for (int i = 0; i < dp.nSide; ++i) HIP_TRY(hipStreamWaitEvent(stream, dp.join[i], 0));
   if (ev) HIP_TRY(hipEventRecord(ev[3], stream));
   if (nSplit > 0) {
     hipLaunchKernelGGL(k2, dim3((unsigned)std::min(nSplit, cus)), dim3(kWgThreads), lds, stream, args, (int32_t)nSplit);
@@ -1791,7 +1807,7 @@ int ycnr_als_step_async(ycnr_als *h, int side) {
       h->info.dualRows += S.dualRows;
       h->info.dualRatings += S.dualRatings;
       h->info.dualFlops += S.dualFlops;
-      if (S.dualRows >= kMinOverlapDualRows && h->opt.factorsCount <= kMaxFactors && !(h->opt.flags & YCNR_FLAG_NO_OVERLAP) &&
+      if (S.dualRows >= kMinOverlapDualRows && !is_gen(YCNR_F32, h->opt.factorsCount) && !(h->opt.flags & YCNR_FLAG_NO_OVERLAP) &&
           !env_flags().noOverlap)
         h->info.dualOverlapped = 1;
     }
