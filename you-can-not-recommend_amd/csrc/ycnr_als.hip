@@ -56,7 +56,10 @@ constexpr int kMaxFactorsAny = 4096; // beyond kMaxFactorsBig (float64: kMaxFact
 constexpr int kGenChunk = 4096;      // ratings per unit of the any-k path (als_gen_kernels.hip.h): every row goes through slabs there
 constexpr int64_t kGenArenaBytes = (int64_t)2 << 30;  // slab arena of that path: rows are solved in batches that fit it
 constexpr int kPairNB = 16;           // block count whose whole rows go Gramian -> slab -> two-wave solve (als_pair_kernels.hip.h): 240 < k <= 256
-constexpr int64_t kPairBatchRows = 12288;  // rows per batch of that path (a slab is 140 KB: 1.7 GB of arena)
+constexpr int64_t kPairBatchRows = 4096;   // rows per batch of that path (a slab is 140 KB: 0.57 GB of arena).  One GPU's eighth of C5, ms per
+                                           // iteration at 512 / 1024 / 2048 / 3072 / 4096 / 6144 / 8192 / 12288 / 24576 / 98304 rows: 141.6 / 138.0 / 136.7 /
+                                           // 136.3 / 136.2 / 136.5 / 137.3 / 139.7 / 138.6 / 137.6 -- short batches leave more of a batch's slabs in the
+                                           // last-level cache for its solve, shorter ones pay two kernel tails per batch (YCNR_PAIR_BATCH_ROWS overrides)
 constexpr int kWgChunk = 8192;       // ratings per chunk of a row that is split over workgroups (k > 128)
 constexpr int kWgFusedMax = 16384;   // longest row one workgroup takes whole (k > 128)
 constexpr int kDefaultChunk = 1024;  // ratings per split unit (and the largest fused row)
@@ -1449,7 +1452,9 @@ static int build_part(ycnr_als *h, int side, const int64_t *rowPtr, const int32_
     S.dualFlops += nd * (nd + 1) * kd + nd * nd * nd / 3.0 + 2.0 * nd * nd + 2.0 * nd * kd;
   }
   if (big && slab_nb(h->kPad ? h->kPad : h->opt.factorsCount) == kPairNB && S.nPrimal > 0 && !env_flags().noPair) {
-    S.rowSlabRows = std::min<int64_t>(S.nPrimal, kPairBatchRows);
+    int64_t batchRows = kPairBatchRows;
+    if (const char *e = getenv("YCNR_PAIR_BATCH_ROWS")) batchRows = std::max(256, atoi(e));  // read per upload
+    S.rowSlabRows = std::min<int64_t>(S.nPrimal, batchRows);
     HIP_TRY(hipMalloc(&S.dRowSlabs, (size_t)S.rowSlabRows * (size_t)wg_slab_floats(kPairNB) * sizeof(float)));
   }
   if (S.nUnits) {
