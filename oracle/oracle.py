@@ -10,7 +10,9 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "_build", "libals_oracle.so")
+# YCNR_ORACLE_LIB: another build of the same sources (`make -C oracle asan`: AddressSanitizer + UBSan, run with the
+# sanitizer runtimes preloaded -- see the Makefile)
+_SO = os.environ.get("YCNR_ORACLE_LIB") or os.path.join(_HERE, "_build", "libals_oracle.so")
 _lib = None
 
 i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
@@ -23,6 +25,8 @@ def build(force=False):
     """Compile the oracle with gcc if the .so is missing or stale."""
     srcs = [os.path.join(_HERE, f) for f in ("als_oracle.c", "als_oracle_impl.h")]
     stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
+    if os.environ.get("YCNR_ORACLE_LIB"):
+        return _SO
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
     return _SO
