@@ -405,6 +405,7 @@ def emulate_world(args, local_rank):
                                     "dbType": "mal" if max_rating == 10 else "ml", "chunkRatings": args.chunk, "dataSetDistr": [100, 0, 0],
                                     "exchangeChunks": args.exchange_chunks, "commTransport": "stub", "rebalanceAfterIters": 0},
                             dist=EmulatedDist(r, W))
+            t_rank = time.time()
             lord.prepareToTrain(ds, seed=20260004, device=local_rank, shards=shards)
             used = {s: np.asarray(lord.shards[s]).tolist() for s in (0, 1)}
             for _ in range(max(args.warmup, 1)):
@@ -424,6 +425,10 @@ def emulate_world(args, local_rank):
             lord.destroy()
             del lord
             torch.cuda.empty_cache()
+            # (progress on stderr: at C5 scale a rank takes a minute of host-side preparation, and a silent run looks hung)
+            print(f"emulate-world: rank {r + 1}/{W} of the {'cost-model' if shards is None else 'feedback'} cut done in "
+                  f"{time.time() - t_rank:.1f} s: byUser {per['byUser']['compute_ms'][-1]} ms, byItem {per['byItem']['compute_ms'][-1]} ms",
+                  file=sys.stderr, flush=True)
         for n in names:
             c = np.asarray(per[n]["compute_ms"])
             per[n]["imbalance_max_over_mean"] = round(float(c.max() / c.mean()), 4)
