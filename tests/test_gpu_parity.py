@@ -763,3 +763,38 @@ def test_gram32_kernels_against_the_shipped_gramian(tmp_path):
         assert d.max() <= 2e-5, (name, float(d.max()))
     assert not np.array_equal(a["V"], b["V"])
     assert abs(float(a["rmse"]) - float(b["rmse"])) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [4, 20, 36, 64, 100, 112, 128, 256])
+def test_signed_fractional_ratings(als, k):
+    """Ratings that are neither positive nor exact in bf16 (standard normal x 3, a few exact zeros and tiny values): the
+    right-hand side then needs all three bf16 planes of the ratings, and a negative rating must not leak a sign bit into
+    a padded lane (at k = 16 m + 4 the planes of the last block share one MFMA operand: a "-0" in a padded lane of the high
+    plane flipped the sign of another column's middle term -- found by the full-size linearity test, reproduced here at
+    test size).  Whole rows in primal form, rows cut into chunks, and the dual classes, against float64."""
+    from ycnr_als import _lib
+    items = 600
+    lens = [1, 5, 16, 17, 40, 80, 81, 97, 130, 177, 200, 333, 500, 0, 64] * 3
+    rng = np.random.default_rng(1000 + k)
+    rowPtr = np.zeros(len(lens) + 1, np.int64)
+    rowPtr[1:] = np.cumsum(lens)
+    indx = np.concatenate([np.sort(rng.choice(items, n, replace=False)) for n in lens] + [np.zeros(0, np.int64)]).astype(np.int32)
+    vals = (rng.standard_normal(rowPtr[-1]) * 3.0).astype(np.float32)
+    vals[::37] = 0.0
+    vals[5::41] *= 1e-6
+    bu = Csr(len(lens), items, rowPtr, indx, vals)
+    U = np.zeros((len(lens), k), np.float32)
+    V = (rng.standard_normal((items, k)) / np.sqrt(k)).astype(np.float32)
+    want, conds = numpy_step(0.05, k, bu, V, U)
+    for name, flags, chunk in (("default", 0, 0), ("primal", _lib.FLAG_NO_DUAL, 0), ("chunks", _lib.FLAG_NO_DUAL, 64)):
+        dev = als.AlsDevice(k, len(lens), items, flags=flags, chunkRatings=chunk)
+        dev.set_ratings("byUser", bu.rowPtr, bu.indx, bu.vals)
+        dev.set_factors("byUser", U)
+        dev.set_factors("byItem", V)
+        info = dev.step("byUser")
+        assert info.numericErrors == 0, name
+        if name == "chunks":
+            assert info.splitRows > 0
+        check_rows(dev.get_factors("byUser"), want, conds, np.float32)
+        dev.destroy()

@@ -1733,7 +1733,8 @@ struct GramX6D {
               float rv[8];
               read_r(s + 1, rv);
 #pragma unroll
-              for (int j = 0; j < 8; ++j) x[j] = lastLive ? x[j] : rv[j] * padOne;
+              for (int j = 0; j < 8; ++j) x[j] = lastLive ? x[j] : (padOne != 0.0f ? rv[j] : 0.0f);  // (not rv * 0: a negative rating would leave -0,
+                                                                                                     // whose sign bit the packed operand of PK3 ORs into another column's term)
             } else {
 #pragma unroll
               for (int j = 0; j < 8; ++j) x[j] = lastLive ? x[j] : 0.0f;
