@@ -271,9 +271,9 @@ def test_full_size_iteration(als, oracle, name):
         assert bool((U1[lu == 0] == 7.0).all())  # rows without ratings untouched
     rec = {"config": name, "k": k, "nnz": bu.nnz, "byUser_ms": iu.totalMs, "byItem_ms": ii.totalMs,
            "splitRows": [int(iu.splitRows), int(ii.splitRows)], "dualRows": [int(iu.dualRows), int(ii.dualRows)]}
-    # one sampling bucket per dual-form class of the library (16-rating blocks up to 176 ratings for k > 128, up to 80
+    # one sampling bucket per dual-form class of the library (16-rating blocks up to 192 ratings for k > 128, up to 80
     # below; als_dual_quad for <= 16), whole rows, split rows, the longest rows
-    dual_max = 176 if k > 128 else 80
+    dual_max = 192 if k > 128 else 80
     lun, lin = lu.cpu().numpy(), li.cpu().numpy()
     ru = sample_by_class(lun, 60 if k <= 128 else 24, 8, 5, dual_max, 1024)
     ri = sample_by_class(lin, 40 if k <= 128 else 12, 4, 6, dual_max, 1024)

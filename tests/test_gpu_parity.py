@@ -189,7 +189,7 @@ def test_every_row_length_class(als, k):
     float32 solver variants (dual+MFMA, MFMA only, LDS) against each other."""
     from ycnr_als import _lib
     items = 400
-    lens = list(range(1, 131)) + [0, 16, 32, 48, 64, 80, 96, 97, 112, 300, 143, 144, 145, 159, 160, 161, 176]
+    lens = list(range(1, 131)) + [0, 16, 32, 48, 64, 80, 96, 97, 112, 300, 143, 144, 145, 159, 160, 161, 176, 177, 191, 192, 193]
     rng = np.random.default_rng(k)
     rowPtr = np.zeros(len(lens) + 1, np.int64)
     rowPtr[1:] = np.cumsum(lens)
@@ -212,7 +212,7 @@ def test_every_row_length_class(als, k):
         info = dev.step("byUser")
         if name == "dual":
             nb = (k + 15) // 16
-            dual_max = 16 * min(11 if k > 128 else 5, nb - 1)   # k > 128: up to 176 ratings stay one wave's n x n problem
+            dual_max = 16 * min(12 if k > 128 else 5, nb - 1)   # k > 128: up to 192 ratings stay one wave's n x n problem
             assert info.dualRows == sum(1 for n in lens if 0 < n <= dual_max)
         else:
             assert info.dualRows == 0
@@ -238,8 +238,8 @@ def test_any_factors_count(als, oracle, k, dt, monkeypatch):
     repeatability."""
     monkeypatch.setenv("YCNR_GEN_ARENA_MB", "8")  # a k = 512 image is 0.5 / 1 MB: several batches
     users, items = 60, 400
-    # (float32: rows of at most 176 ratings take the dual classes, whatever k; the longer ones the any-k kernels)
-    lens = [0, 1, 2, 15, 16, 17, 40, 90, 33, 64, 5, 77, 176, 177, 200, 260, 333] + [int(x) for x in np.random.default_rng(k).integers(1, 91, users - 17)]
+    # (float32: rows of at most 192 ratings take the dual classes, whatever k; the longer ones the any-k kernels)
+    lens = [0, 1, 2, 15, 16, 17, 40, 90, 33, 64, 5, 77, 176, 192, 193, 260, 333] + [int(x) for x in np.random.default_rng(k).integers(1, 91, users - 17)]
     rng = np.random.default_rng(5 * k)
     rowPtr = np.zeros(users + 1, np.int64)
     rowPtr[1:] = np.cumsum(lens)

@@ -67,7 +67,7 @@ constexpr int kMaxSlabsPerRow = 64;  // heavier rows get proportionally longer c
 constexpr int64_t kBandBytes = (int64_t)96 << 20;  // slice of the fixed matrix one band of chunks gathers from (cache-sized)
 constexpr size_t kErrBytes = 65536;
 constexpr size_t kZeroRowBytes = 32768 + 64;  // >= kMaxFactorsAny doubles: the "row" the dual kernels gather for ratings past a row's end
-constexpr int kMaxDualBlocks = 11;       // dual-form kernels exist for 1..11 blocks of 16 ratings (12 spills 1452 bytes per lane)
+constexpr int kMaxDualBlocks = 12;       // dual-form kernels exist for 1..12 blocks of 16 ratings (12: 340 bytes of scratch per lane, still 1.0 ms per C5-shard iteration cheaper than the primal form for rows of 177..192 ratings; 13: 936 bytes and no gain)
 constexpr int kMaxDualBlocksSmallK = 5;  // k <= 128: beyond 80 ratings the row kernel (k x k) is cheaper (MAL scale, k = 100: 6 -> 5 blocks took 0.2 ms off the user half-step once the solve had lost its readlanes and transposes; 4 was slower)
 
 size_t tsize(int dtype) { return dtype == YCNR_F64 ? 8 : 4; }
@@ -286,7 +286,8 @@ template <typename T>
 int launch_duals(const StepArgs<T> &, const DualPlan &, hipStream_t) { return YCNR_OK; }
 template <>
 int launch_duals<float>(const StepArgs<float> &args, const DualPlan &dp, hipStream_t stream) {
-  int rc = launch_dual<11>(args, dp, stream);
+  int rc = launch_dual<12>(args, dp, stream);
+  if (!rc) rc = launch_dual<11>(args, dp, stream);
   if (!rc) rc = launch_dual<10>(args, dp, stream);
   if (!rc) rc = launch_dual<9>(args, dp, stream);
   if (!rc) rc = launch_dual<8>(args, dp, stream);

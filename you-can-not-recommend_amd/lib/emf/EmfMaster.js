@@ -38,7 +38,7 @@ class EmfMaster extends EmfManager {
   static rowCost(n, k, double) {
     if (n <= 0) return 0;
     const nb = Math.ceil(k / 16);
-    const dualMax = (double || k % 4) ? 0 : 16 * Math.min(k > 128 ? 11 : 5, nb - 1);
+    const dualMax = (double || k % 4) ? 0 : 16 * Math.min(k > 128 ? 12 : 5, nb - 1);
     if (n <= dualMax) return 2700.0 * Math.pow(Math.ceil(n / 16), 1.36) * (k / 100);
     return n * (1.2 * k) + 0.0165 * k * k * k;
   }

@@ -123,7 +123,7 @@ def row_cost(counts, k, double=False):
     work per rating."""
     n = np.asarray(counts, np.float64)
     nb = (k + 15) // 16
-    dual_max = 0 if (double or k % 4) else 16 * min(11 if k > 128 else 5, nb - 1)
+    dual_max = 0 if (double or k % 4) else 16 * min(12 if k > 128 else 5, nb - 1)
     primal = n * (1.2 * k) + 0.0165 * float(k) ** 3
     dual = 2700.0 * np.ceil(n / 16.0) ** 1.36 * (k / 100.0)
     c = np.where(n <= dual_max, dual, primal)
