@@ -42,7 +42,9 @@ __host__ __device__ inline void split_counts(int64_t freeCnt, int64_t c1, int64_
   if (nw[0] + nw[1] + nw[2] < freeCnt) nw[0] += freeCnt - (nw[0] + nw[1] + nw[2]);
 }
 
-constexpr int kSplitShortRow = 1024;   // rows up to this length: 5 KB of LDS per wave, many waves per CU
+constexpr int kSplitRankRow = 192;     // rows up to this length: every rating ranked by one wave (8 n + 2560 instructions of bisection
+                                       // against 6 n^2 / 64 of ranking cross near 190 ratings)
+constexpr int kSplitShortRow = 1024;   // rows up to this length: one wave, 5 KB of LDS, many waves per CU
 constexpr int kSplitLdsKeys = 12288;   // longer rows: 60 KB per wave; beyond this keys are recomputed in the inner loop
 
 // One wave per row.  Rank of every free rating among the row's free ratings by (key, j): O(n^2 / 64)
@@ -119,6 +121,97 @@ __global__ __launch_bounds__(BLOCK) void split_to_sets_kernel(const int64_t *row
       __syncthreads();
       for (int64_t j = tid; j < n; j += BLOCK)
         if (t[j] & 0x40) t[j] = (int8_t)(t[j] & 0x3f);
+    }
+  }
+}
+
+// Long rows (round 3): the sets only ask on which side of two thresholds a rating's (key, j) lies -- the pairs of the free
+// ratings of rank nw[0] and nw[0] + nw[1] -- so the ranks themselves are never formed: each threshold is found by bisection
+// over the 64-bit pair, one count of "free and below" per step with the keys (and free flags) of the row in LDS.
+// O(n / BLOCK) per thread and step, 2 x ~47 steps per row, instead of O(n^2 / BLOCK) compares: the longest MAL-scale user
+// (13 K ratings) used to take 2 ms of one CU.  Same sets bit for bit as split_to_sets_kernel and the oracle (the order is
+// total: (key, j) pairs are unique).  Rows longer than CAP recompute keys and re-read flags in every step.
+template <int CAP, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void split_to_sets_select_kernel(const int64_t *rowPtr, const int32_t *rowList, int64_t nList,
+                                                                    int8_t *types, int p0, int p1, uint32_t seed) {
+  __shared__ uint32_t keys[CAP];
+  __shared__ uint8_t isFree[CAP];
+  __shared__ int cshared[4];
+  __shared__ unsigned cnt[2];
+  const int tid = threadIdx.x;
+  for (int64_t li = blockIdx.x; li < nList; li += gridDim.x) {
+    const int64_t r = rowList[li];
+    const int64_t b = rowPtr[r], n = rowPtr[r + 1] - b;
+    if (n <= 0) continue;
+    int8_t *t = types + b;
+    __syncthreads();  // the previous row's LDS contents are dead
+    if (tid < 4) cshared[tid] = 0;
+    __syncthreads();
+    int c[4] = {0, 0, 0, 0};
+    for (int64_t j = tid; j < n; j += BLOCK) {
+      const int v = t[j];
+      if (v >= 0 && v <= 3) ++c[v];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      for (int m = 32; m >= 1; m >>= 1) c[q] += __shfl_xor(c[q], m, 64);
+      if ((tid & 63) == 0 && c[q]) atomicAdd(&cshared[q], c[q]);
+    }
+    __syncthreads();
+    const int64_t c0 = cshared[0], c1 = cshared[1], c2 = cshared[2], c3 = cshared[3];
+    if (c0 == 0) continue;
+    int64_t nw[3];
+    split_counts(c0, c1, c2, c3, p0, p1, nw);
+    const bool cached = n <= CAP;
+    if (cached) {
+      for (int64_t j = tid; j < n; j += BLOCK) {
+        keys[j] = split_key(seed, (uint32_t)r, (uint32_t)j);
+        isFree[j] = t[j] == 0;
+      }
+    }
+    __syncthreads();
+    // Pair (key << 32 | j) of the free rating of rank R -- pairs below it number exactly R, and it is the largest value of which
+    // that holds -- for R = nw[0] and nw[0] + nw[1] at once: bisection with the invariant below(lo) <= R < below(hi), where
+    // below(v) = the number of free ratings whose pair is < v (below(0) = 0; below(2^64 - 1) = c0: j < n keeps pairs under it).
+    // R >= c0: every free rating lies below the threshold.  64 steps, one pass over the row and two barriers per step.
+    const int64_t R[2] = {nw[0], nw[0] + nw[1]};
+    unsigned long long lo[2] = {0ull, 0ull}, hi[2] = {~0ull, ~0ull};
+    for (int step = 0; step < 64; ++step) {
+      unsigned long long mid[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) mid[q] = lo[q] + ((hi[q] - lo[q]) >> 1);
+      if (tid < 2) cnt[tid] = 0;
+      __syncthreads();
+      unsigned mine[2] = {0u, 0u};
+      for (int64_t j = tid; j < n; j += BLOCK) {
+        const bool fr = cached ? isFree[j] != 0 : t[j] == 0;
+        const uint32_t k = cached ? keys[j] : split_key(seed, (uint32_t)r, (uint32_t)j);
+        const unsigned long long pj = ((unsigned long long)k << 32) | (unsigned long long)j;
+        mine[0] += (fr && pj < mid[0]) ? 1u : 0u;
+        mine[1] += (fr && pj < mid[1]) ? 1u : 0u;
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        for (int m = 32; m >= 1; m >>= 1) mine[q] += __shfl_xor(mine[q], m, 64);
+        if ((tid & 63) == 0 && mine[q]) atomicAdd(&cnt[q], mine[q]);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        if (hi[q] - lo[q] <= 1) continue;
+        if ((int64_t)cnt[q] > R[q]) hi[q] = mid[q]; else lo[q] = mid[q];
+      }
+      __syncthreads();  // cnt[] is reset at the top of the next step
+    }
+    unsigned long long theta[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) theta[q] = R[q] >= c0 ? ~0ull : lo[q];
+    // the rating whose pair equals theta[q] has rank R[q] itself: it belongs to the NEXT set (rank < R fails)
+    for (int64_t j = tid; j < n; j += BLOCK) {
+      if (t[j] != 0) continue;
+      const uint32_t k = cached ? keys[j] : split_key(seed, (uint32_t)r, (uint32_t)j);
+      const unsigned long long pj = ((unsigned long long)k << 32) | (unsigned long long)j;
+      t[j] = pj < theta[0] ? 1 : pj < theta[1] ? 2 : 3;
     }
   }
 }

@@ -906,27 +906,34 @@ int ycnr_split_to_sets(int64_t rows, const int64_t *rowPtr, int8_t *types, const
   HIP_TRY(evp.create());
   const hipEvent_t e0 = evp.a, e1 = evp.b;
   HIP_TRY(hipEventRecord(e0, nullptr));
-  // short rows and long rows apart: the long rows' 60 KB of LDS would leave two waves per CU for everybody
-  std::vector<int32_t> lists[2];
+  // three classes of rows: up to kSplitRankRow ratings one wave ranks every rating (O(n^2 / 64), cheapest for short rows);
+  // longer ones find the two thresholds by bisection instead -- one wave up to kSplitShortRow ratings, a 1024-thread
+  // workgroup beyond (whose 60 KB of LDS would leave two waves per CU for everybody, hence the separate launch)
+  std::vector<int32_t> lists[3];
   for (int64_t r = 0; r < rows; ++r) {
     const int64_t n = rowPtr[r + 1] - rowPtr[r];
-    if (n > 0) lists[n > kSplitShortRow ? 1 : 0].push_back((int32_t)r);
+    if (n > 0) lists[n > kSplitShortRow ? 1 : n > kSplitRankRow ? 2 : 0].push_back((int32_t)r);
   }
-  // longest first within the long class (they set the tail)
-  std::stable_sort(lists[1].begin(), lists[1].end(),
-                   [&](int32_t x, int32_t y) { return rowPtr[x + 1] - rowPtr[x] > rowPtr[y + 1] - rowPtr[y]; });
-  DevBuf dList[2];
-  for (int q = 0; q < 2; ++q) {
+  // longest first within the long classes (they set the tail)
+  for (int q = 1; q < 3; ++q)
+    std::stable_sort(lists[q].begin(), lists[q].end(),
+                     [&](int32_t x, int32_t y) { return rowPtr[x + 1] - rowPtr[x] > rowPtr[y + 1] - rowPtr[y]; });
+  DevBuf dList[3];
+  for (int q = 0; q < 3; ++q) {
     if (lists[q].empty()) continue;
     HIP_TRY(hipMalloc(&dList[q].p, lists[q].size() * 4));
     HIP_TRY(hipMemcpy(dList[q].p, lists[q].data(), lists[q].size() * 4, hipMemcpyHostToDevice));
   }
   HIP_TRY(hipEventRecord(e0, nullptr));  // the kernels only (lists are part of the upload)
   if (!lists[1].empty())
-    hipLaunchKernelGGL((split_to_sets_kernel<kSplitLdsKeys, 1024>), dim3((unsigned)lists[1].size()), dim3(1024), 0, nullptr, (const int64_t *)dPtr.p,
+    hipLaunchKernelGGL((split_to_sets_select_kernel<kSplitLdsKeys, 1024>), dim3((unsigned)lists[1].size()), dim3(1024), 0, nullptr, (const int64_t *)dPtr.p,
                        (const int32_t *)dList[1].p, (int64_t)lists[1].size(), (int8_t *)dTypes.p, (int)pcts[0], (int)pcts[1], seed);
+  if (!lists[2].empty())
+    hipLaunchKernelGGL((split_to_sets_select_kernel<kSplitShortRow, 64>), dim3((unsigned)std::min<size_t>(lists[2].size(), (size_t)1 << 20)), dim3(64), 0,
+                       nullptr, (const int64_t *)dPtr.p, (const int32_t *)dList[2].p, (int64_t)lists[2].size(), (int8_t *)dTypes.p,
+                       (int)pcts[0], (int)pcts[1], seed);
   if (!lists[0].empty())
-    hipLaunchKernelGGL((split_to_sets_kernel<kSplitShortRow, 64>), dim3((unsigned)std::min<size_t>(lists[0].size(), (size_t)1 << 20)), dim3(64), 0,
+    hipLaunchKernelGGL((split_to_sets_kernel<kSplitRankRow, 64>), dim3((unsigned)std::min<size_t>(lists[0].size(), (size_t)1 << 20)), dim3(64), 0,
                        nullptr, (const int64_t *)dPtr.p, (const int32_t *)dList[0].p, (int64_t)lists[0].size(), (int8_t *)dTypes.p,
                        (int)pcts[0], (int)pcts[1], seed);
   hipError_t le = hipGetLastError();
