@@ -121,7 +121,7 @@ def main():
         "roofline": {"bound": "hbm", "unit": "GB/s", "peak": 8000.0,
                      "split_to_sets": round(b_split / (ms_split * 1e-3) / 1e9, 1),
                      "rating_stats": round(b_stats / ((ms_su + ms_si) * 1e-3) / 1e9, 1),
-                     "note": "the split never reads the ratings: short rows rank every position by a keyed order (O(n^2/64) per row), rows beyond 192 "
+                     "note": "the split never reads the ratings: short rows rank every position by a keyed order (O(n^2/64) per row), rows beyond 40 "
                              "find the two set thresholds by bisection (O(n) per step); it is bound by the latency of its 1.7 M one-wave rows; "
                              "the statistics stream the ratings once"},
         "ingest": {"csr_from_triplets_ms": round(ms_build, 3), "csr_transpose_ms": round(ms_tr, 3),

@@ -42,8 +42,8 @@ __host__ __device__ inline void split_counts(int64_t freeCnt, int64_t c1, int64_
   if (nw[0] + nw[1] + nw[2] < freeCnt) nw[0] += freeCnt - (nw[0] + nw[1] + nw[2]);
 }
 
-constexpr int kSplitRankRow = 192;     // rows up to this length: every rating ranked by one wave (8 n + 2560 instructions of bisection
-                                       // against 6 n^2 / 64 of ranking cross near 190 ratings)
+constexpr int kSplitRankRow = 40;      // rows up to this length: every rating ranked by one wave; longer ones find the two thresholds by bisection
+                                       // (MAL scale, ms for 16 / 40 / 80 / 192 ratings: 3.04 / 2.80 / 3.10 / 3.95)
 constexpr int kSplitShortRow = 1024;   // rows up to this length: one wave, 5 KB of LDS, many waves per CU
 constexpr int kSplitLdsKeys = 12288;   // longer rows: 60 KB per wave; beyond this keys are recomputed in the inner loop
 
@@ -126,9 +126,9 @@ __global__ __launch_bounds__(BLOCK) void split_to_sets_kernel(const int64_t *row
 }
 
 // Long rows (round 3): the sets only ask on which side of two thresholds a rating's (key, j) lies -- the pairs of the free
-// ratings of rank nw[0] and nw[0] + nw[1] -- so the ranks themselves are never formed: each threshold is found by bisection
+// ratings of rank nw[0] and nw[0] + nw[1] -- so the ranks themselves are never formed: both thresholds are found by bisection
 // over the 64-bit pair, one count of "free and below" per step with the keys (and free flags) of the row in LDS.
-// O(n / BLOCK) per thread and step, 2 x ~47 steps per row, instead of O(n^2 / BLOCK) compares: the longest MAL-scale user
+// O(n / BLOCK) per thread and step, about log2(n) + 2 steps per row, instead of O(n^2 / BLOCK) compares: the longest MAL-scale user
 // (13 K ratings) used to take 2 ms of one CU.  Same sets bit for bit as split_to_sets_kernel and the oracle (the order is
 // total: (key, j) pairs are unique).  Rows longer than CAP recompute keys and re-read flags in every step.
 template <int CAP, int BLOCK>
@@ -170,18 +170,25 @@ __global__ __launch_bounds__(BLOCK) void split_to_sets_select_kernel(const int64
       }
     }
     __syncthreads();
-    // Pair (key << 32 | j) of the free rating of rank R -- pairs below it number exactly R, and it is the largest value of which
-    // that holds -- for R = nw[0] and nw[0] + nw[1] at once: bisection with the invariant below(lo) <= R < below(hi), where
-    // below(v) = the number of free ratings whose pair is < v (below(0) = 0; below(2^64 - 1) = c0: j < n keeps pairs under it).
-    // R >= c0: every free rating lies below the threshold.  64 steps, one pass over the row and two barriers per step.
+    // A threshold theta with below(theta) == R, where below(v) = the number of free ratings whose pair (key << 32 | j) is < v:
+    // then exactly the R first free ratings of the keyed order lie below it.  For R = nw[0] and nw[0] + nw[1] at once, by
+    // bisection with the invariant below(lo) <= R < below(hi) (below(0) = 0; below(2^64 - 1) = c0: j < n keeps every pair
+    // under it), stopping at the first midpoint whose count IS R -- about log2(n) + 2 steps, since the keys are hashes --
+    // and at lo when the interval has closed (then below(lo) == R).  R >= c0: every free rating lies below the threshold.
+    // One pass over the row per step; a one-wave block needs neither LDS nor barriers for the counts.
     const int64_t R[2] = {nw[0], nw[0] + nw[1]};
-    unsigned long long lo[2] = {0ull, 0ull}, hi[2] = {~0ull, ~0ull};
-    for (int step = 0; step < 64; ++step) {
+    unsigned long long lo[2] = {0ull, 0ull}, hi[2] = {~0ull, ~0ull}, theta[2] = {0ull, 0ull};
+    bool found[2] = {R[0] >= c0 || R[0] == 0, R[1] >= c0 || R[1] == 0};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) theta[q] = R[q] >= c0 ? ~0ull : 0ull;
+    for (int step = 0; step < 64 && !(found[0] && found[1]); ++step) {
       unsigned long long mid[2];
 #pragma unroll
       for (int q = 0; q < 2; ++q) mid[q] = lo[q] + ((hi[q] - lo[q]) >> 1);
-      if (tid < 2) cnt[tid] = 0;
-      __syncthreads();
+      if constexpr (BLOCK > 64) {
+        if (tid < 2) cnt[tid] = 0;
+        __syncthreads();
+      }
       unsigned mine[2] = {0u, 0u};
       for (int64_t j = tid; j < n; j += BLOCK) {
         const bool fr = cached ? isFree[j] != 0 : t[j] == 0;
@@ -190,23 +197,40 @@ __global__ __launch_bounds__(BLOCK) void split_to_sets_select_kernel(const int64
         mine[0] += (fr && pj < mid[0]) ? 1u : 0u;
         mine[1] += (fr && pj < mid[1]) ? 1u : 0u;
       }
+      int64_t total[2];
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         for (int m = 32; m >= 1; m >>= 1) mine[q] += __shfl_xor(mine[q], m, 64);
-        if ((tid & 63) == 0 && mine[q]) atomicAdd(&cnt[q], mine[q]);
+        if constexpr (BLOCK > 64) {
+          if ((tid & 63) == 0 && mine[q]) atomicAdd(&cnt[q], mine[q]);
+        } else {
+          total[q] = mine[q];
+        }
       }
-      __syncthreads();
+      if constexpr (BLOCK > 64) {
+        __syncthreads();
+        total[0] = cnt[0];
+        total[1] = cnt[1];
+        __syncthreads();  // cnt[] is reset at the top of the next step
+      }
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        if (hi[q] - lo[q] <= 1) continue;
-        if ((int64_t)cnt[q] > R[q]) hi[q] = mid[q]; else lo[q] = mid[q];
+        if (found[q]) continue;
+        if (total[q] == R[q]) {
+          theta[q] = mid[q];
+          found[q] = true;
+        } else if (total[q] > R[q]) {
+          hi[q] = mid[q];
+        } else {
+          lo[q] = mid[q];
+        }
+        if (!found[q] && hi[q] - lo[q] <= 1) {  // closed: below(lo) <= R < below(lo + 1) <= below(lo) + 1
+          theta[q] = lo[q];
+          found[q] = true;
+        }
       }
-      __syncthreads();  // cnt[] is reset at the top of the next step
     }
-    unsigned long long theta[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) theta[q] = R[q] >= c0 ? ~0ull : lo[q];
-    // the rating whose pair equals theta[q] has rank R[q] itself: it belongs to the NEXT set (rank < R fails)
+    // (pairs below theta[q] are exactly the ratings of rank < R[q])
     for (int64_t j = tid; j < n; j += BLOCK) {
       if (t[j] != 0) continue;
       const uint32_t k = cached ? keys[j] : split_key(seed, (uint32_t)r, (uint32_t)j);
