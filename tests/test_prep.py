@@ -127,6 +127,29 @@ def test_gpu_split_bit_exact(als, pre):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("pcts", [(85, 10, 5), (100, 0, 0), (0, 0, 100), (0, 100, 0), (1, 1, 98), (50, 50, 0), (33, 33, 34)])
+def test_gpu_split_class_boundaries_and_degenerate_percentages(als, pcts):
+    """Rows on both sides of every kernel class boundary (ranking up to 40 ratings, one-wave bisection up to 1024, a
+    1024-thread workgroup beyond, keys recomputed past 12 288), fresh and with some ratings already assigned (types 1..3,
+    and 4 = excluded), with percentages that put a threshold at rank 0 or past the last free rating: bit-exact against
+    the oracle."""
+    lens = [0, 1, 2, 3, 16, 39, 40, 41, 42, 63, 64, 65, 100, 191, 192, 193, 500, 1023, 1024, 1025, 1026, 2000, 4097, 12288, 12289, 13001]
+    rng = np.random.default_rng(sum(pcts) * 7 + pcts[0])
+    rowPtr = np.zeros(len(lens) + 1, np.int64)
+    rowPtr[1:] = np.cumsum(lens)
+    for pre in (False, True):
+        types = np.zeros(rowPtr[-1], np.int8)
+        if pre:
+            types[:] = rng.choice(np.array([0, 0, 0, 1, 2, 3, 4], np.int8), rowPtr[-1])
+            types[rowPtr[5]:rowPtr[6]] = 1      # a row with nothing left to assign
+            types[rowPtr[12]:rowPtr[13]] = 4    # a row of excluded ratings only
+        for seed in (1, 0xFFFFFFFF):
+            got, _ = als.split_to_sets(rowPtr, types, pcts, seed)
+            want = orc.split_to_sets(rowPtr, types, pcts, seed)
+            assert np.array_equal(got, want), (pcts, pre, seed, int(np.flatnonzero(got != want)[0]))
+
+
+@pytest.mark.gpu
 def test_gpu_split_edge_cases(als):
     empty = np.zeros(0, np.int8)
     got, _ = als.split_to_sets(np.zeros(5, np.int64), empty)          # rows without ratings
