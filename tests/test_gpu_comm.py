@@ -36,9 +36,15 @@ def free_port():
         return s.getsockname()[1]
 
 
-def problem(k=36, users=900, items=400, seed=3):
-    bu, bi, U, V = make_problem(users, items, k, density=0.08, seed=seed, empty_rows=(5, 17))
+def problem(k=36, users=900, items=400, seed=3, density=0.08):
+    bu, bi, U, V = make_problem(users, items, k, density=density, seed=seed, empty_rows=(5, 17))
     return k, users, items, bu, bi, U, V
+
+
+# (k, users, items, seed, density): the default small problem; k = 100 (bf16x6 row kernel, packed last block, dual classes);
+# k = 256 with rows of ~190 ratings either side of the primal / dual crossover (Gramian -> slab -> four-wave solve in
+# batches, dual classes on the side streams) and items of ~330 ratings
+SHAPES = {"k36": (36, 900, 400, 3, 0.08), "k100": (100, 1200, 500, 4, 0.15), "k256": (256, 700, 400, 5, 0.47)}
 
 
 def reference_iteration(als, k, users, items, bu, bi, U, V):
@@ -123,9 +129,9 @@ def test_train_under_the_nccl_backend(als):
     assert q.get(timeout=5) is True
 
 
-def _rank_main(rank, world, uid, pieces, out, transport="shm", device=0):
+def _rank_main(rank, world, uid, pieces, out, transport="shm", device=0, shape="k36"):
     import ycnr_als as als
-    k, users, items, bu, bi, U, V = problem()
+    k, users, items, bu, bi, U, V = problem(*SHAPES[shape])
     dev = als.AlsDevice(k, users, items, device=device)
     dev.comm_init(uid, rank, world, transport)
     if transport != "ipc":
@@ -148,18 +154,19 @@ def _rank_main(rank, world, uid, pieces, out, transport="shm", device=0):
     out.put((rank, got, s.tolist(), int(iu.parts), int(iu.exchangeBytes), int(ii.exchangeBytes)))
 
 
-@pytest.mark.parametrize("transport,world,pieces", [("shm", 2, 1), ("shm", 3, 4), ("ipc", 2, 1), ("ipc", 3, 4)])
-def test_ranks_of_one_node_on_one_gpu(als, transport, world, pieces):
+@pytest.mark.parametrize("transport,world,pieces,shape", [("shm", 2, 1, "k36"), ("shm", 3, 4, "k36"), ("ipc", 2, 1, "k36"), ("ipc", 3, 4, "k36"),
+                                                          ("ipc", 2, 3, "k100"), ("ipc", 2, 3, "k256"), ("shm", 3, 2, "k256")])
+def test_ranks_of_one_node_on_one_gpu(als, transport, world, pieces, shape):
     """Several ranks sharing cuda:0: 'shm' stages rows through the host, 'ipc' is the device-to-device path -- every
     rank maps its peers' replicas (hipIpcOpenMemHandle) and pushes its solved rows into them piece by piece on
     the communicator's stream, behind the kernels that produced them.  Exchange, join-time broadcast and
     all-reduce between real processes, against the single-process result bit for bit."""
-    k, users, items, bu, bi, U, V = problem()
+    k, users, items, bu, bi, U, V = problem(*SHAPES[shape])
     U1, V1 = reference_iteration(als, k, users, items, bu, bi, U, V)
     uid = als.AlsDevice.comm_unique_id(transport)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_rank_main, args=(r, world, uid, pieces, q, transport)) for r in range(world)]
+    procs = [ctx.Process(target=_rank_main, args=(r, world, uid, pieces, q, transport, 0, shape)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in procs]
