@@ -269,15 +269,19 @@ __global__ __launch_bounds__(256) void rating_stats_kernel(const int64_t *rowPtr
   }
 }
 
-// The same for long rows (item rows of a popular title have 10^5 ratings): one 256-thread
-// workgroup per listed row, strided partial sums, fixed tree.
+// The same for long rows (item rows of a popular title have 10^5 ratings), cut into segments of kStatsSegment ratings
+// (round 3: one workgroup per ROW left the longest row's 2400 dependent iterations as the tail of the launch): one
+// 256-thread workgroup per segment, strided partial sums, fixed tree -> a partial per segment; rating_stats_combine_kernel
+// adds a row's partials in segment order.  The summation tree depends on the row's length only.
+constexpr int64_t kStatsSegment = 8192;
 template <typename T>
-__global__ __launch_bounds__(256) void rating_stats_long_kernel(const int64_t *rowPtr, const int32_t *rowList, const T *vals,
-                                                               const int8_t *types, int32_t *cnt, double *sum) {
+__global__ __launch_bounds__(256) void rating_stats_long_kernel(const int64_t *rowPtr, const int32_t *segRow, const int64_t *segBeg, const T *vals,
+                                                               const int8_t *types, int32_t *partCnt, double *partSum) {
   __shared__ double ss[256];
   __shared__ int32_t sc[256];
-  const int64_t r = rowList[blockIdx.x];
-  const int64_t b = rowPtr[r], e = rowPtr[r + 1];
+  const int64_t r = segRow[blockIdx.x];
+  const int64_t b = segBeg[blockIdx.x], rowEnd = rowPtr[r + 1];
+  const int64_t e = b + kStatsSegment < rowEnd ? b + kStatsSegment : rowEnd;
   double s = 0.0;
   int32_t c = 0;
   for (int64_t q = b + threadIdx.x; q < e; q += 256) {
@@ -298,9 +302,23 @@ __global__ __launch_bounds__(256) void rating_stats_long_kernel(const int64_t *r
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    cnt[r] = sc[0];
-    sum[r] = ss[0];
+    partCnt[blockIdx.x] = sc[0];
+    partSum[blockIdx.x] = ss[0];
   }
+}
+// long row i of the list: its segments' partials [first[i], first[i + 1]) in order
+__global__ void rating_stats_combine_kernel(const int32_t *rowList, const int64_t *first, int64_t nLong, const int32_t *partCnt,
+                                            const double *partSum, int32_t *cnt, double *sum) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nLong) return;
+  double s = 0.0;
+  int32_t c = 0;
+  for (int64_t u = first[i]; u < first[i + 1]; ++u) {
+    s += partSum[u];
+    c += partCnt[u];
+  }
+  cnt[rowList[i]] = c;
+  sum[rowList[i]] = s;
 }
 
 // ---- N2: CSR construction (sort by a 64-bit (row, col) key with rocPRIM's radix sort; these

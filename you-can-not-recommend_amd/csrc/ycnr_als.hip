@@ -967,30 +967,52 @@ int ycnr_rating_stats(int dtype, int64_t rows, const int64_t *rowPtr, const void
   HIP_TRY(evp.create());
   const hipEvent_t e0 = evp.a, e1 = evp.b;
   HIP_TRY(hipEventRecord(e0, nullptr));
-  constexpr int64_t kLongRow = 2048;  // longer rows get a workgroup each
-  std::vector<int32_t> longRows;
-  for (int64_t r = 0; r < rows; ++r)
-    if (rowPtr[r + 1] - rowPtr[r] > kLongRow) longRows.push_back((int32_t)r);
-  DevBuf dLong;
+  constexpr int64_t kLongRow = 2048;  // longer rows: a workgroup per segment of kStatsSegment ratings, then the segments in order
+  std::vector<int32_t> longRows, segRow;
+  std::vector<int64_t> segBeg, firstSeg;
+  for (int64_t r = 0; r < rows; ++r) {
+    const int64_t n = rowPtr[r + 1] - rowPtr[r];
+    if (n <= kLongRow) continue;
+    longRows.push_back((int32_t)r);
+    firstSeg.push_back((int64_t)segRow.size());
+    for (int64_t b = rowPtr[r]; b < rowPtr[r + 1]; b += kStatsSegment) {
+      segRow.push_back((int32_t)r);
+      segBeg.push_back(b);
+    }
+  }
+  firstSeg.push_back((int64_t)segRow.size());
+  DevBuf dLong, dSegRow, dSegBeg, dFirst, dPartCnt, dPartSum;
   if (!longRows.empty()) {
     HIP_TRY(hipMalloc(&dLong.p, longRows.size() * 4));
+    HIP_TRY(hipMalloc(&dSegRow.p, segRow.size() * 4));
+    HIP_TRY(hipMalloc(&dSegBeg.p, segBeg.size() * 8));
+    HIP_TRY(hipMalloc(&dFirst.p, firstSeg.size() * 8));
+    HIP_TRY(hipMalloc(&dPartCnt.p, segRow.size() * 4));
+    HIP_TRY(hipMalloc(&dPartSum.p, segRow.size() * 8));
     HIP_TRY(hipMemcpy(dLong.p, longRows.data(), longRows.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dSegRow.p, segRow.data(), segRow.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dSegBeg.p, segBeg.data(), segBeg.size() * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dFirst.p, firstSeg.data(), firstSeg.size() * 8, hipMemcpyHostToDevice));
   }
   HIP_TRY(hipEventRecord(e0, nullptr));
   const unsigned blocks = (unsigned)((rows * 16 + 255) / 256);
+  const unsigned nSeg = (unsigned)segRow.size(), nLong = (unsigned)longRows.size();
   if (dtype == YCNR_F32) {
+    if (nLong)  // (first: its workgroups are the long ones)
+      hipLaunchKernelGGL(rating_stats_long_kernel<float>, dim3(nSeg), dim3(256), 0, nullptr, (const int64_t *)dPtr.p, (const int32_t *)dSegRow.p,
+                         (const int64_t *)dSegBeg.p, (const float *)dVals.p, (const int8_t *)dTypes.p, (int32_t *)dPartCnt.p, (double *)dPartSum.p);
     hipLaunchKernelGGL(rating_stats_kernel<float>, dim3(blocks), dim3(256), 0, nullptr, (const int64_t *)dPtr.p, rows,
                        (const float *)dVals.p, (const int8_t *)dTypes.p, (int32_t *)dCnt.p, (double *)dSum.p, kLongRow);
-    if (!longRows.empty())
-      hipLaunchKernelGGL(rating_stats_long_kernel<float>, dim3((unsigned)longRows.size()), dim3(256), 0, nullptr, (const int64_t *)dPtr.p,
-                         (const int32_t *)dLong.p, (const float *)dVals.p, (const int8_t *)dTypes.p, (int32_t *)dCnt.p, (double *)dSum.p);
   } else {
+    if (nLong)
+      hipLaunchKernelGGL(rating_stats_long_kernel<double>, dim3(nSeg), dim3(256), 0, nullptr, (const int64_t *)dPtr.p, (const int32_t *)dSegRow.p,
+                         (const int64_t *)dSegBeg.p, (const double *)dVals.p, (const int8_t *)dTypes.p, (int32_t *)dPartCnt.p, (double *)dPartSum.p);
     hipLaunchKernelGGL(rating_stats_kernel<double>, dim3(blocks), dim3(256), 0, nullptr, (const int64_t *)dPtr.p, rows,
                        (const double *)dVals.p, (const int8_t *)dTypes.p, (int32_t *)dCnt.p, (double *)dSum.p, kLongRow);
-    if (!longRows.empty())
-      hipLaunchKernelGGL(rating_stats_long_kernel<double>, dim3((unsigned)longRows.size()), dim3(256), 0, nullptr, (const int64_t *)dPtr.p,
-                         (const int32_t *)dLong.p, (const double *)dVals.p, (const int8_t *)dTypes.p, (int32_t *)dCnt.p, (double *)dSum.p);
   }
+  if (nLong)
+    hipLaunchKernelGGL(rating_stats_combine_kernel, dim3((nLong + 255) / 256), dim3(256), 0, nullptr, (const int32_t *)dLong.p, (const int64_t *)dFirst.p,
+                       (int64_t)nLong, (const int32_t *)dPartCnt.p, (const double *)dPartSum.p, (int32_t *)dCnt.p, (double *)dSum.p);
   hipError_t le = hipGetLastError();
   int rc = le == hipSuccess ? timed(e0, e1, deviceMs) : fail(YCNR_ERR_HIP, "rating_stats launch: %s", hipGetErrorString(le));
   if (rc) return rc;
