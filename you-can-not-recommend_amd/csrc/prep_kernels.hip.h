@@ -367,40 +367,56 @@ __global__ void row_ptr_kernel(const uint64_t *keys, int64_t n, int64_t rows, in
 // predict = u . I[item] + globalAvgShift for every item that is not in the user's skip list;
 // items below minRecommendRating score -inf.  One 256-thread workgroup per user, a 16-lane group
 // per item row (float4 / double2 loads, fixed summation tree), 16 items per pass.
-template <typename T>
-__global__ __launch_bounds__(256) void recommend_scores_kernel(const T *userRows, const T *items, int64_t totalItems, int k,
-                                                              const int64_t *skipPtr, const int32_t *skipIds, double shift,
-                                                              double minRating, double *scores) {
+template <typename T, int UB>
+__global__ __launch_bounds__(256) void recommend_scores_kernel(const T *userRows, int64_t nUsers, const T *items, int64_t totalItems, int k,
+                                                              double shift, double minRating, double *scores) {
+  // UB users per workgroup (round 3: one user per workgroup re-read the item matrix from L2 once per user): an item row is
+  // loaded once and multiplied into UB accumulators; every (user, item) sum keeps its order, so the scores do not change.
   extern __shared__ __attribute__((aligned(16))) unsigned char smemRec[];
-  T *u = reinterpret_cast<T *>(smemRec);
-  const int64_t user = blockIdx.x;
-  for (int f = threadIdx.x; f < k; f += 256) u[f] = userRows[user * k + f];
+  T *u = reinterpret_cast<T *>(smemRec);  // [UB][k]
+  const int64_t user0 = (int64_t)blockIdx.x * UB;
+  const int nu = (int)(nUsers - user0 < UB ? nUsers - user0 : UB);
+  for (int f = threadIdx.x; f < UB * k; f += 256) u[f] = f / k < nu ? userRows[user0 * k + f] : T(0);
   __syncthreads();
   const int sub = threadIdx.x & 15, slot = threadIdx.x >> 4;
-  const int32_t *skip = skipIds + skipPtr[user];
-  const int64_t nSkip = skipPtr[user + 1] - skipPtr[user];
-  double *out = scores + user * totalItems;
   for (int64_t it0 = 0; it0 < totalItems; it0 += 16) {
     const int64_t it = it0 + slot;
-    double s = 0.0;
+    double s[UB];
+#pragma unroll
+    for (int q = 0; q < UB; ++q) s[q] = 0.0;
     if (it < totalItems) {
       const T *row = items + it * k;
-      T acc = T(0);
-      for (int f = sub; f < k; f += 16) acc = fma(u[f], row[f], acc);  // uF.dot(iF) in the factors' precision
-      s = (double)acc;
-    }
-    for (int m = 8; m >= 1; m >>= 1) s += __shfl_xor(s, m, 16);
-    if (it < totalItems && sub == 0) {
-      int64_t lo = 0, hi = nSkip;  // is `it` in the ascending skip list?
-      while (lo < hi) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (skip[mid] < it) lo = mid + 1;
-        else hi = mid;
+      T acc[UB];
+#pragma unroll
+      for (int q = 0; q < UB; ++q) acc[q] = T(0);
+      for (int f = sub; f < k; f += 16) {
+        const T rv = row[f];
+#pragma unroll
+        for (int q = 0; q < UB; ++q) acc[q] = fma(u[q * k + f], rv, acc[q]);  // uF.dot(iF) in the factors' precision
       }
-      const bool skipped = lo < nSkip && skip[lo] == it;
-      const double predict = s + shift;
-      out[it] = (!skipped && predict >= minRating) ? predict : -INFINITY;
+#pragma unroll
+      for (int q = 0; q < UB; ++q) s[q] = (double)acc[q];
     }
+#pragma unroll
+    for (int q = 0; q < UB; ++q)
+      for (int m = 8; m >= 1; m >>= 1) s[q] += __shfl_xor(s[q], m, 16);
+    // lane q of the group finishes user q (the skip lists are applied by recommend_skip_kernel afterwards: a binary search
+    // per (user, item) here was six dependent global loads per item pass -- most of this kernel's time)
+    if (it < totalItems && sub < nu) {
+      double mine = s[0];
+#pragma unroll
+      for (int q = 1; q < UB; ++q) mine = sub == q ? s[q] : mine;
+      const double predict = mine + shift;
+      scores[(user0 + sub) * totalItems + it] = predict >= minRating ? predict : -INFINITY;
+    }
+  }
+}
+// the items a user must not be offered (already rated): -inf into their scores; one workgroup per user
+__global__ __launch_bounds__(256) void recommend_skip_kernel(const int64_t *skipPtr, const int32_t *skipIds, int64_t totalItems, double *scores) {
+  const int64_t user = blockIdx.x;
+  for (int64_t q = skipPtr[user] + threadIdx.x; q < skipPtr[user + 1]; q += 256) {
+    const int64_t id = skipIds[q];
+    if (id >= 0 && id < totalItems) scores[user * totalItems + id] = -INFINITY;  // (ids outside the catalogue match nothing, as before)
   }
 }
 

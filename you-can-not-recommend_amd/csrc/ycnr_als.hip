@@ -1184,14 +1184,17 @@ int ycnr_recommend_items(int dtype, int32_t k, int64_t nUsers, const void *userR
     HIP_TRY(hipMemcpy(dUsers.p, (const char *)userRows + (size_t)u0 * k * ts, (size_t)nb * k * ts, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dSkipPtr.p, localPtr.data(), (size_t)(nb + 1) * 8, hipMemcpyHostToDevice));
     HIP_TRY(hipEventRecord(e0, nullptr));
+    constexpr int kRecUsers = 4;  // users per workgroup of the scoring kernel
+    const unsigned nblk = (unsigned)((nb + kRecUsers - 1) / kRecUsers);
     if (dtype == YCNR_F32)
-      hipLaunchKernelGGL(recommend_scores_kernel<float>, dim3((unsigned)nb), dim3(256), (size_t)k * ts, nullptr, (const float *)dUsers.p,
-                         (const float *)dItems.p, totalItems, (int)k, (const int64_t *)dSkipPtr.p, (const int32_t *)dSkip.p, globalAvgShift,
-                         minRecommendRating, (double *)dScores.p);
+      hipLaunchKernelGGL((recommend_scores_kernel<float, kRecUsers>), dim3(nblk), dim3(256), (size_t)kRecUsers * k * ts, nullptr, (const float *)dUsers.p, nb,
+                         (const float *)dItems.p, totalItems, (int)k, globalAvgShift, minRecommendRating, (double *)dScores.p);
     else
-      hipLaunchKernelGGL(recommend_scores_kernel<double>, dim3((unsigned)nb), dim3(256), (size_t)k * ts, nullptr, (const double *)dUsers.p,
-                         (const double *)dItems.p, totalItems, (int)k, (const int64_t *)dSkipPtr.p, (const int32_t *)dSkip.p, globalAvgShift,
-                         minRecommendRating, (double *)dScores.p);
+      hipLaunchKernelGGL((recommend_scores_kernel<double, kRecUsers>), dim3(nblk), dim3(256), (size_t)kRecUsers * k * ts, nullptr, (const double *)dUsers.p, nb,
+                         (const double *)dItems.p, totalItems, (int)k, globalAvgShift, minRecommendRating, (double *)dScores.p);
+    if (nSkip)
+      hipLaunchKernelGGL(recommend_skip_kernel, dim3((unsigned)nb), dim3(256), 0, nullptr, (const int64_t *)dSkipPtr.p, (const int32_t *)dSkip.p, totalItems,
+                         (double *)dScores.p);
     hipLaunchKernelGGL(recommend_select_kernel, dim3((unsigned)nb), dim3(256), 0, nullptr, (double *)dScores.p, totalItems, take, (int)limit,
                        (int32_t *)dIds.p, (double *)dPred.p, (int32_t *)dCnt.p);
     hipError_t le = hipGetLastError();
