@@ -411,6 +411,56 @@ __global__ __launch_bounds__(256) void recommend_scores_kernel(const T *userRows
     }
   }
 }
+// The same scores on the matrix cores (round 3): predict = U V^T is a GEMM -- 16 users x 16 items per MFMA tile, the
+// users' factors of the workgroup in LDS (zero-padded to a multiple of 16), a wave per item tile; lane (g, j) feeds
+// V[item j][16 m + 4 g + t] (a 16-byte load) and U[user j][16 m + 4 g + t] to MFMA (m, t) -- operands of
+// v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64 carry contraction index g, so any assignment of factors to (MFMA, g) that
+// is the same on both sides is a dot product.  The dot stays in the factors' precision (float32 / float64 accumulators),
+// shift and threshold in double as before.  Needs als_kernels.hip.h's MfmaTraits in front of this header.
+template <typename T>
+__global__ __launch_bounds__(256) void recommend_scores_mfma_kernel(const T *userRows, int64_t nUsers, const T *items, int64_t totalItems, int k,
+                                                                   double shift, double minRating, double *scores) {
+  using Tr = MfmaTraits<T>;
+  using acc_t = typename Tr::acc_t;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smemRec[];
+  T *u = reinterpret_cast<T *>(smemRec);  // [16][kp]
+  const int kp = (k + 15) & ~15;
+  const int64_t user0 = (int64_t)blockIdx.x * 16;
+  const int nu = (int)(nUsers - user0 < 16 ? nUsers - user0 : 16);
+  for (int f = threadIdx.x; f < 16 * kp; f += 256) {
+    const int i = f / kp, c = f - i * kp;
+    u[f] = (i < nu && c < k) ? userRows[(user0 + i) * k + c] : T(0);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, j = lane & 15;
+  const int64_t ntiles = (totalItems + 15) >> 4;
+  const T *urow = u + j * kp + 4 * g;
+  for (int64_t tile = (int64_t)blockIdx.y * 4 + wave; tile < ntiles; tile += 4 * (int64_t)gridDim.y) {
+    const int64_t item = tile * 16 + j;
+    const bool valid = item < totalItems;
+    const T *row = items + (valid ? item : 0) * (int64_t)k + 4 * g;
+    acc_t acc = {T(0), T(0), T(0), T(0)};
+    for (int c0 = 0; c0 < kp; c0 += 16) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int c = c0 + 4 * g + t;
+        const T b = (valid && c < k) ? row[c0 + t] : T(0);
+        acc = Tr::mma(urow[c0 + t], b, acc);
+      }
+    }
+    if (valid) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int64_t user = user0 + Tr::cd_row(lane, t);
+        if (user < nUsers) {
+          const double predict = (double)acc[t] + shift;
+          scores[user * totalItems + item] = predict >= minRating ? predict : -INFINITY;
+        }
+      }
+    }
+  }
+}
+
 // the items a user must not be offered (already rated): -inf into their scores; one workgroup per user
 __global__ __launch_bounds__(256) void recommend_skip_kernel(const int64_t *skipPtr, const int32_t *skipIds, int64_t totalItems, double *scores) {
   const int64_t user = blockIdx.x;

@@ -1184,14 +1184,27 @@ int ycnr_recommend_items(int dtype, int32_t k, int64_t nUsers, const void *userR
     HIP_TRY(hipMemcpy(dUsers.p, (const char *)userRows + (size_t)u0 * k * ts, (size_t)nb * k * ts, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dSkipPtr.p, localPtr.data(), (size_t)(nb + 1) * 8, hipMemcpyHostToDevice));
     HIP_TRY(hipEventRecord(e0, nullptr));
-    constexpr int kRecUsers = 4;  // users per workgroup of the scoring kernel
-    const unsigned nblk = (unsigned)((nb + kRecUsers - 1) / kRecUsers);
-    if (dtype == YCNR_F32)
-      hipLaunchKernelGGL((recommend_scores_kernel<float, kRecUsers>), dim3(nblk), dim3(256), (size_t)kRecUsers * k * ts, nullptr, (const float *)dUsers.p, nb,
-                         (const float *)dItems.p, totalItems, (int)k, globalAvgShift, minRecommendRating, (double *)dScores.p);
-    else
-      hipLaunchKernelGGL((recommend_scores_kernel<double, kRecUsers>), dim3(nblk), dim3(256), (size_t)kRecUsers * k * ts, nullptr, (const double *)dUsers.p, nb,
-                         (const double *)dItems.p, totalItems, (int)k, globalAvgShift, minRecommendRating, (double *)dScores.p);
+    // scores on the matrix cores: 16 users per workgroup, the item tiles dealt over the waves of gridDim.y workgroups
+    // (YCNR_RECOMMEND_VALU=1: the 16-lane-group kernel, one user per workgroup, for A/B runs)
+    const size_t kp = (size_t)((k + 15) & ~15);
+    const unsigned ublk = (unsigned)((nb + 15) / 16);
+    const unsigned yblk = (unsigned)std::max<int64_t>(1, std::min<int64_t>((totalItems + 63) / 64, (8 * device_cus() + ublk - 1) / ublk));
+    const bool valu = getenv("YCNR_RECOMMEND_VALU") != nullptr || 16 * kp * ts > 48 * 1024;  // (16 users' factors must fit the default LDS limit)
+    if (dtype == YCNR_F32) {
+      if (valu)
+        hipLaunchKernelGGL((recommend_scores_kernel<float, 1>), dim3((unsigned)nb), dim3(256), (size_t)k * ts, nullptr, (const float *)dUsers.p, nb,
+                           (const float *)dItems.p, totalItems, (int)k, globalAvgShift, minRecommendRating, (double *)dScores.p);
+      else
+        hipLaunchKernelGGL(recommend_scores_mfma_kernel<float>, dim3(ublk, yblk), dim3(256), 16 * kp * ts, nullptr, (const float *)dUsers.p, nb,
+                           (const float *)dItems.p, totalItems, (int)k, globalAvgShift, minRecommendRating, (double *)dScores.p);
+    } else {
+      if (valu)
+        hipLaunchKernelGGL((recommend_scores_kernel<double, 1>), dim3((unsigned)nb), dim3(256), (size_t)k * ts, nullptr, (const double *)dUsers.p, nb,
+                           (const double *)dItems.p, totalItems, (int)k, globalAvgShift, minRecommendRating, (double *)dScores.p);
+      else
+        hipLaunchKernelGGL(recommend_scores_mfma_kernel<double>, dim3(ublk, yblk), dim3(256), 16 * kp * ts, nullptr, (const double *)dUsers.p, nb,
+                           (const double *)dItems.p, totalItems, (int)k, globalAvgShift, minRecommendRating, (double *)dScores.p);
+    }
     if (nSkip)
       hipLaunchKernelGGL(recommend_skip_kernel, dim3((unsigned)nb), dim3(256), 0, nullptr, (const int64_t *)dSkipPtr.p, (const int32_t *)dSkip.p, totalItems,
                          (double *)dScores.p);
