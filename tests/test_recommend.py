@@ -69,9 +69,11 @@ def test_gpu_float64_exact(als):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("k", [20, 100])
+@pytest.mark.parametrize("k", [20, 100, 7, 1000])
 def test_gpu_float32_against_oracle(als, k):
-    U, V, ptr, sk, skips = problem(64, 5000, k, 7 + k)
+    # k = 20, 100, 7: the scores on the matrix cores (k padded to 32, 112, 16 in LDS); k = 1000: sixteen users' factors no
+    # longer fit the default LDS limit, the 16-lane-group kernel takes over
+    U, V, ptr, sk, skips = problem(64, 5000 if k <= 100 else 700, k, 7 + k)
     ids, pred, cnt, _ = als.recommend_items(U, V, ptr, sk, globalAvgShift=-0.1, minRecommendRating=1.5, limit=20)
     for u in range(64):
         oid, opr = orc.recommend(U[u], V, skips[u], -0.1, 1.5, 20)
