@@ -321,43 +321,69 @@ __global__ void rating_stats_combine_kernel(const int32_t *rowList, const int64_
   sum[rowList[i]] = s;
 }
 
-// ---- N2: CSR construction (sort by a 64-bit (row, col) key with rocPRIM's radix sort; these
-// kernels build the keys and unpack the result) ----
-__global__ void make_keys_kernel(const int32_t *rowIdx, const int32_t *colIdx, int64_t n, uint64_t *keys, uint32_t *pos) {
+// ---- N2: CSR construction (sort by a (row << colBits | col) key with rocPRIM's radix sort; these
+// kernels build the keys and unpack the result).  colBits = the bits the column ids need (round 3: the key was
+// row << 32 | col, whose 18 always-zero bits between the two ids at MAL scale each radix pass still had to read) ----
+__global__ void make_keys_kernel(const int32_t *rowIdx, const int32_t *colIdx, int64_t n, int colBits, uint64_t *keys, uint32_t *pos) {
   const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= n) return;
-  keys[q] = ((uint64_t)(uint32_t)rowIdx[q] << 32) | (uint32_t)colIdx[q];
-  pos[q] = (uint32_t)q;
-}
-// transposing: entry q of a CSR belongs to row = upper_bound(rowPtr, q) - 1; its key is (col, row)
-__global__ void make_transpose_keys_kernel(const int64_t *rowPtr, int64_t rows, const int32_t *indx, int64_t n, uint64_t *keys,
-                                           uint32_t *pos) {
-  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= n) return;
-  int64_t lo = 0, hi = rows;  // first r with rowPtr[r + 1] > q
-  while (lo < hi) {
-    const int64_t mid = (lo + hi) >> 1;
-    if (rowPtr[mid + 1] <= q) lo = mid + 1;
-    else hi = mid;
-  }
-  keys[q] = ((uint64_t)(uint32_t)indx[q] << 32) | (uint32_t)lo;
+  keys[q] = ((uint64_t)(uint32_t)rowIdx[q] << colBits) | (uint32_t)colIdx[q];
   pos[q] = (uint32_t)q;
 }
 template <typename T>
-__global__ void unpack_sorted_kernel(const uint64_t *keys, const uint32_t *pos, const T *vals, int64_t n, int32_t *indx, T *outVals) {
+__global__ void unpack_sorted_kernel(const uint64_t *keys, const uint32_t *pos, const T *vals, int64_t n, int colBits, int32_t *indx, T *outVals) {
   const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= n) return;
-  indx[q] = (int32_t)(uint32_t)keys[q];
+  indx[q] = (int32_t)(keys[q] & (((uint64_t)1 << colBits) - 1));
   outVals[q] = vals[pos[q]];
 }
 // rowPtr[r] = first sorted position whose row (high key half) is >= r, r = 0..rows
-__global__ void row_ptr_kernel(const uint64_t *keys, int64_t n, int64_t rows, int64_t *rowPtr) {
+__global__ void row_ptr_kernel(const uint64_t *keys, int64_t n, int64_t rows, int colBits, int64_t *rowPtr) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r > rows) return;
   int64_t lo = 0, hi = n;
   while (lo < hi) {
     const int64_t mid = (lo + hi) >> 1;
-    if ((int64_t)(keys[mid] >> 32) < r) lo = mid + 1;
+    if ((int64_t)(keys[mid] >> colBits) < r) lo = mid + 1;
+    else hi = mid;
+  }
+  rowPtr[r] = lo;
+}
+
+// Transposing a CSR needs no (col, row) key: the entries are already in (row, col-position) order, so a STABLE sort by
+// column id alone (a 32-bit key of bits_for(cols) bits: two radix passes at MAL scale instead of five) leaves every new row
+// in ascending order of the old row ids (round 3).  The old row of every entry is found before the sort.
+// position q -> itself, and the row it belongs to (first r with rowPtr[r + 1] > q); consecutive threads search
+// neighbouring ranges, so rowPtr stays in cache (the same search from the SORTED positions, scattered over the array, cost
+// three times as much)
+__global__ void iota_rows_kernel(const int64_t *rowPtr, int64_t rows, int64_t n, uint32_t *pos, int32_t *rowOf) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  int64_t lo = 0, hi = rows;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (rowPtr[mid + 1] <= q) lo = mid + 1;
+    else hi = mid;
+  }
+  pos[q] = (uint32_t)q;
+  rowOf[q] = (int32_t)lo;
+}
+template <typename T>
+__global__ void unpack_transposed_kernel(const uint32_t *pos, const int32_t *rowOf, const T *vals, int64_t n, int32_t *indx, T *outVals) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  const int64_t p = pos[q];
+  indx[q] = rowOf[p];
+  outVals[q] = vals[p];
+}
+// rowPtr[r] = first sorted position whose key is >= r, r = 0..rows
+__global__ void row_ptr32_kernel(const uint32_t *keys, int64_t n, int64_t rows, int64_t *rowPtr) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > rows) return;
+  int64_t lo = 0, hi = n;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if ((int64_t)keys[mid] < r) lo = mid + 1;
     else hi = mid;
   }
   rowPtr[r] = lo;

@@ -1039,19 +1039,18 @@ int sort_and_unpack(int dtype, int64_t n, int64_t outRows, int64_t outCols, uint
   HIP_TRY(hipMalloc(&dOutVals.p, (size_t)n * ts));
   HIP_TRY(hipMalloc(&dPtr.p, (size_t)(outRows + 1) * 8));
   size_t tmpBytes = 0;
-  const int endBit = 32 + bits_for(outRows);
-  (void)outCols;
+  const int colBits = bits_for(outCols), endBit = colBits + bits_for(outRows);
   HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmpBytes, dKeys, (uint64_t *)dKeys2.p, dPos, (uint32_t *)dPos2.p, (int)n, 0, endBit));
   HIP_TRY(hipMalloc(&dTmp.p, std::max<size_t>(tmpBytes, 8)));
   HIP_TRY(hipcub::DeviceRadixSort::SortPairs(dTmp.p, tmpBytes, dKeys, (uint64_t *)dKeys2.p, dPos, (uint32_t *)dPos2.p, (int)n, 0, endBit));
   const unsigned b256 = (unsigned)((n + 255) / 256);
   if (dtype == YCNR_F32)
     hipLaunchKernelGGL(unpack_sorted_kernel<float>, dim3(b256), dim3(256), 0, nullptr, (const uint64_t *)dKeys2.p, (const uint32_t *)dPos2.p,
-                       (const float *)dVals, n, (int32_t *)dIndx.p, (float *)dOutVals.p);
+                       (const float *)dVals, n, colBits, (int32_t *)dIndx.p, (float *)dOutVals.p);
   else
     hipLaunchKernelGGL(unpack_sorted_kernel<double>, dim3(b256), dim3(256), 0, nullptr, (const uint64_t *)dKeys2.p, (const uint32_t *)dPos2.p,
-                       (const double *)dVals, n, (int32_t *)dIndx.p, (double *)dOutVals.p);
-  hipLaunchKernelGGL(row_ptr_kernel, dim3((unsigned)((outRows + 1 + 255) / 256)), dim3(256), 0, nullptr, (const uint64_t *)dKeys2.p, n, outRows,
+                       (const double *)dVals, n, colBits, (int32_t *)dIndx.p, (double *)dOutVals.p);
+  hipLaunchKernelGGL(row_ptr_kernel, dim3((unsigned)((outRows + 1 + 255) / 256)), dim3(256), 0, nullptr, (const uint64_t *)dKeys2.p, n, outRows, colBits,
                      (int64_t *)dPtr.p);
   hipError_t le = hipGetLastError();
   if (le != hipSuccess) return fail(YCNR_ERR_HIP, "csr build: %s", hipGetErrorString(le));
@@ -1094,7 +1093,7 @@ int ycnr_csr_from_triplets(int dtype, int64_t n, const int32_t *rowIdx, const in
   const hipEvent_t e0 = evp.a, e1 = evp.b;
   HIP_TRY(hipEventRecord(e0, nullptr));
   hipLaunchKernelGGL(make_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, (const int32_t *)dR.p, (const int32_t *)dC.p, n,
-                     (uint64_t *)dKeys.p, (uint32_t *)dPos.p);
+                     bits_for(cols), (uint64_t *)dKeys.p, (uint32_t *)dPos.p);
   int rc = sort_and_unpack(dtype, n, rows, cols, (uint64_t *)dKeys.p, (uint32_t *)dPos.p, dV.p, rowPtr, indx, outVals, e0, e1, deviceMs);
   return rc;
 }
@@ -1117,23 +1116,50 @@ int ycnr_csr_transpose(int dtype, int64_t rows, int64_t cols, const int64_t *row
   for (int64_t q = 0; q < n; ++q)
     if (indx[q] < 0 || indx[q] >= cols) return fail(YCNR_ERR_INVALID, "entry %lld: column %d outside %lld", (long long)q, indx[q], (long long)cols);
   const size_t ts = tsize(dtype);
-  DevBuf dP, dI, dV, dKeys, dPos;
+  DevBuf dP, dI, dV, dPos, dRowOf, dKeys2, dPos2, dTmp, dIndx, dOutVals, dPtr;
   HIP_TRY(hipMalloc(&dP.p, (size_t)(rows + 1) * 8));
   HIP_TRY(hipMalloc(&dI.p, (size_t)n * 4));
   HIP_TRY(hipMalloc(&dV.p, (size_t)n * ts));
-  HIP_TRY(hipMalloc(&dKeys.p, (size_t)n * 8));
   HIP_TRY(hipMalloc(&dPos.p, (size_t)n * 4));
+  HIP_TRY(hipMalloc(&dRowOf.p, (size_t)n * 4));
+  HIP_TRY(hipMalloc(&dKeys2.p, (size_t)n * 4));
+  HIP_TRY(hipMalloc(&dPos2.p, (size_t)n * 4));
+  HIP_TRY(hipMalloc(&dIndx.p, (size_t)n * 4));
+  HIP_TRY(hipMalloc(&dOutVals.p, (size_t)n * ts));
+  HIP_TRY(hipMalloc(&dPtr.p, (size_t)(cols + 1) * 8));
   HIP_TRY(hipMemcpy(dP.p, rowPtr, (size_t)(rows + 1) * 8, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(dI.p, indx, (size_t)n * 4, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(dV.p, vals, (size_t)n * ts, hipMemcpyHostToDevice));
+  // a stable sort of the positions by column id alone (prep_kernels.hip.h): the ids are non-negative, so they sort as uint32
+  size_t tmpBytes = 0;
+  const int endBit = bits_for(cols);
+  HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmpBytes, (const uint32_t *)dI.p, (uint32_t *)dKeys2.p, (const uint32_t *)dPos.p,
+                                             (uint32_t *)dPos2.p, (int)n, 0, endBit));
+  HIP_TRY(hipMalloc(&dTmp.p, std::max<size_t>(tmpBytes, 8)));
   EvPair evp;
   HIP_TRY(evp.create());
   const hipEvent_t e0 = evp.a, e1 = evp.b;
   HIP_TRY(hipEventRecord(e0, nullptr));
-  hipLaunchKernelGGL(make_transpose_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, (const int64_t *)dP.p, rows,
-                     (const int32_t *)dI.p, n, (uint64_t *)dKeys.p, (uint32_t *)dPos.p);
-  int rc = sort_and_unpack(dtype, n, cols, rows, (uint64_t *)dKeys.p, (uint32_t *)dPos.p, dV.p, outPtr, outIndx, outVals, e0, e1, deviceMs);
-  return rc;
+  const unsigned b256 = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(iota_rows_kernel, dim3(b256), dim3(256), 0, nullptr, (const int64_t *)dP.p, rows, n, (uint32_t *)dPos.p, (int32_t *)dRowOf.p);
+  HIP_TRY(hipcub::DeviceRadixSort::SortPairs(dTmp.p, tmpBytes, (const uint32_t *)dI.p, (uint32_t *)dKeys2.p, (const uint32_t *)dPos.p,
+                                             (uint32_t *)dPos2.p, (int)n, 0, endBit));
+  if (dtype == YCNR_F32)
+    hipLaunchKernelGGL(unpack_transposed_kernel<float>, dim3(b256), dim3(256), 0, nullptr, (const uint32_t *)dPos2.p, (const int32_t *)dRowOf.p,
+                       (const float *)dV.p, n, (int32_t *)dIndx.p, (float *)dOutVals.p);
+  else
+    hipLaunchKernelGGL(unpack_transposed_kernel<double>, dim3(b256), dim3(256), 0, nullptr, (const uint32_t *)dPos2.p, (const int32_t *)dRowOf.p,
+                       (const double *)dV.p, n, (int32_t *)dIndx.p, (double *)dOutVals.p);
+  hipLaunchKernelGGL(row_ptr32_kernel, dim3((unsigned)((cols + 1 + 255) / 256)), dim3(256), 0, nullptr, (const uint32_t *)dKeys2.p, n, cols,
+                     (int64_t *)dPtr.p);
+  hipError_t le = hipGetLastError();
+  if (le != hipSuccess) return fail(YCNR_ERR_HIP, "csr transpose: %s", hipGetErrorString(le));
+  int rc = timed(e0, e1, deviceMs);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpy(outPtr, dPtr.p, (size_t)(cols + 1) * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(outIndx, dIndx.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(outVals, dOutVals.p, (size_t)n * ts, hipMemcpyDeviceToHost));
+  return YCNR_OK;
 }
 
 // ---- N3: top-N recommend ----
