@@ -499,25 +499,32 @@ __global__ __launch_bounds__(256) void recommend_skip_kernel(const int64_t *skip
 // picks the `take` best scores of a user, best first, ties by the lower item id; -1 pads
 __global__ __launch_bounds__(256) void recommend_select_kernel(double *scores, int64_t totalItems, int take, int stride, int32_t *outIds,
                                                               double *outPredict, int32_t *outCount) {
+  // Every thread keeps the best of its own slice (items tid, tid + 256, ...); a round is a workgroup arg-max over those and a
+  // re-scan of the winner's slice by its owner only (round 3: every thread re-read its slice in every round -- the 208 MB
+  // of scores of 2048 users crossed the memory system `limit` times).
   __shared__ double bestV[256];
   __shared__ int64_t bestI[256];
+  __shared__ int64_t winner;
   const int64_t user = blockIdx.x;
   double *sc = scores + user * totalItems;
-  int found = 0;
-  for (int round = 0; round < stride; ++round) {
-    double v = -INFINITY;
-    int64_t idx = -1;
-    if (round < take) {
-      for (int64_t it = threadIdx.x; it < totalItems; it += 256) {
-        const double x = sc[it];
-        if (x > v) {  // strict: the lowest id among equal scores of this thread stays
-          v = x;
-          idx = it;
-        }
+  auto scan = [&](double &v, int64_t &idx) {
+    v = -INFINITY;
+    idx = -1;
+    for (int64_t it = threadIdx.x; it < totalItems; it += 256) {
+      const double x = sc[it];
+      if (x > v) {  // strict: the lowest id among equal scores of this thread stays
+        v = x;
+        idx = it;
       }
     }
-    bestV[threadIdx.x] = v;
-    bestI[threadIdx.x] = idx;
+  };
+  double myV;
+  int64_t myI;
+  scan(myV, myI);
+  int found = 0;
+  for (int round = 0; round < stride; ++round) {
+    bestV[threadIdx.x] = round < take ? myV : -INFINITY;
+    bestI[threadIdx.x] = round < take ? myI : -1;
     __syncthreads();
     for (int m = 128; m >= 1; m >>= 1) {
       if ((int)threadIdx.x < m) {
@@ -535,10 +542,14 @@ __global__ __launch_bounds__(256) void recommend_select_kernel(double *scores, i
       const bool got = bestI[0] >= 0 && bestV[0] > -INFINITY;
       outIds[user * stride + round] = got ? (int32_t)bestI[0] : -1;
       outPredict[user * stride + round] = got ? bestV[0] : 0.0;
-      if (got) {
-        sc[bestI[0]] = -INFINITY;
-        ++found;
-      }
+      winner = got ? bestI[0] : -1;
+      if (got) ++found;
+    }
+    __syncthreads();
+    const int64_t w = winner;
+    if (w >= 0 && (int)(w & 255) == (int)threadIdx.x) {  // the owner of the winner takes it out and looks for its next best
+      sc[w] = -INFINITY;
+      scan(myV, myI);
     }
     __syncthreads();
   }
