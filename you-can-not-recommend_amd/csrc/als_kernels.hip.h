@@ -1958,7 +1958,7 @@ __global__ __launch_bounds__(64, 2) void als_gram_solve_x6d_kernel(StepArgs<floa
 // operand values 32 s + 8 g .. + 7 of row 16 ba + c as two float4 and splits them in place; 6 MFMAs
 // of K = 32 per tile replace 8 float32 MFMAs of K = 4 that cost 35 cycles each.
 template <int NBN, bool X6>
-__global__ __launch_bounds__(64, NBN == 3 ? 4 : NBN == 4 ? 3 : NBN == 7 ? 2 : 1) void als_dual_solve_kernel(StepArgs<float> a) {
+__global__ __launch_bounds__(64, NBN == 3 ? 4 : NBN == 4 ? 3 : 1) void als_dual_solve_kernel(StepArgs<float> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using Sv = SolveMfmaF32<NBN>;
   using Tr = MfmaTraits<float>;
