@@ -91,6 +91,35 @@ def test_packed_fma_lint_names_the_gram_x6d_kernels_only(tmp_path, capsys):
     assert "x6d" in capsys.readouterr().out
 
 
+SCRATCH = """
+	.amdhsa_kernel _ZN4ycnr21als_dual_solve_kernelILi7ELb1EEEvNS_8StepArgsIfEE
+		.amdhsa_private_segment_fixed_size 24
+	.end_amdhsa_kernel
+	.amdhsa_kernel _ZN4ycnr21als_dual_solve_kernelILi11ELb1EEEvNS_8StepArgsIfEE
+		.amdhsa_private_segment_fixed_size 112
+	.end_amdhsa_kernel
+	.amdhsa_kernel _ZN4ycnr21als_dual_solve_kernelILi4ELb1EEEvNS_8StepArgsIfEE
+		.amdhsa_private_segment_fixed_size 0
+	.end_amdhsa_kernel
+	.amdhsa_kernel _ZN4ycnr23als_reduce_solve_kernelIdLi8ELb0ELb0ELb0EEEvNS_8StepArgsIT_EE
+		.amdhsa_private_segment_fixed_size 320
+	.end_amdhsa_kernel
+"""
+
+
+def test_scratch_lint_rejects_any_spill_in_the_smaller_dual_classes(tmp_path, capsys):
+    """A 7-block dual class with 24 bytes of scratch (forced to two waves per SIMD) solved rows wrong at C5 scale in round 3
+    and passed every small GPU test: the build is rejected here, on the CPU.  The verified 11-block class and other
+    kernels below the general limit pass."""
+    lint = load_lint()
+    f = tmp_path / "scratch.s"
+    f.write_text(SCRATCH)
+    assert lint.lint_scratch(str(f)) == 1
+    out = capsys.readouterr().out
+    fails = [l for l in out.splitlines() if l.startswith("FAIL")]
+    assert len(fails) == 1 and "dual class of 7 blocks" in fails[0]
+
+
 def test_dpp_lint_counts_wait_states_over_every_path(tmp_path, capsys):
     lint = load_lint()
     good, bad = tmp_path / "good.s", tmp_path / "bad.s"
