@@ -76,10 +76,15 @@ def main():
     ap.add_argument("--transport", default="", choices=["", "rccl", "ipc", "shm"],
                     help="exchange transport inside libycnr_als.so for N > 1 (default: rccl; shm with --same-device / gloo; "
                          "ipc = mapped peer replicas + copy engines, also with several ranks on one GPU)")
+    ap.add_argument("--transport-ab", default="", choices=["", "rccl", "ipc", "shm"],
+                    help="N > 1: after the timed run, the same iterations once more over THIS transport; reported beside it as exchange.ab")
+    ap.add_argument("--allow-fallback", action="store_true",
+                    help="N > 1: let the host fall back to torch.distributed's all-gather when the requested transport cannot be "
+                         "set up (default: exit non-zero -- a line must not name a path that did not run)")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="one GPU solves the shard of every rank of a world of this size in turn (exchange left out) and "
                          "reports the compute time per rank, before and after the feedback re-cut of the shards")
-    ap.add_argument("--rebalance-after", type=int, default=1, help="N > 1: re-cut the shards from measured times after this many iterations (0 = never)")
+    ap.add_argument("--rebalance-after", type=int, default=2, help="N > 1: re-cut the shards from measured times after each of the first this-many iterations (0 = never)")
     ap.add_argument("--exchange-chunks", type=int, default=4, help="pieces a large side's shard is solved in (exchange overlaps solve)")
     ap.add_argument("--dump-factors", default="", help="write the final factor matrices of rank 0 to this .npz")
     ap.add_argument("--debug-mod-idx", type=int, default=0,
@@ -130,12 +135,15 @@ def main():
     from ycnr_als.data import select_csr
     val = select_csr(by_user, torch.rand(nnz, generator=g, device=dev) < 0.10)
     ds = Dataset(by_user, by_item, validate=val, test=None, total_ratings_avg=float(by_user.vals.double().mean()))
+    requested_transport = args.transport or ("shm" if args.same_device or args.backend == "gloo" else "rccl")
     lord = EmfLord(options={"factorsCount": k, "trainIters": args.steps, "useDoublePrecision": args.double,
                             "dbType": "mal" if max_rating == 10 else "ml", "chunkRatings": args.chunk,
                             "dataSetDistr": [90, 10, 0], "exchangeChunks": args.exchange_chunks, "rebalanceAfterIters": args.rebalance_after,
-                            "commTransport": args.transport or ("shm" if args.same_device or args.backend == "gloo" else "rccl")},
+                            "commTransport": requested_transport, "strictTransport": not args.allow_fallback},
                     dist=dist)
     lord.prepareToTrain(ds, seed=20260004, device=local_rank)
+    if world > 1 and not args.allow_fallback and lord.exchangePath != "libycnr_als:" + requested_transport:
+        sys.exit(f"bench.py: the exchange runs over '{lord.exchangePath}', not over the requested 'libycnr_als:{requested_transport}'")
     t_prep = time.time() - t0 - t_gen
 
     def barrier():
@@ -249,6 +257,11 @@ def main():
                 "algorithmic_GBs": round(gb, 1), "hbm_frac": round(gb / PEAK_HBM_GBS, 4)}
 
     dd = describe(dom)
+    # an entry whose flops could not have run in its time (fraction of the pipe's peak above 1) is an accounting error --
+    # flops attributed to a kernel that did not execute them -- and is not printed as a measurement
+    bad_entries = [n for n in kern if kern[n]["launches"] and describe(n)["mfma_frac"] > 1.0]
+    if bad_entries:
+        sys.exit("bench.py: accounting error, mfma_frac > 1 for " + ", ".join(bad_entries) + " -- refusing to print the line")
     tot_ms = sum(d["ms"] for d in kern.values())
     tot_fl = sum(d["fg"] + d["fs"] for d in kern.values())
     tot_by = sum(d["bytes"] for d in kern.values())
@@ -320,10 +333,13 @@ def main():
         for sd in ("byUser", "byItem"):
             exchange[sd]["compute_ms_by_rank"] = [r[sd] for r in per_rank]
         exchange["replicas_consistent"] = all(r["sums"] == per_rank[0]["sums"] for r in per_rank)
+        exchange["requested_transport"] = requested_transport
         if lord.rebalanced:
             exchange["rebalanced_after_iter"] = args.rebalance_after
             exchange["before_rebalance_ms_by_rank"] = {("byUser", "byItem")[sd]: [round(x, 4) for x in v["ms_by_rank"]]
                                                        for sd, v in lord.rebalanced.items()}
+        if args.transport_ab and args.transport_ab != requested_transport:
+            exchange["ab"] = transport_ab(args, dist, ds, k, max_rating, local_rank, dev, barrier, lord.shards)
 
     rmse = lord.calcRmse("rmseValidate", False)
     if args.dump_factors and rank == 0:
@@ -348,8 +364,62 @@ def main():
         }
         print(json.dumps(out), flush=True)
     lord.destroy()
+    consistent = (not dist) or exchange.get("replicas_consistent", True)
     if dist:
         dist.destroy_process_group()
+    if not consistent:
+        sys.exit("bench.py: the replicas of the factor matrices differ between the ranks after the last exchange")
+
+
+def transport_ab(args, dist, ds, k, max_rating, local_rank, dev, barrier, shards):
+    """--transport-ab T: the same warm-up + timed iterations once more with the exchange over transport T, on the shards the
+    main run ended with (no re-cut), for a line that shows both transports from one process group.  A transport that cannot
+    be set up is reported as an error string; it never takes the main line down."""
+    from ycnr_als.emf import EmfLord
+    world = dist.get_world_size()
+    out = {"transport": args.transport_ab}
+    lord = None
+    try:
+        lord = EmfLord(options={"factorsCount": k, "trainIters": args.steps, "useDoublePrecision": args.double,
+                                "dbType": "mal" if max_rating == 10 else "ml", "chunkRatings": args.chunk, "dataSetDistr": [90, 10, 0],
+                                "exchangeChunks": args.exchange_chunks, "rebalanceAfterIters": 0, "commTransport": args.transport_ab,
+                                "strictTransport": True}, dist=dist)
+        lord.prepareToTrain(ds, seed=20260004, device=local_rank, shards={s: np.asarray(shards[s]) for s in (0, 1)})
+        for _ in range(args.warmup):
+            lord.alsTrainIter()
+        lord.stepTimes.clear()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            lord.alsTrainIter()
+        barrier()
+        t = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        out["path"] = lord.exchangePath
+        out["ms_per_step"] = 1e3 * float(t.item()) / args.steps
+        for sd in ("byUser", "byItem"):
+            st = [x for x in lord.stepTimes if x["stepType"] == sd]
+            n = max(len(st), 1)
+            out[sd] = {"compute_ms": round(sum(x["info"].totalMs for x in st) / n, 4),
+                       "exchange_ms": round(sum(x["info"].exchangeMs for x in st) / n, 4),
+                       "exposed_exchange_ms": round(sum(x["info"].exposedExchangeMs for x in st) / n, 4),
+                       "wall_ms": round(sum(x["wall"] for x in st) * 1e3 / n, 4)}
+        sums = []
+        for side in (0, 1):
+            f = lord.backend.factors(side)
+            sums.append(int(f.view(torch.int32 if f.dtype == torch.float32 else torch.int64).to(torch.int64).sum().item()))
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, sums)
+        out["replicas_consistent"] = all(r == per_rank[0] for r in per_rank)
+    except Exception as e:  # noqa: BLE001 -- reported, the main line stands
+        out["error"] = str(e)[:300]
+    finally:
+        if lord is not None and lord.backend is not None:
+            try:
+                lord.destroy()
+            except Exception:  # noqa: BLE001
+                pass
+    return out
 
 
 class EmulatedDist:

@@ -237,7 +237,11 @@ int ycnr_als_bind_factors(ycnr_als *h, int side, void *devicePtr);
  * row with >= 1 rating is re-solved against the CURRENT opposite factors and written in
  * place; rows without ratings are untouched.  Returns after the stream has drained. */
 int ycnr_als_step(ycnr_als *h, int side);
-/* Enqueue only; pair with ycnr_als_sync before reading results or step info. */
+/* Enqueue only; pair with ycnr_als_sync before reading results or step info.  Several half-steps may be
+ * enqueued back to back.  With a communicator the call is collective like ycnr_als_step; on the YCNR_COMM_IPC
+ * transport a half-step enqueued behind one that ycnr_als_sync has not completed first completes that one
+ * (stream drained + the end-of-step barrier: its fixed side is the matrix the peers were still pushing into),
+ * so back-to-back calls are correct there too, only not asynchronous. */
 int ycnr_als_step_async(ycnr_als *h, int side);
 int ycnr_als_sync(ycnr_als *h);
 int ycnr_als_last_step_info(ycnr_als *h, ycnr_als_step_info *info);

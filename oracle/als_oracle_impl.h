@@ -138,7 +138,7 @@ int64_t PFX(AlsCalcPortion)(double lambda, int k, const int32_t *alsRows, const 
     T *Y = (T *)malloc(sizeof(T) * ((size_t)(maxCols > 0 ? maxCols : 1) * k));
     T *A = (T *)malloc(sizeof(T) * (size_t)k * k);
     T *b = (T *)malloc(sizeof(T) * (size_t)k);
-#pragma omp for schedule(dynamic, 8)
+#pragma omp for schedule(dynamic, 1)
     for (int r = 0; r < nRows; r++) {
       int rowId = alsRows[1 + 2 * r];
       int cols = alsRows[1 + 2 * r + 1];
@@ -176,7 +176,7 @@ int64_t PFX(AlsStepCsr)(double lambda, int k, int64_t rowBegin, int64_t rowEnd, 
     T *Y = (T *)malloc(sizeof(T) * ((size_t)(maxCols > 0 ? maxCols : 1) * k));
     T *A = (T *)malloc(sizeof(T) * (size_t)k * k);
     T *b = (T *)malloc(sizeof(T) * (size_t)k);
-#pragma omp for schedule(dynamic, 8)
+#pragma omp for schedule(dynamic, 1)
     for (int64_t r = rowBegin; r < rowEnd; r++) {
       int64_t cols = rowPtr[r + 1] - rowPtr[r];
       if (cols <= 0) continue;

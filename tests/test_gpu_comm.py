@@ -129,7 +129,7 @@ def test_train_under_the_nccl_backend(als):
     assert q.get(timeout=5) is True
 
 
-def _rank_main(rank, world, uid, pieces, out, transport="shm", device=0, shape="k36"):
+def _rank_main(rank, world, uid, pieces, out, transport="shm", device=0, shape="k36", back_to_back=False):
     import ycnr_als as als
     k, users, items, bu, bi, U, V = problem(*SHAPES[shape])
     dev = als.AlsDevice(k, users, items, device=device)
@@ -146,9 +146,20 @@ def _rank_main(rank, world, uid, pieces, out, transport="shm", device=0, shape="
     # only rank 1 holds the item factors at first: the join-time copy (EmfChief.js:55-71)
     dev.set_factors("byItem", V if rank == 1 else np.zeros_like(V))
     dev.broadcast_factors("byItem", 1)
-    iu = dev.step("byUser")
-    ii = dev.step("byItem")
-    s = dev.allreduce_sum(np.array([float(rank + 1), float(iu.ratings)]))
+    if back_to_back:
+        # both half-steps enqueued before one sync: the item half-step must not read user rows the peers are still
+        # pushing (ycnr_als_step_async completes a pending IPC half-step first)
+        dev.step_async("byUser")
+        dev.step_async("byItem")
+        dev.sync()
+        ii = dev.last_step_info()
+        iu = ii
+        ratings = float(bu.nnz)
+    else:
+        iu = dev.step("byUser")
+        ii = dev.step("byItem")
+        ratings = float(iu.ratings)
+    s = dev.allreduce_sum(np.array([float(rank + 1), ratings]))
     got = dev.get_factors("byUser"), dev.get_factors("byItem")
     dev.destroy()
     out.put((rank, got, s.tolist(), int(iu.parts), int(iu.exchangeBytes), int(ii.exchangeBytes)))
@@ -177,6 +188,27 @@ def test_ranks_of_one_node_on_one_gpu(als, transport, world, pieces, shape):
         assert np.array_equal(Ug, U1) and np.array_equal(Vg, V1), f"rank {rank}: replicas differ from the single-process run"
         assert s == [world * (world + 1) / 2, float(bu.nnz)]
         assert parts == pieces and xu > 0 and xi > 0
+
+
+@pytest.mark.parametrize("transport,world", [("ipc", 2), ("ipc", 3), ("shm", 2)])
+def test_back_to_back_async_half_steps(als, transport, world):
+    """step_async(byUser); step_async(byItem); sync between real processes sharing cuda:0: on the push transport the
+    second half-step would read user rows that its peers are still writing unless the first is completed before it
+    starts (round-3 review; ycnr_als.h documents the rule).  Bit for bit against the single-process result."""
+    k, users, items, bu, bi, U, V = problem(*SHAPES["k100"])
+    U1, V1 = reference_iteration(als, k, users, items, bu, bi, U, V)
+    uid = als.AlsDevice.comm_unique_id(transport)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_main, args=(r, world, uid, 3, q, transport, 0, "k100", True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, (Ug, Vg), s, parts, xu, xi in res:
+        assert np.array_equal(Ug, U1) and np.array_equal(Vg, V1), f"rank {rank}: replicas differ from the single-process run"
 
 
 @pytest.mark.parametrize("transport", ["rccl", "ipc"])

@@ -1,4 +1,4 @@
-"""BASELINE.json's configurations C2, C3 and C5 (whole, and one GPU's shard) through the HIP path, and the k = 100
+"""BASELINE.json's configurations C2, C3, C4 and C5 (whole, and one GPU's shard) through the HIP path, and the k = 100
 regimes of fixed matrices beyond 2 GB and 4 GB.
 
   C2  MovieLens-1M shape (6040 x 3883, ~1 M ratings), k = 100, 10 ALS iterations, float32 and
@@ -6,6 +6,8 @@ regimes of fixed matrices beyond 2 GB and 4 GB.
       (/root/reference README.md:118-129 is the configuration; lib/emf/EmfWorker.js:169-261 the path).
   C3  200 K x 20 K, 20 M ratings, k = 64 at full size: one iteration; oracle on a row sample of
       every length class + size-independent properties (normal equations, linearity).
+  C4  MAL scale, 1.75 M x 12.7 K, 121 M ratings, k = 100 -- the configuration bench.py's headline is quoted on -- at
+      full size: every row-length class of both sides against the float32 and the float64 oracle (round 4).
   C5  10 M x 100 K, 1 B ratings, k = 256 at FULL size on one GPU (10.24 GB of user factors: 64-bit addressing on the
       item side, index arrays past 2^31 bytes), and one GPU's eighth of it (1.25 M x 100 K, 125 M ratings): the same.
       Rows beyond 400 K ratings are too slow for the CPU oracle (an item of the full C5 has up to ~10 M): they are
@@ -127,6 +129,7 @@ def test_c2_ml1m_shape_ten_iterations(als, double):
 CONFIGS = {
     # users, items, nnz, k, max_rating, zipf_a, degree_sigma   (bench.py WORKLOADS)
     "c3": (200_000, 20_000, 20_000_000, 64, 10, 0.8, 1.0),
+    "mal": (1_750_000, 12_700, 121_000_000, 100, 10, 0.6, 1.2),
     "c5shard": (1_250_000, 100_000, 125_000_000, 256, 10, 0.7, 1.0),
     "c5": (10_000_000, 100_000, 1_000_000_000, 256, 10, 0.7, 1.0),
     # nnz = None: item rows of prescribed lengths (ratings_by_item_lengths), users spread over the whole matrix
@@ -162,16 +165,27 @@ def ratings_by_item_lengths(torch, users, items, seed, dev):
     return by_user, by_item
 
 
-def sample_by_class(lens, per_class, longest, seed, dual_max, chunk):
+def sample_by_class(lens, per_class, longest, seed, dual_max, chunk, ratings_budget=None):
     """Row ids covering every kernel class: one bucket per 16-rating block count up to dual_max, the
-    whole rows above it, the rows split into chunks, plus the `longest` longest rows."""
+    whole rows above it, the rows split into chunks -- in buckets of a factor 4 in length, so that rows of
+    2, 8, 32 ... chunks are all there (an item of C5 has 1 K ... 10 M ratings: one bucket for "split" used to
+    leave its item side with 12 oracle rows) -- plus the `longest` longest rows.  ratings_budget bounds the
+    ratings drawn from one bucket of split rows (the CPU oracle costs k^2 per rating): long buckets get fewer
+    rows, never fewer than 3."""
     rng = np.random.default_rng(seed)
-    edges = list(range(0, dual_max + 1, 16)) + [chunk, int(lens.max()) + 1]
+    top = int(lens.max()) + 1
+    edges = list(range(0, dual_max + 1, 16)) + [chunk]
+    while edges[-1] * 4 < top:
+        edges.append(edges[-1] * 4)
+    edges.append(top)
     pick = []
     for lo, hi in zip(edges[:-1], edges[1:]):
         ids = np.flatnonzero((lens > lo) & (lens <= hi))
+        want = per_class
+        if ratings_budget and lo >= chunk:
+            want = max(3, min(per_class, int(ratings_budget // max(1, min(hi, ORACLE_ROW_CAP)))))
         if len(ids):
-            pick.append(rng.choice(ids, min(per_class, len(ids)), replace=False))
+            pick.append(rng.choice(ids, min(want, len(ids)), replace=False))
     pick.append(np.argsort(lens)[-longest:])
     return np.unique(np.concatenate(pick))
 
@@ -193,6 +207,8 @@ def sub_problem(torch, csr, rows, fixed):
 
 def check_sample(oracle, torch, csr, rows, fixed, solved, k, what, rec):
     """HIP rows against the float32 oracle, the float64 oracle and the conditioning-aware bound."""
+    lens = (csr.rowPtr[1:] - csr.rowPtr[:-1])[torch.as_tensor(rows, device=csr.rowPtr.device)].cpu().numpy()
+    rows = np.asarray(rows)[np.argsort(-lens, kind="stable")]  # longest first: the oracle's threads take rows one at a time
     sp, si, sv, sf = sub_problem(torch, csr, rows, fixed)
     got = solved[torch.as_tensor(rows, device=solved.device)].cpu().numpy()
     o32 = np.zeros_like(got)
@@ -237,7 +253,7 @@ def backward_errors(torch, csr, vals, fixed, solved, rows, k):
     return np.array(out)
 
 
-@pytest.mark.parametrize("name", ["c3", "c5shard", "big2g", "big4g", "c5"])
+@pytest.mark.parametrize("name", ["c3", "mal", "c5shard", "big2g", "big4g", "c5"])
 def test_full_size_iteration(als, oracle, name):
     import torch
     from ycnr_als.data import synth_ratings
@@ -275,8 +291,10 @@ def test_full_size_iteration(als, oracle, name):
     # below; als_dual_quad for <= 16), whole rows, split rows, the longest rows
     dual_max = 192 if k > 128 else 80
     lun, lin = lu.cpu().numpy(), li.cpu().numpy()
-    ru = sample_by_class(lun, 60 if k <= 128 else 24, 8, 5, dual_max, 1024)
-    ri = sample_by_class(lin, 40 if k <= 128 else 12, 4, 6, dual_max, 1024)
+    # (the oracle costs k^2 per rating: per bucket of split rows about 6 M ratings at k <= 128, 1.5 M beyond)
+    budget = 6_000_000 if k <= 128 else 1_500_000
+    ru = sample_by_class(lun, 60 if k <= 128 else 24, 8, 5, dual_max, 1024, budget)
+    ri = sample_by_class(lin, 40 if k <= 128 else 16, 4, 6, dual_max, 1024, budget)
     ru, ri = ru[lun[ru] <= ORACLE_ROW_CAP], ri[lin[ri] <= ORACLE_ROW_CAP]
     rec["classes_sampled"] = {"byUser_blocks": sorted(set(np.minimum((lun[ru] + 15) // 16, 12).tolist())),
                               "byItem_blocks": sorted(set(np.minimum((lin[ri] + 15) // 16, 12).tolist()))}

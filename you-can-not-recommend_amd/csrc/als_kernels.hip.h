@@ -1957,8 +1957,13 @@ __global__ __launch_bounds__(64, 2) void als_gram_solve_x6d_kernel(StepArgs<floa
 // runs over the k factors, which are contiguous in a gathered row, so lane (g, c) loads its eight
 // operand values 32 s + 8 g .. + 7 of row 16 ba + c as two float4 and splits them in place; 6 MFMAs
 // of K = 32 per tile replace 8 float32 MFMAs of K = 4 that cost 35 cycles each.
+// (YCNR_DUAL7_WAVES: devtest/dual7 builds the 7-block class at two waves per SIMD -- 24 bytes of scratch per lane --, the form
+// that solved rows wrong at C5 scale in round 3; the library keeps one wave per SIMD and no scratch there)
+#ifndef YCNR_DUAL7_WAVES
+#define YCNR_DUAL7_WAVES 1
+#endif
 template <int NBN, bool X6>
-__global__ __launch_bounds__(64, NBN == 3 ? 4 : NBN == 4 ? 3 : 1) void als_dual_solve_kernel(StepArgs<float> a) {
+__global__ __launch_bounds__(64, NBN == 3 ? 4 : NBN == 4 ? 3 : NBN == 7 ? YCNR_DUAL7_WAVES : 1) void als_dual_solve_kernel(StepArgs<float> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using Sv = SolveMfmaF32<NBN>;
   using Tr = MfmaTraits<float>;
@@ -1972,13 +1977,24 @@ __global__ __launch_bounds__(64, NBN == 3 ? 4 : NBN == 4 ? 3 : 1) void als_dual_
   // this lane's rating of each 16-rating block: its factor row and its value
   const float *rowp[NBN];
   float bacc[NBN];
+  // The ratings are only needed by the solve.  Classes of 7 and more blocks (k > 128) have no registers to keep them
+  // across the Gramian loop -- at two waves per SIMD the 7-block class spilled exactly these (5 dwords stored in front
+  // of the loop, reloaded behind it) -- so they load them after the loop (LATE_RHS): one more load latency per row,
+  // behind the last K-step's MFMAs.
+#ifdef YCNR_DUAL_EARLY_RHS  // devtest: the round-3 form (with YCNR_DUAL7_WAVES=2: 24 bytes of scratch per lane in the 7-block class)
+  constexpr bool LATE_RHS = false;
+#else
+  constexpr bool LATE_RHS = NBN >= 7;
+#endif
 #pragma unroll
   for (int ba = 0; ba < NBN; ++ba) {
     const int i = ba * 16 + c;
     const int64_t q = u.beg + (i < n ? i : n - 1);
     rowp[ba] = i < n ? a.fixed + (int64_t)a.indx[q] * k : a.zeros;
-    const float r = a.vals[q];
-    bacc[ba] = (i < n && g == 0) ? r : 0.0f;  // group_sum in the solver restores r in all groups
+    if constexpr (!LATE_RHS) {
+      const float r = a.vals[q];
+      bacc[ba] = (i < n && g == 0) ? r : 0.0f;  // group_sum in the solver restores r in all groups
+    }
   }
   acc_t acc[NT];
 #pragma unroll
@@ -2151,6 +2167,14 @@ __global__ __launch_bounds__(64, NBN == 3 ? 4 : NBN == 4 ? 3 : 1) void als_dual_
       for (int ba = 0; ba < NBN; ++ba) ya[ba] = yb[ba];
     }
 #endif
+  }
+  if constexpr (LATE_RHS) {
+#pragma unroll
+    for (int ba = 0; ba < NBN; ++ba) {
+      const int i = ba * 16 + c;
+      const float r = a.vals[u.beg + (i < n ? i : n - 1)];
+      bacc[ba] = (i < n && g == 0) ? r : 0.0f;
+    }
   }
   const float lam = (float)(a.lambda * (double)n);
   float wcol[NBN];

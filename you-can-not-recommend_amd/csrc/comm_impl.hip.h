@@ -239,27 +239,59 @@ int comm_setup(Comm &c, const void *id, int transport, int rank, int world, size
 struct IpcSlot {
   hipIpcMemHandle_t handle[2];
   uint64_t offset[2];
-  int32_t device, pad;
+  int32_t device;
+  int32_t status;  // 1: handles valid; -1: this rank failed before or while making them (every rank then returns an error)
 };
-int ipc_publish(Comm &c, void *const fac[2]) {
+// localFailed: the caller's own preparation of this collective call failed (e.g. the upload in front of the
+// publication): the rank still takes part in both barriers and reports through its slot, so that its peers return an
+// error at once instead of waiting 120 s at a barrier it never reaches, and the barrier counts stay in step.
+int ipc_publish(Comm &c, void *const fac[2], bool localFailed = false) {
   if ((size_t)c.world * sizeof(IpcSlot) > c.dataBytes) return fail(YCNR_ERR_STATE, "ipc: control segment too small for %d ranks", c.world);
-  if (c.stream) HIP_TRY(hipStreamSynchronize(c.stream));
-  ipc_close_peers(c);
   IpcSlot mine;
   memset(&mine, 0, sizeof mine);
-  HIP_TRY(hipGetDevice(&mine.device));
-  for (int s = 0; s < 2; ++s) {
+  mine.status = localFailed ? -1 : 1;
+  std::string why;
+  auto local_fail = [&](const char *what, hipError_t e) {
+    if (mine.status > 0) why = std::string(what) + ": " + hipGetErrorString(e);
+    mine.status = -1;
+    (void)hipGetLastError();
+  };
+  if (mine.status > 0 && c.stream) {
+    hipError_t e = hipStreamSynchronize(c.stream);
+    if (e != hipSuccess) local_fail("hipStreamSynchronize", e);
+  }
+  ipc_close_peers(c);
+  if (mine.status > 0) {
+    hipError_t e = hipGetDevice(&mine.device);
+    if (e != hipSuccess) local_fail("hipGetDevice", e);
+  }
+  for (int s = 0; s < 2 && mine.status > 0; ++s) {
     hipDeviceptr_t base = nullptr;
     size_t size = 0;
-    HIP_TRY(hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)fac[s]));
-    HIP_TRY(hipIpcGetMemHandle(&mine.handle[s], (void *)base));
+    hipError_t e = hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)fac[s]);
+    if (e != hipSuccess) {
+      local_fail("hipMemGetAddressRange (is the matrix device memory of an ordinary allocation?)", e);
+      break;
+    }
+    e = hipIpcGetMemHandle(&mine.handle[s], (void *)base);
+    if (e != hipSuccess) {
+      local_fail("hipIpcGetMemHandle", e);
+      break;
+    }
     mine.offset[s] = (uint64_t)((const char *)fac[s] - (const char *)base);
   }
   IpcSlot *slots = (IpcSlot *)c.data;
   memcpy(&slots[c.rank], &mine, sizeof mine);
   int rc = shm_barrier(c);
   if (rc) return rc;
+  int failedRank = -1;
   for (int p = 0; p < c.world; ++p) {
+    IpcSlot theirs;
+    memcpy(&theirs, &slots[p], sizeof theirs);
+    if (theirs.status <= 0 && failedRank < 0) failedRank = p;
+  }
+  std::string openErr;
+  for (int p = 0; p < c.world && failedRank < 0 && openErr.empty(); ++p) {
     if (p == c.rank) continue;
     IpcSlot theirs;
     memcpy(&theirs, &slots[p], sizeof theirs);
@@ -273,15 +305,23 @@ int ipc_publish(Comm &c, void *const fac[2]) {
       hipError_t e = hipIpcOpenMemHandle(&base, theirs.handle[s], hipIpcMemLazyEnablePeerAccess);
       if (e != hipSuccess) {
         (void)hipGetLastError();
-        (void)shm_barrier(c);  // keep the ranks in step: everybody leaves through the second barrier
-        return fail(YCNR_ERR_HIP, "ipc: hipIpcOpenMemHandle of rank %d's matrix %d failed: %s", p, s, hipGetErrorString(e));
+        char buf[200];
+        snprintf(buf, sizeof buf, "hipIpcOpenMemHandle of rank %d's matrix %d failed: %s", p, s, hipGetErrorString(e));
+        openErr = buf;
+        break;
       }
       c.peers[(size_t)p].base[s] = base;
       c.peers[(size_t)p].fac[s] = (char *)base + theirs.offset[s];
     }
   }
-  rc = shm_barrier(c);  // the slots may be overwritten again
+  rc = shm_barrier(c);  // the slots may be overwritten again; everybody leaves through this barrier, failed or not
   if (rc) return rc;
+  if (failedRank >= 0 || !openErr.empty()) {
+    ipc_close_peers(c);
+    if (failedRank == c.rank && !why.empty()) return fail(YCNR_ERR_HIP, "ipc: %s", why.c_str());
+    if (failedRank >= 0) return fail(YCNR_ERR_STATE, "ipc: rank %d could not publish its matrices (this call failed on that rank)", failedRank);
+    return fail(YCNR_ERR_HIP, "ipc: %s", openErr.c_str());
+  }
   c.mapped[0] = fac[0];
   c.mapped[1] = fac[1];
   return YCNR_OK;

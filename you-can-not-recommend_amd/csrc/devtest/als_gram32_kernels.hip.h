@@ -19,7 +19,7 @@
 // The accumulators leave in the 16 x 16 image layout of als_wg_kernels.hip.h (four sub-tiles per 32 x 32 tile), so the
 // slab, the reduce and the solve kernels do not change.
 #pragma once
-#include "als_pair_kernels.hip.h"
+#include "../als_pair_kernels.hip.h"
 
 namespace ycnr {
 

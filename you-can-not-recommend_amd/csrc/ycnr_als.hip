@@ -7,7 +7,10 @@
 #include "../../include/ycnr_als.h"
 #include "als_kernels.hip.h"
 #include "als_wg_kernels.hip.h"
-#include "als_gram32_kernels.hip.h"
+#include "als_pair_kernels.hip.h"
+#ifdef YCNR_WITH_G32  // devtest build only (make EXTRA=-DYCNR_WITH_G32): the 32 x 32 Gramian kernel of round 3, measured equal
+#include "devtest/als_gram32_kernels.hip.h"
+#endif
 #include "als_gen_kernels.hip.h"
 #include "prep_kernels.hip.h"
 #include <hipcub/hipcub.hpp>
@@ -19,6 +22,7 @@
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <new>
@@ -64,6 +68,9 @@ constexpr int kWgChunk = 8192;       // ratings per chunk of a row that is split
 constexpr int kWgFusedMax = 16384;   // longest row one workgroup takes whole (k > 128)
 constexpr int kDefaultChunk = 1024;  // ratings per split unit (and the largest fused row)
 constexpr int kMaxSlabsPerRow = 64;  // heavier rows get proportionally longer chunks
+constexpr int kMaxSlabsPerRowBig = 4096;  // k > 128 (chunks of kWgChunk ratings): an item of the full C5 has 10 M ratings; with 64 slabs its
+                                          // chunks were float32 sums over 156 K ratings each (backward error 0.86 of its gate in round 3);
+                                          // 8192-rating chunks keep every accumulation chain short, the workgroup reduce adds the slabs in order
 constexpr int64_t kBandBytes = (int64_t)96 << 20;  // slice of the fixed matrix one band of chunks gathers from (cache-sized)
 constexpr size_t kErrBytes = 65536;
 constexpr size_t kZeroRowBytes = 32768 + 64;  // >= kMaxFactorsAny doubles: the "row" the dual kernels gather for ratings past a row's end
@@ -162,7 +169,7 @@ int auto_chunk(int64_t nnz) {
 // rowPtr: local (length nRows + 1, any base).  Units index ratings relative to rowPtr[0].
 void build_schedule(const int64_t *rowPtr, int64_t rowBegin, int64_t nRows, int chunk,
                     std::vector<Unit> &units, std::vector<SplitRow> &split, int64_t &nSlabs,
-                    int64_t &solvedRows, int64_t splitAbove = -1, int fusedMax = 0) {
+                    int64_t &solvedRows, int64_t splitAbove = -1, int fusedMax = 0, int maxSlabs = kMaxSlabsPerRow) {
   // fusedMax: longest row that stays one unit (default: chunk)
   if (fusedMax <= 0) fusedMax = chunk;
   // splitAbove >= 0 (big path): every row longer than splitAbove goes through slabs, in row
@@ -185,7 +192,7 @@ void build_schedule(const int64_t *rowPtr, int64_t rowBegin, int64_t nRows, int 
       continue;
     }
     int64_t ch = chunk;
-    if ((n + ch - 1) / ch > kMaxSlabsPerRow) ch = (n + kMaxSlabsPerRow - 1) / kMaxSlabsPerRow;
+    if ((n + ch - 1) / ch > maxSlabs) ch = (n + maxSlabs - 1) / maxSlabs;
     ch = (ch + 3) & ~(int64_t)3;
     const int64_t parts = (n + ch - 1) / ch;
     split.push_back(SplitRow{n, row, (int32_t)nSlabs, (int32_t)parts, 0});
@@ -232,7 +239,17 @@ int set_max_lds(const void *fn, size_t bytes) {
   return YCNR_OK;
 }
 
-constexpr int kSideStreams = 2;
+constexpr int kSideStreams = 6;  // most side streams a handle can have; side_streams() of them are in use
+// Side streams in use (YCNR_SIDE_STREAMS, read once; experiments).  The runtime maps a process's streams onto
+// GPU_MAX_HW_QUEUES hardware queues (4 unless that variable says otherwise, read when the runtime starts): kernels on two
+// streams that share a hardware queue run one after the other.
+int side_streams() {
+  static const int n = [] {
+    const char *e = getenv("YCNR_SIDE_STREAMS");
+    return e ? std::max(1, std::min(kSideStreams, atoi(e))) : 2;
+  }();
+  return n;
+}
 constexpr int64_t kGraphMaxRatings = 2 * 1024 * 1024;  // uploads below this replay their half-step as a captured hipGraph ...
 constexpr int64_t kGraphMinRatings = 256 * 1024;       // ... unless they are so small that the graph launch itself costs more than four
                                                         // kernel launches (ML-100k shape: 0.124 ms per iteration launch by launch, 0.174 as graphs)
@@ -276,7 +293,9 @@ int launch_dual(StepArgs<float> args, const DualPlan &dp, hipStream_t stream) {
     const bool x6 = !dp.noX6 && !env_flags().noDualX6;
     void (*kd)(StepArgs<float>) = als_dual_solve_kernel<M, false>;
     if (x6) kd = als_dual_solve_kernel<M, true>;
-    hipLaunchKernelGGL(kd, dim3((unsigned)dp.count[M]), dim3(64), SolveMfmaF32<M>::lds_bytes(), stream, args);
+    // (YCNR_DUAL_LDSPAD: occupancy experiments -- extra dynamic LDS per workgroup limits the workgroups a CU holds)
+    static const size_t ldsPad = getenv("YCNR_DUAL_LDSPAD") ? (size_t)atoi(getenv("YCNR_DUAL_LDSPAD")) : 0;
+    hipLaunchKernelGGL(kd, dim3((unsigned)dp.count[M]), dim3(64), SolveMfmaF32<M>::lds_bytes() + ldsPad, stream, args);
     HIP_TRY(hipGetLastError());
   }
   return YCNR_OK;
@@ -484,16 +503,20 @@ int launch_wg_nb(StepArgs<float> args, int64_t nSplitUnits, int64_t nPrimal, int
   }
   // NB = 16, YCNR_G32=1: the Gramians on 32 x 32 MFMAs, one wave per SIMD (als_gram32_kernels.hip.h) -- measured equal to
   // WgGram on one GPU's eighth of C5 (both are bound by the power the bf16 pipe + the split draw), so off
+#ifdef YCNR_WITH_G32
   const bool g32 = NB == kPairNB && env_flags().g32;
   if (g32) {
     if (int rc = set_max_lds(reinterpret_cast<const void *>(als_g32_slab_kernel), (size_t)G32Cfg::LDS_BYTES)) return rc;
     if (int rc = set_max_lds(reinterpret_cast<const void *>(als_g32_rowslab_kernel), (size_t)G32Cfg::LDS_BYTES)) return rc;
   }
+#endif
   if (nSplitUnits > 0) {
+#ifdef YCNR_WITH_G32
     if (g32)
       hipLaunchKernelGGL(als_g32_slab_kernel, dim3((unsigned)std::min(nSplitUnits, cus)), dim3(kG32Threads), (size_t)G32Cfg::LDS_BYTES, stream, args,
                          (int32_t)nSplitUnits);
     else
+#endif
       hipLaunchKernelGGL(k0, dim3((unsigned)std::min(nSplitUnits, cus)), dim3(kWgThreads), lds, stream, args, (int32_t)nSplitUnits);
     HIP_TRY(hipGetLastError());
   }
@@ -510,10 +533,12 @@ int launch_wg_nb(StepArgs<float> args, int64_t nSplitUnits, int64_t nPrimal, int
       for (int64_t b0 = 0; b0 < nPrimal; b0 += rowSlabRows) {
         const int64_t cnt = std::min(rowSlabRows, nPrimal - b0);
         const int32_t first = (int32_t)(nSplitUnits + b0);
+#ifdef YCNR_WITH_G32
         if (g32)
           hipLaunchKernelGGL(als_g32_rowslab_kernel, dim3((unsigned)std::min(cnt, cus)), dim3(kG32Threads), (size_t)G32Cfg::LDS_BYTES, stream, args,
                              rowSlabs, first, (int32_t)cnt);
         else
+#endif
           hipLaunchKernelGGL(kg, dim3((unsigned)std::min(cnt, cus)), dim3(kWgThreads), lds, stream, args, rowSlabs, first, (int32_t)cnt);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(ks, dim3((unsigned)cnt), dim3(kPairThreads), (size_t)PairCfg<NB>::LDS_BYTES, stream, args, (const float *)rowSlabs, first);
@@ -1028,9 +1053,12 @@ int bits_for(int64_t n) {
   while (b < 32 && ((int64_t)1 << b) < n) ++b;
   return b;
 }
-// keys / pos prepared on the device; sorts, unpacks into host arrays
+// makeKeys launches the kernel that writes keys / pos on the device; then sorts and unpacks into host arrays.  Every
+// buffer is allocated BEFORE the first timing event: the events bracket kernels only.  (Round 3 allocated six buffers
+// between the two events; the host time of those hipMalloc calls -- 10 ... 110 ms depending on the box -- was reported as
+// device time of the sort.)
 int sort_and_unpack(int dtype, int64_t n, int64_t outRows, int64_t outCols, uint64_t *dKeys, uint32_t *dPos, const void *dVals,
-                    int64_t *rowPtr, int32_t *indx, void *outVals, hipEvent_t e0, hipEvent_t e1, double *deviceMs) {
+                    int64_t *rowPtr, int32_t *indx, void *outVals, const std::function<void()> &makeKeys, double *deviceMs) {
   const size_t ts = tsize(dtype);
   DevBuf dKeys2, dPos2, dTmp, dIndx, dOutVals, dPtr;
   HIP_TRY(hipMalloc(&dKeys2.p, (size_t)n * 8));
@@ -1042,6 +1070,12 @@ int sort_and_unpack(int dtype, int64_t n, int64_t outRows, int64_t outCols, uint
   const int colBits = bits_for(outCols), endBit = colBits + bits_for(outRows);
   HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmpBytes, dKeys, (uint64_t *)dKeys2.p, dPos, (uint32_t *)dPos2.p, (int)n, 0, endBit));
   HIP_TRY(hipMalloc(&dTmp.p, std::max<size_t>(tmpBytes, 8)));
+  EvPair evp;
+  HIP_TRY(evp.create());
+  const hipEvent_t e0 = evp.a, e1 = evp.b;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipEventRecord(e0, nullptr));
+  makeKeys();
   HIP_TRY(hipcub::DeviceRadixSort::SortPairs(dTmp.p, tmpBytes, dKeys, (uint64_t *)dKeys2.p, dPos, (uint32_t *)dPos2.p, (int)n, 0, endBit));
   const unsigned b256 = (unsigned)((n + 255) / 256);
   if (dtype == YCNR_F32)
@@ -1088,14 +1122,11 @@ int ycnr_csr_from_triplets(int dtype, int64_t n, const int32_t *rowIdx, const in
   HIP_TRY(hipMemcpy(dR.p, rowIdx, (size_t)n * 4, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(dC.p, colIdx, (size_t)n * 4, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(dV.p, vals, (size_t)n * ts, hipMemcpyHostToDevice));
-  EvPair evp;
-  HIP_TRY(evp.create());
-  const hipEvent_t e0 = evp.a, e1 = evp.b;
-  HIP_TRY(hipEventRecord(e0, nullptr));
-  hipLaunchKernelGGL(make_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, (const int32_t *)dR.p, (const int32_t *)dC.p, n,
-                     bits_for(cols), (uint64_t *)dKeys.p, (uint32_t *)dPos.p);
-  int rc = sort_and_unpack(dtype, n, rows, cols, (uint64_t *)dKeys.p, (uint32_t *)dPos.p, dV.p, rowPtr, indx, outVals, e0, e1, deviceMs);
-  return rc;
+  auto makeKeys = [&] {
+    hipLaunchKernelGGL(make_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, (const int32_t *)dR.p, (const int32_t *)dC.p, n,
+                       bits_for(cols), (uint64_t *)dKeys.p, (uint32_t *)dPos.p);
+  };
+  return sort_and_unpack(dtype, n, rows, cols, (uint64_t *)dKeys.p, (uint32_t *)dPos.p, dV.p, rowPtr, indx, outVals, makeKeys, deviceMs);
 }
 
 int ycnr_csr_transpose(int dtype, int64_t rows, int64_t cols, const int64_t *rowPtr, const int32_t *indx, const void *vals,
@@ -1278,7 +1309,7 @@ int ycnr_als_create(const ycnr_als_options *o, ycnr_als **out) {
   hipError_t e = hipStreamCreateWithFlags(&h->ownStream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreate(&h->evComputeEnd);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->evStepStart, hipEventDisableTiming);
-  for (int i = 0; i < kSideStreams && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&h->sideStream[i], hipStreamNonBlocking);
+  for (int i = 0; i < side_streams() && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&h->sideStream[i], hipStreamNonBlocking);
   for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&h->pieceStream[i], hipStreamNonBlocking);
   for (int s = 0; s < 2 && e == hipSuccess; ++s) {
     e = hipMalloc(&h->factors[s], (size_t)h->rows(s) * o->factorsCount * h->ts());
@@ -1400,7 +1431,7 @@ static int upload_ratings(ycnr_als *h, Ratings &R, int64_t totalRows, int64_t op
 // Upload + schedule of one piece [rowBegin, rowEnd) of a side's rows into newR / S (both released
 // by the caller when this fails).
 static int build_part(ycnr_als *h, int side, const int64_t *rowPtr, const int32_t *indx, const void *vals, int64_t rowBegin,
-                      int64_t rowEnd, int memKind, Ratings &newR, Schedule &S) {
+                      int64_t rowEnd, int memKind, Ratings &newR, Schedule &S, int64_t sideNnz) {
   std::vector<int64_t> hp;
   int rc = upload_ratings(h, newR, h->rows(side), h->rows(1 - side), rowPtr, indx, vals, rowBegin,
                           rowEnd, memKind, hp, side == YCNR_BY_USER ? "set_ratings(byUser)" : "set_ratings(byItem)");
@@ -1412,12 +1443,15 @@ static int build_part(ycnr_als *h, int side, const int64_t *rowPtr, const int32_
   const bool big = !gen && h->opt.factorsCount > kMaxFactors;
   // k > 128: a unit is a whole workgroup's work, so chunks are long (a slab is 140 KB at k = 256)
   // (an explicit options.chunkRatings is honoured there too: tests cut short rows into chunks with it)
-  const int chunkRatings = h->autoChunk ? (gen ? kGenChunk : big ? kWgChunk : auto_chunk(hp[rowEnd - rowBegin] - hp[0])) : h->opt.chunkRatings;
+  // The automatic chunk length follows the ratings of the WHOLE side, not of this piece: where a split row is cut decides
+  // the order its partial sums are added in, so a length that depended on the piece would make the factors depend on how
+  // the rows are cut into shards and pieces (and a feedback re-cut would change them: round-3 review).
+  const int chunkRatings = h->autoChunk ? (gen ? kGenChunk : big ? kWgChunk : auto_chunk(sideNnz)) : h->opt.chunkRatings;
   if (gen)
     build_schedule(hp.data(), rowBegin, rowEnd - rowBegin, chunkRatings, units, split, nSlabs, solved, dual_max_ratings(h->opt), 0);
   else
     build_schedule(hp.data(), rowBegin, rowEnd - rowBegin, chunkRatings, units, split, nSlabs, solved, -1,
-                   big && h->autoChunk ? kWgFusedMax : std::min(chunkRatings, h->opt.chunkRatings));
+                   big && h->autoChunk ? kWgFusedMax : std::min(chunkRatings, h->opt.chunkRatings), big ? kMaxSlabsPerRowBig : kMaxSlabsPerRow);
   int64_t arenaSlabs = nSlabs;
   // Band-major chunks (unless YCNR_FLAG_NO_BANDS): when the fixed matrix is far larger than the
   // last-level cache, cut every split row at the same column-id boundaries ("bands" of
@@ -1570,11 +1604,22 @@ static int set_ratings_parts(ycnr_als *h, int side, const int64_t *rowPtr, const
     }
   } pend;
   pend.parts.resize((size_t)nParts);
+  // ratings of the whole side (rowPtr describes every row of it, whatever shard this handle solves)
+  int64_t ends[2] = {0, 0};
+  if (!rowPtr) return fail(YCNR_ERR_INVALID, "set_ratings: null rowPtr");
+  if (memKind == YCNR_MEM_DEVICE) {
+    HIP_TRY(hipMemcpy(&ends[0], rowPtr, sizeof(int64_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&ends[1], rowPtr + h->rows(side), sizeof(int64_t), hipMemcpyDeviceToHost));
+  } else {
+    ends[0] = rowPtr[0];
+    ends[1] = rowPtr[h->rows(side)];
+  }
+  const int64_t sideNnz = std::max<int64_t>(0, ends[1] - ends[0]);
   for (int i = 0; i < nParts; ++i) {
     Part &p = pend.parts[(size_t)i];
     hipError_t e = p.create_events();
     if (e != hipSuccess) return fail(YCNR_ERR_HIP, "set_ratings: hipEventCreate: %s", hipGetErrorString(e));
-    int rc = build_part(h, side, rowPtr, indx, vals, b[i], b[i + 1], memKind, p.R, p.S);
+    int rc = build_part(h, side, rowPtr, indx, vals, b[i], b[i + 1], memKind, p.R, p.S, sideNnz);
     if (rc) return rc;
   }
   HIP_TRY(hipStreamSynchronize(h->stream));  // nothing in flight still reads the previous upload
@@ -1619,13 +1664,20 @@ int ycnr_als_set_ratings_sharded(ycnr_als *h, int side, const int64_t *rowPtr, c
     if (bounds[(size_t)r * (nChunks + 1) + nChunks] != bounds[(size_t)(r + 1) * (nChunks + 1)])
       return fail(YCNR_ERR_INVALID, "set_ratings_sharded: the shards of ranks %d and %d do not meet", r, r + 1);
   int rc = set_ratings_parts(h, side, rowPtr, indx, vals, memKind, nChunks, bounds + (size_t)rank * (nChunks + 1));
-  if (rc) return rc;
-  h->bounds[side].assign(bounds, bounds + n);
+  if (!rc) h->bounds[side].assign(bounds, bounds + n);
   // IPC: the peers map this rank's matrices; a matrix bound (ycnr_als_bind_factors) since the communicator was made is
-  // published here -- this call is collective, every rank passes through
+  // published here -- this call is collective, every rank passes through, also one whose upload has just failed
+  // (it says so in its slot: the peers return an error instead of waiting for it at the barrier)
   if (h->comm.transport == YCNR_COMM_IPC && h->comm.world > 1) {
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    rc = ipc_publish(h->comm, h->factors);
+    const std::string uploadError = g_last_error;
+    bool failed = rc != YCNR_OK;
+    if (!failed && hipStreamSynchronize(h->stream) != hipSuccess) {
+      (void)hipGetLastError();
+      failed = true;
+    }
+    const int rcp = ipc_publish(h->comm, h->factors, failed);
+    if (rc) g_last_error = uploadError;  // this rank's own failure is the message to keep
+    else rc = rcp;
   }
   return rc;
 }
@@ -1724,8 +1776,8 @@ static int launch_part(ycnr_als *h, int side, Part &part, hipStream_t stream, bo
       // (the fork and join cost nine more runtime calls per half-step: with a few hundred rows,
       // where the half-step is bound by the launches themselves, they made it slower)
       if ((S.dualRows >= kMinOverlapDualRows || (branches && S.dualRows > 0)) && !(h->opt.flags & YCNR_FLAG_NO_OVERLAP) && !env_flags().noOverlap) {
-        dp.nSide = kSideStreams;
-        for (int i = 0; i < kSideStreams; ++i) {
+        dp.nSide = side_streams();
+        for (int i = 0; i < dp.nSide; ++i) {
           dp.side[i] = h->sideStream[i];
           dp.join[i] = part.join[i];
         }
@@ -1805,8 +1857,18 @@ int ycnr_als_step_async(ycnr_als *h, int side) {
     return fail(YCNR_ERR_STATE, "step: the sharded upload of this side was made for another communicator (bounds of %zu values, world %d x %zu pieces)",
                 h->bounds[side].size(), h->comm.world, parts.size());
   h->exchangedInStep = exchange;
-  if (exchange)
+  if (exchange) {
+    // IPC, a half-step enqueued behind one that has not been completed by ycnr_als_sync (back-to-back
+    // ycnr_als_step_async calls): the peers' pushes of THAT half-step land in this rank's replica at the peers' pace, and
+    // this half-step reads that matrix as its fixed side -- so the pending half-step is completed here first (this rank's
+    // stream drained, then the end-of-step barrier: every rank's pushes have landed everywhere).  Receiver-posted
+    // transports (RCCL, SHM) order this on the stream.  Collective like the call itself: every rank sees the same flag.
+    if (h->comm.transport == YCNR_COMM_IPC && h->comm.pendingFinish) {
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      if (int rcf = ipc_finish(h->comm)) return rcf;
+    }
     if (int rcb = ipc_enter(h->comm)) return rcb;  // push transport: no peer is still preparing its replica
+  }
   memset(&h->info, 0, sizeof h->info);
   // Small uploads (the ML-100k / ML-1M shapes): ~15 launches, forks and joins of a half-step whose kernels each fill a
   // fraction of the chip.  Captured once in the branch form (launch_part) and replayed: one launch per half-step.
@@ -2364,7 +2426,18 @@ int64_t als_calc_portion(double lambda, int k, const int32_t *alsRows, const int
   const size_t ioBytes = al(oFixed + (pinned ? 0 : sizeof(T) * uniq.size() * (size_t)k));
   L1_TRY(C.io.reserve(ioBytes));
   L1_TRY(C.reserve_host(ioBytes));
-  L1_TRY(C.slabs.reserve(sizeof(T) * std::max<size_t>(1, (size_t)nSlabs * slabElems)));
+  // any-k path: rows are solved in batches whose images fit the arena, as in the resident trainer (build_part) -- one
+  // image is 541 KB at k = 512 and several MB beyond 1024 factors, a portion of 10 K short rows would ask for gigabytes
+  std::vector<GenBatch> genBatches;
+  int64_t arenaSlabs = nSlabs;
+  if (gen) {
+    int64_t arenaBytes = kGenArenaBytes;
+    if (const char *e = getenv("YCNR_GEN_ARENA_MB")) arenaBytes = (int64_t)std::max(1, atoi(e)) << 20;  // tests force several batches
+    genBatches = gen_batches(split, std::max<int64_t>(1, arenaBytes / (int64_t)(slabElems * sizeof(T))));
+    arenaSlabs = 0;
+    for (const GenBatch &b : genBatches) arenaSlabs = std::max<int64_t>(arenaSlabs, b.nSlabs);
+  }
+  L1_TRY(C.slabs.reserve(sizeof(T) * std::max<size_t>(1, (size_t)arenaSlabs * slabElems)));
   char *hb = (char *)C.hostIo, *db = (char *)C.io.p;
   memset(hb + oErr, 0, sizeof(ErrInfo));
   if (!units.empty()) memcpy(hb + oUnits, units.data(), sizeof(Unit) * units.size());
@@ -2392,7 +2465,7 @@ int64_t als_calc_portion(double lambda, int k, const int32_t *alsRows, const int
     StepArgs<T> a{(const Unit *)(db + oUnits), (const SplitRow *)(db + oSplit), (const int32_t *)(db + oIndx), (const T *)(db + oVals), dFixed, dZeros,
                   (T *)(db + oSolved), (T *)C.slabs.p, dErr, lambda, k, 0, 0, 0u};
     if (gen) {
-      rc = launch_step_gen<T>(a, gen_batches(split, std::max<int64_t>(1, nSlabs)), stream, nullptr, DualPlan());
+      rc = launch_step_gen<T>(a, genBatches, stream, nullptr, DualPlan());
     } else if constexpr (std::is_same<T, float>::value) {
       if (big) rc = launch_step_big(a, (int64_t)units.size(), nSlabs, (int64_t)split.size(), stream, nullptr, DualPlan());
       else rc = launch_step<T>(a, (int64_t)units.size(), nSlabs, (int64_t)split.size(), stream, nullptr);

@@ -70,7 +70,7 @@ class EmfBase extends EventEmitter {
       commId: null,
       commTransport: 'rccl', // 'rccl' | 'ipc' (mapped peer replicas + copy engines; also several ranks on one GPU) | 'shm' (host-staged stand-in)
       exchangeChunks: 4,
-      rebalanceAfterIters: 1,   // multi-GPU: cut the row shards again from the measured compute times after this many iterations (0 = never)
+      rebalanceAfterIters: 2,   // multi-GPU: cut the row shards again from the measured compute times after each of the first N iterations (0 = never)
       gpuDevices: 0,            // devices the per-GPU processes are spread over (0 = what the library reports)
       gpuProcessScript: null,   // entry point of a per-GPU process (default lib/emf/EmfGpuProcess.js)
       gpuProcessTimeoutMs: 0,   // trainOnGpus gives up after this long (0 = no limit)

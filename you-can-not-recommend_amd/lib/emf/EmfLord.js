@@ -234,7 +234,7 @@ class EmfLord extends EmfMaster {
       .then(() => this.alsTrainStep('byItem'))
       .then(() => {
         // feedback for the static shards (options.rebalanceAfterIters, EmfMaster.rebalance)
-        if (this.options.world > 1 && ++this.itersRun == this.options.rebalanceAfterIters) this.rebalance();
+        if (this.options.world > 1 && ++this.itersRun <= this.options.rebalanceAfterIters) this.rebalance();
       });
   }
 

@@ -38,9 +38,27 @@ class EmfMaster extends EmfManager {
   static rowCost(n, k, double) {
     if (n <= 0) return 0;
     const nb = Math.ceil(k / 16);
+    const tiles = nb * (nb + 1) / 2.0;
     const dualMax = (double || k % 4) ? 0 : 16 * Math.min(k > 128 ? 12 : 5, nb - 1);
     if (n <= dualMax) return 2700.0 * Math.pow(Math.ceil(n / 16), 1.36) * (k / 100);
-    return n * (1.2 * k) + 0.0165 * k * k * k;
+    const edge4 = !double && k <= 128 && nb >= 2 && k % 16 == 4;
+    const nbs = edge4 ? nb - 1 : nb;
+    const mfmas = 4.0 * (nbs * (nbs - 1) / 2.0 + (nbs - 1) * nbs * (nbs + 1) / 6.0) + (edge4 ? nbs * (nbs + 1) / 2.0 : 0.0);
+    let perRating, perRow;
+    if (double) {
+      perRating = k > 128 ? 40.0 * tiles : 16.0 * tiles;
+      perRow = k <= 128 ? 2.0 * (1500.0 * nbs + 35.0 * mfmas) : 0.1 * k * k * k;
+    } else if (k <= 128) {
+      perRating = 4.9 * (tiles - (edge4 ? nb / 2.0 : 0.0));
+      perRow = 1500.0 * nbs + 35.0 * mfmas;
+    } else if (k <= 256) {
+      perRating = 5.4 * tiles;
+      perRow = 0.0153 * k * k * k;
+    } else {
+      perRating = 40.0 * tiles;
+      perRow = 0.1 * k * k * k;
+    }
+    return n * perRating + perRow;
   }
 
   /**

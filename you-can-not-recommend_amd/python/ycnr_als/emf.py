@@ -53,7 +53,7 @@ def default_options():
         # are cut again from the compute time every rank measured (0 = never); the static cut comes from a cost
         # model (row_cost), this is the feedback that corrects it -- the role of the reference's work-stealing
         # portion dispenser (EmfLord.m_incrNextPortion, lib/emf/EmfLord.js:996-1006)
-        "rebalanceAfterIters": 1,
+        "rebalanceAfterIters": 2,  # a re-cut after each of the first N iterations
     }
 
 
@@ -114,17 +114,39 @@ def split_to_portions(cnt_per_row, rows_cnt, ratings_in_portion, num_threads, pc
 
 def row_cost(counts, k, double=False):
     """Modelled cost (SIMD-cycles) of re-solving one row with `counts` ratings in a half-step, used
-    to cut shards that finish together.  A rating costs the Gramian update of a k x k matrix, a row
-    costs its solve whatever its length, and rows with fewer ratings than factors take the cheaper
-    dual (n x n) form; constants from the per-kernel times of the MAL-scale run at k = 100
-    (120 cycles per rating and 16.5 K per solve in the row kernel; 2.7 K ... 24 K per row
-    for the dual classes of 16 ... 80 ratings).  Balancing ratings alone (what the reference's
-    splitToPortions does, lib/emf/EmfLord.js:571-592) gives the shard with many short rows more
-    work per rating."""
+    to cut shards that finish together.  Balancing ratings alone (what the reference's splitToPortions
+    does, lib/emf/EmfLord.js:571-592) gives the shard with many short rows more work per rating.
+
+    The model follows what the kernels execute, with constants from measured kernel times:
+      * a rating costs the update of the T = nb (nb + 1) / 2 upper 16 x 16 tiles of the Gramian (nb = ceil(k / 16)):
+        4.9 cycles per tile on the one-wave bf16x6 kernels of k <= 128 (MAL scale, k = 100: 120 cycles per rating
+        with the packed last block of k = 16 m + 4, which saves half a tile column), 5.4 on the workgroup kernels
+        of 128 < k <= 256 (2.95 us of a CU per 32 ratings at k = 256);
+      * a row in primal form costs its solve whatever its length: 1500 cycles per diagonal tile (the pivot chains)
+        + 35 per float32 MFMA of panel and trailing update up to k = 128 (16.5 K at k = 100, where the four edge
+        columns are eliminated first), 0.0153 k^3 on the four-wave solve beyond (32 us of a CU at k = 256);
+      * rows with fewer ratings than factors take the dual (n x n) form: 2700 m^1.36 k / 100 for m = ceil(n / 16)
+        blocks (2.7 K ... 24 K for the classes of 16 ... 80 ratings at k = 100; 132 K measured for 176 ratings at k = 256);
+      * float64 and the any-k path (no dual classes): coarse multiples of the above.
+    The feedback re-cut (rebalanced_ranges) corrects what the model gets wrong on a given box."""
     n = np.asarray(counts, np.float64)
     nb = (k + 15) // 16
+    tiles = nb * (nb + 1) / 2.0
     dual_max = 0 if (double or k % 4) else 16 * min(12 if k > 128 else 5, nb - 1)
-    primal = n * (1.2 * k) + 0.0165 * float(k) ** 3
+    edge4 = (not double) and k <= 128 and nb >= 2 and k % 16 == 4
+    nbs = nb - 1 if edge4 else nb
+    mfmas = 4.0 * (nbs * (nbs - 1) / 2.0 + (nbs - 1) * nbs * (nbs + 1) / 6.0) + (nbs * (nbs + 1) / 2.0 if edge4 else 0.0)
+    if double:
+        per_rating, per_row = 16.0 * tiles, 2.0 * (1500.0 * nbs + 35.0 * mfmas) if k <= 128 else 0.1 * float(k) ** 3
+        if k > 128:
+            per_rating = 40.0 * tiles
+    elif k <= 128:
+        per_rating, per_row = 4.9 * (tiles - (nb / 2.0 if edge4 else 0.0)), 1500.0 * nbs + 35.0 * mfmas
+    elif k <= 256:
+        per_rating, per_row = 5.4 * tiles, 0.0153 * float(k) ** 3
+    else:
+        per_rating, per_row = 40.0 * tiles, 0.1 * float(k) ** 3
+    primal = n * per_rating + per_row
     dual = 2700.0 * np.ceil(n / 16.0) ** 1.36 * (k / 100.0)
     c = np.where(n <= dual_max, dual, primal)
     return np.where(n > 0, c, 0.0)
@@ -153,8 +175,10 @@ def rebalanced_ranges(counts, bounds, ms_by_rank, k=None, double=False):
     EmfChief._incrNextPortion, lib/emf/EmfChief.js:308-318), so a slow node simply takes fewer.  Shards here are
     static within a half-step, so the feedback acts between iterations: the modelled cost of the rows of shard r
     is scaled by (measured ms of r) / (modelled cost of r) and the ranges are cut again at equal scaled cost --
-    a shard that ran long gives rows away.  Results do not depend on the cuts (every row is solved by one wave
-    / workgroup or a fixed slab order)."""
+    a shard that ran long gives rows away.  Results do not depend on the cuts: every row is solved by one wave /
+    workgroup, or summed over chunks whose boundaries follow the row and the ratings of the whole side, not the
+    shard (libycnr_als derives the chunk length from the side's total; tests/test_gpu_comm.py re-cuts at a size where
+    a per-shard length would differ)."""
     counts = np.asarray(counts, np.int64)
     bounds = np.asarray(bounds, np.int64)
     world = len(bounds) - 1
@@ -362,9 +386,12 @@ class EmfLord:
             flags = [None] * self.world
             self._dist.all_gather_object(flags, (ok, why))
             if not all(f[0] for f in flags):
+                why = "; ".join("rank %d: %s" % (r, f[1]) for r, f in enumerate(flags) if not f[0])
+                if self.options.get("strictTransport", False):
+                    # a measurement must not silently run over another path than the one it names (bench.py)
+                    raise RuntimeError("exchange transport '%s' unavailable (%s)" % (transport, why))
                 import warnings
-                warnings.warn("native exchange unavailable (%s); using torch.distributed all-gather"
-                              % "; ".join(f[1] for f in flags if not f[0]))
+                warnings.warn("native exchange unavailable (%s); using torch.distributed all-gather" % why)
                 self.native_exchange = False
         self.exchangePath = ("libycnr_als:" + self.options.get("commTransport", "rccl")) if self.native_exchange else \
             ("torch.distributed" if self.world > 1 else "none")
@@ -531,7 +558,9 @@ class EmfLord:
         self.alsTrainStep("byUser")
         self.alsTrainStep("byItem")
         self._itersRun = getattr(self, "_itersRun", 0) + 1
-        if self.world > 1 and self._itersRun == int(self.options.get("rebalanceAfterIters", 0) or 0):
+        # feedback for the static shards: a re-cut after each of the first rebalanceAfterIters iterations (the second
+        # re-cut corrects what the first one's extrapolation got wrong; a side within 3 % of balanced is left alone)
+        if self.world > 1 and self._itersRun <= int(self.options.get("rebalanceAfterIters", 0) or 0):
             self.rebalance()
 
     def alsTrainStep(self, stepType):
