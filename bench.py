@@ -25,6 +25,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "you-can-not-recommend_amd", "python"))
 sys.path.insert(0, ROOT)
 
+# (read by the HIP runtime when it starts, i.e. at torch's first device call: see python/ycnr_als/_lib.py)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 

@@ -804,3 +804,19 @@ def test_signed_fractional_ratings(als, k):
             assert info.splitRows > 0
         check_rows(dev.get_factors("byUser"), want, conds, np.float32)
         dev.destroy()
+
+
+@pytest.mark.gpu
+def test_planes_row_kernel_against_the_float_gather():
+    """Round 4: the user half-step's fused row kernel gathers bf16 PLANES of the item matrix, split once per half-step
+    (GramX6P), instead of floats that every wave splits again (GramX6D).  Same truncations, same products in the same order:
+    every row bit-identical for k = 4 ... 108, except the 5 x 5 corner of the packed last block at k = 16 m + 4 (another
+    order of nine float32 sums: rows within 2e-5).  tests/tools/x6p_check.py runs both forms in child processes (the toggle
+    YCNR_NO_X6P is read once per process) over whole rows and over rows short enough for the dual classes."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "x6p_check.py")], capture_output=True, text=True, timeout=900)
+    print(r.stdout[-1500:])
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+

@@ -93,31 +93,90 @@ def test_packed_fma_lint_names_the_gram_x6d_kernels_only(tmp_path, capsys):
 
 SCRATCH = """
 	.amdhsa_kernel _ZN4ycnr21als_dual_solve_kernelILi7ELb1EEEvNS_8StepArgsIfEE
-		.amdhsa_private_segment_fixed_size 24
+		.amdhsa_private_segment_fixed_size 0
+		.amdhsa_next_free_vgpr 256
 	.end_amdhsa_kernel
 	.amdhsa_kernel _ZN4ycnr21als_dual_solve_kernelILi11ELb1EEEvNS_8StepArgsIfEE
 		.amdhsa_private_segment_fixed_size 112
+		.amdhsa_next_free_vgpr 512
 	.end_amdhsa_kernel
 	.amdhsa_kernel _ZN4ycnr21als_dual_solve_kernelILi4ELb1EEEvNS_8StepArgsIfEE
 		.amdhsa_private_segment_fixed_size 0
+		.amdhsa_next_free_vgpr 160
 	.end_amdhsa_kernel
 	.amdhsa_kernel _ZN4ycnr23als_reduce_solve_kernelIdLi8ELb0ELb0ELb0EEEvNS_8StepArgsIT_EE
 		.amdhsa_private_segment_fixed_size 320
+		.amdhsa_next_free_vgpr 512
 	.end_amdhsa_kernel
+	.amdhsa_kernel _ZN4ycnr24als_gram_slab_x6d_kernelILi7ELb1ELb1EEEvNS_8StepArgsIfEE
+		.amdhsa_private_segment_fixed_size 16
+		.amdhsa_next_free_vgpr 248
+	.end_amdhsa_kernel
+_ZN4ycnr24als_gram_slab_x6d_kernelILi7ELb1ELb1EEEvNS_8StepArgsIfEE: ; @counted waits + a spill
+	buffer_load_dwordx4 v212, s[8:11], s83 offen lds
+	scratch_store_dword off, v146, off offset:16 ; 4-byte Folded Spill
+	;;#ASMSTART
+	s_waitcnt vmcnt(14)
+	;;#ASMEND
+	scratch_load_dword v146, off, off offset:16 ; 4-byte Folded Reload
+	s_endpgm
+_ZN4ycnr21als_dual_solve_kernelILi11ELb1EEEvNS_8StepArgsIfEE: ; @scratch, but every wait is the compiler's own
+	scratch_store_dword off, v1, off
+	s_waitcnt vmcnt(0)
+	s_endpgm
 """
 
 
-def test_scratch_lint_rejects_any_spill_in_the_smaller_dual_classes(tmp_path, capsys):
-    """A 7-block dual class with 24 bytes of scratch (forced to two waves per SIMD) solved rows wrong at C5 scale in round 3
-    and passed every small GPU test: the build is rejected here, on the CPU.  The verified 11-block class and other
-    kernels below the general limit pass."""
+def test_scratch_lints_name_counted_waits_and_the_two_wave_dual_class(tmp_path, capsys):
+    """(1) A kernel that counts its vector-memory waits by hand (inline-asm vmcnt, LDS-DMA) must have NO scratch: a spill is a
+    vector-memory operation its count does not know.  (2) The dual class of 7 blocks built for two waves per SIMD solved rows
+    wrong at C5 scale -- with and without scratch (devtest/dual7/README.md) -- so the classes of 7+ blocks must be built for
+    one wave per SIMD.  Other kernels below the general limit pass, whatever their scratch."""
     lint = load_lint()
     f = tmp_path / "scratch.s"
     f.write_text(SCRATCH)
-    assert lint.lint_scratch(str(f)) == 1
+    assert lint.lint_scratch(str(f)) == 0
+    assert lint.lint_counted_waits_have_no_scratch(str(f)) == 1
+    assert lint.lint_dual_occupancy(str(f)) == 1
     out = capsys.readouterr().out
     fails = [l for l in out.splitlines() if l.startswith("FAIL")]
-    assert len(fails) == 1 and "dual class of 7 blocks" in fails[0]
+    assert len(fails) == 2 and "x6d" in fails[0] and "dual class of 7 blocks" in fails[1]
+
+
+ASM_LOAD_BAD = """
+_ZN4ycnr7asmloadEv: ; @a value loaded by inline asm, carried around the loop and copied at the back edge while in flight
+	s_branch .LBB0_2
+.LBB0_1:
+	buffer_load_dwordx4 v205, s[8:11], s80 offen lds
+	s_cbranch_scc0 .LBB0_3
+.LBB0_2:
+	v_mov_b32_e32 v206, v194
+	;;#ASMSTART
+	s_waitcnt vmcnt(1)
+	;;#ASMEND
+	;;#ASMSTART
+	buffer_load_dword v194, v203, s[16:19], 0 offen
+	;;#ASMEND
+	buffer_load_dwordx4 v205, s[8:11], s79 offen lds
+	s_branch .LBB0_1
+.LBB0_3:
+	s_endpgm
+"""
+
+
+def test_asm_vector_load_lint_follows_the_back_edge(tmp_path, capsys):
+    """GramX6P loads the ids and ratings of a step into registers from inline asm and retires them with hand-counted waits.  Its
+    first build let the compiler copy the loop-carried rating at the loop header, one operation before the count allowed: one
+    row in 10^5 was wrong on the GPU.  The lint must see that copy (reached only around the loop's back edge), and pass the
+    same loop with a wait that retires the load in front of the back edge."""
+    lint = load_lint()
+    bad, good = tmp_path / "bad.s", tmp_path / "good.s"
+    bad.write_text(ASM_LOAD_BAD)
+    good.write_text(ASM_LOAD_BAD.replace("\tbuffer_load_dwordx4 v205, s[8:11], s79 offen lds\n\ts_branch .LBB0_1",
+                                         "\tbuffer_load_dwordx4 v205, s[8:11], s79 offen lds\n\ts_waitcnt vmcnt(1)\n\ts_branch .LBB0_1"))
+    assert lint.lint_asm_vector_loads(str(bad), []) >= 1
+    assert "v_mov_b32_e32 v206, v194" in capsys.readouterr().out
+    assert lint.lint_asm_vector_loads(str(good), []) == 0
 
 
 def test_dpp_lint_counts_wait_states_over_every_path(tmp_path, capsys):
@@ -149,11 +208,17 @@ def test_device_assembly_has_no_premature_lds_uses(tmp_path):
                     "-I" + os.path.join(ROOT, "include"), "--cuda-device-only", "-S", "-o", str(out),
                     os.path.join(CSRC, "ycnr_als.hip")], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     assert lint.lint(str(out), []) == 0
+    # vector loads issued from inline asm (GramX6P's ids and ratings): no use or copy before their counted wait, back edges included
+    assert lint.lint_asm_vector_loads(str(out), []) == 0
     # the inline-asm v_fmac_f32_dpp pivot updates: no compiler-inserted copy may sit within two wait states
     # in front of one
     assert lint.lint_dpp(str(out), []) == 0
     # no instantiation may spill hundreds of bytes per lane to scratch (one did, unnoticed, at twice the run time)
     assert lint.lint_scratch(str(out)) == 0
+    # a kernel with hand-counted vector-memory waits (GramX6D, GramX6P) carries no scratch at all; the dual classes of 7+
+    # blocks are built for one wave per SIMD (devtest/dual7/README.md)
+    assert lint.lint_counted_waits_have_no_scratch(str(out)) == 0
+    assert lint.lint_dual_occupancy(str(out)) == 0
     # the fence of the stale-b hazard: hipcc must not have packed any multiply-add of a GramX6D kernel into
     # v_pk_fma_f32 (devtest/pkrepro.hip is the reproducer)
     assert lint.lint_packed_fma(str(out)) == 0

@@ -833,8 +833,21 @@ struct SolveMfmaF32 {
       R[P] *= rs;  // L[i][P] in groups 0 / 2, Linv[P][c] in groups 1 / 3
       float l = R[P], b = R[P];
       // l.row1 <-> b.row0, l.row3 <-> b.row2: l = L[j][P] in lane j of every 16-lane row (b is scratch)
+#if defined(YCNR_PIVOT_PROBE) && YCNR_PIVOT_PROBE == 1  // devtest (the 7-block dual class at two waves per SIMD): generous wait states around the swap
+      asm("s_nop 7\n\ts_nop 7\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 7\n\ts_nop 7" : "+v"(l), "+v"(b));
+#elif defined(YCNR_PIVOT_PROBE) && YCNR_PIVOT_PROBE == 2  // devtest: nothing of the compiler's scheduled between the statements of a pivot
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(l), "+v"(b));
+      __builtin_amdgcn_sched_barrier(0);
+#else
       asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(l), "+v"(b));
+#endif
       PivotDpp<P, P + 1>::first_two(R, l);
+#if defined(YCNR_PIVOT_PROBE) && YCNR_PIVOT_PROBE == 1
+      asm volatile("s_nop 7" ::: "memory");
+#elif defined(YCNR_PIVOT_PROBE) && YCNR_PIVOT_PROBE == 2
+      __builtin_amdgcn_sched_barrier(0);
+#endif
       pivots_dpp<P + 1, N>(R, dmin);
     }
   }
@@ -1352,6 +1365,8 @@ struct StepArgs {
   int32_t firstDual;   // first unit of the dual-form launch in flight
   uint32_t fixedBytes; // size of the fixed matrix when it is below 4 GB (buffer loads), else 0
   int32_t kReal = 0;   // != 0: only the first kReal of the k columns are factors, the rest zero padding (unit diagonal)
+  const unsigned short *planes = nullptr;  // the fixed matrix split into bf16 planes (GramX6P), when the half-step made one
+  uint32_t planesBytes = 0;
 };
 
 // Kernel 1a: one wave per SPLIT unit -- gather + Gramian + rhs of a chunk of a heavy row,
@@ -1838,6 +1853,288 @@ struct GramX6D {
   }
 };
 
+// ---------------------------------------------------------------------------------------------------------------
+// GramX6P (round 4): the same Gramian from a PRE-SPLIT copy of the fixed matrix.
+//
+// PMC of round 3 (profiles/r03_v6_mal_pmc_by_kernel.json): the user half-step at MAL scale issues 4.7 G vector
+// instructions per half-step -- 8.9 ms of the SIMDs' issue slots in a 12.4 ms step -- and 40 % of the fused row kernel's
+// are the float -> 3 x bf16 split of its gathered values (6.5 per value, 364 per 32-rating step of a wave, next to 147
+// MFMAs that each hold the issue port for 8 of their 16 cycles): the kernel is bound by vector ISSUE, not by the matrix
+// pipe, and (DESIGN.md "power") the split also costs 18 % of the clock.  The item matrix is split the same way by every
+// one of the 10^5..10^6 waves that gather it.  Here it is split ONCE per half-step (als_split_planes_kernel: 12.7 K x 100
+// floats at MAL scale) into three bf16 planes per 16-column block,
+//     planes[row][block b][plane p][16 columns]      (p = 0, 1, 2: high, middle, low 8 mantissa bits; 96 NB bytes per row)
+// and a wave gathers the planes of its 32 ratings straight into LDS by LDS-DMA -- one instruction per (block, plane):
+// lane l fetches the 16 bytes of columns 8 (l & 1) .. + 7 of rating l >> 1, so a slot is a plain [32 ratings][16 columns]
+// image with a 32-byte pitch -- and reads the MFMA operand (lane (g, c): ratings 8 g .. 8 g + 7 of column c) back with two
+// ds_read_b64_tr_b16, the transposing LDS read of gfx950 (conflict-free on this image: cdna_hip_programming.md).  No
+// split, no selects, no second image: per step 21 DMAs + 42 LDS reads + ~40 vector instructions at NB = 7.
+// Same products in the same order as GramX6D<NB, true, false> (the planes are the same truncations): bit-identical.
+//   * PADRHS only (k < 16 NB): the ratings ride in column k of the last block; their three planes are written into the
+//     landed slots (3 ds_write_b16 per rating) before the operand of the last block is read.
+//   * Operand registers are single-buffered as in GramX6D: after tile row bi nothing reads block bi again, so the next
+//     step's block bi is read into the same registers (the reads return behind the MFMAs of row bi + 1) and the slots of
+//     block bi are refilled with step s + 2 once those reads have returned (LDS reads complete in order: lgkmcnt(6)).
+//   * Every wait is counted by hand (inline-asm LDS reads, DMAs through the builtin): a phase issues 2 + 3 NB vector-memory
+//     operations in a fixed order; "block bi of the next step has landed" is vmcnt(3 NB - 1) for bi = 0 and
+//     vmcnt(3 NB - 4) after it.
+// LDS: 3 NB KB of slots + 2 KB of ids / ratings per wave (23 KB at NB = 7: six waves per CU with the solver's image).
+// Needs k % 4 == 0, k <= 112, k % 16 != 0 and the plane matrix below 2 GB; used where the fixed matrix is cache-resident
+// (the user half-step): the planes are 1.68 x the bytes of the float rows.
+// PACK (k = 16 (NB - 1) + 4: k = 100, 20, 36 ...): the last block has four live columns and the ratings' column, so its three
+// planes are stored side by side in ONE 16-column slot -- [h0..h3, hR, m0..m3, mR, l0..l3, lR, 0]; the R positions are
+// zero in the matrix and receive the ratings' planes in LDS -- and a tile of the last block column is A_l, A_m, A_h of its
+// block row against that packed operand (three MFMAs: all nine plane products, as GramX6D's PK3), the corner tile the packed
+// operand against itself (one).  145 MFMAs, 19 DMAs and 38 LDS reads per 32 ratings at k = 100, 19 KB of slots per wave.
+__host__ __device__ constexpr int planes_row_bytes(int nb, bool pack) { return pack ? (nb - 1) * 96 + 32 : nb * 96; }
+__host__ __device__ constexpr bool planes_pack(int k) { return k > 16 && k % 16 == 4; }
+
+// One thread per (row, block, column quad): the exact 3-way split by truncation of GramX6D, columns >= k are zero.
+__global__ void als_split_planes_kernel(const float *__restrict__ fixed, unsigned short *__restrict__ planes, int64_t rows, int k, int nb, int pack) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = rows * nb * 4;
+  if (i >= total) return;
+  const int q = (int)(i & 3);
+  const int b = (int)((i >> 2) % nb);
+  const int64_t r = (i >> 2) / nb;
+  const int c0 = 16 * b + 4 * q;
+  unsigned short h[4], m[4], l[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float x = c0 + j < k ? fixed[r * k + c0 + j] : 0.0f;
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const float s1 = x - __builtin_bit_cast(float, u & 0xFFFF0000u);
+    const unsigned v = __builtin_bit_cast(unsigned, s1);
+    const float t1 = s1 - __builtin_bit_cast(float, v & 0xFFFF0000u);
+    h[j] = (unsigned short)(u >> 16);
+    m[j] = (unsigned short)(v >> 16);
+    l[j] = (unsigned short)(__builtin_bit_cast(unsigned, t1) >> 16);
+  }
+  typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+  unsigned short *row = planes + r * (int64_t)(planes_row_bytes(nb, pack != 0) / 2) + (int64_t)b * 48;
+  if (pack && b == nb - 1) {
+    if (q != 0) return;  // the four live columns are this block's first quad: [h0..h3, 0, m0..m3, 0, l0..l3, 0, 0]
+    *reinterpret_cast<us4 *>(row) = us4{h[0], h[1], h[2], h[3]};
+    *reinterpret_cast<us4 *>(row + 4) = us4{0, m[0], m[1], m[2]};
+    *reinterpret_cast<us4 *>(row + 8) = us4{m[3], 0, l[0], l[1]};
+    *reinterpret_cast<us4 *>(row + 12) = us4{l[2], l[3], 0, 0};
+    return;
+  }
+  *reinterpret_cast<us4 *>(row + 4 * q) = us4{h[0], h[1], h[2], h[3]};
+  *reinterpret_cast<us4 *>(row + 16 + 4 * q) = us4{m[0], m[1], m[2], m[3]};
+  *reinterpret_cast<us4 *>(row + 32 + 4 * q) = us4{l[0], l[1], l[2], l[3]};
+}
+
+template <int NB, bool PACK>
+struct GramX6P {
+  static_assert(!PACK || NB >= 2, "the packed last block needs a block in front of it");
+  using acc_t = typename MfmaTraits<float>::acc_t;
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  static constexpr int NT = tile_count(NB);
+  static constexpr int L = NB - 1;                       // the last block
+  static constexpr int SL = PACK ? 1 : 3;                // its slots
+  static constexpr int NS = 3 * L + SL;                  // slots of 1 KB: (block, plane)
+  static constexpr int LDS_DWORDS = NS * 256;
+  static constexpr unsigned OOB = 0x80000000u;
+  // vector-memory operations issued behind the DMAs of block bi until the wait for them one phase later (a phase issues, behind
+  // its first wait, the two loads of ids / ratings, then the blocks' DMAs in order, block bi - 1 inside iteration bi, the last
+  // block at the end).  The loads are retired by a wait of their own at the end of the phase that issued them.
+  static constexpr int W0 = NS - 3, WMID = 3 * L - 4 + SL, WLAST = 3 * L - 1;
+  static constexpr int RL = PACK ? 2 : 6;                // LDS reads of the last block's operand
+
+  // acc += Y^T Y over ratings [beg, beg + n); column k of the padded Gramian accumulates b = Y^T r.  `lds`: LDS_DWORDS dwords.
+  static __device__ __forceinline__ void accumulate(acc_t (&acc)[NT], unsigned *lds, const int32_t *indx, const float *vals,
+                                                    const unsigned short *planes, uint32_t planesBytes, int k, int64_t beg, int64_t n, int lane) {
+    const int g = lane >> 4;
+    const int kr = k - 16 * L;
+    constexpr unsigned pitch = (unsigned)planes_row_bytes(NB, PACK);
+    const unsigned n32 = (unsigned)(n < 0x3fffffff ? n : 0x3fffffff);
+    const int64_t nsteps = (n + 31) >> 5;
+    const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc((void *)planes, 0, (int)planesBytes, 0x00020000);
+    // ids and ratings come by plain buffer loads into registers (inline asm: a load the compiler counted would drain the DMAs)
+    const uint64_t pI = (uint64_t)(uintptr_t)(indx + beg), pR = (uint64_t)(uintptr_t)(vals + beg);
+    const u32x4 srdI = u32x4{(unsigned)pI, (unsigned)(pI >> 32) & 0xFFFFu, n32 * 4u, 0x00020000u};
+    const u32x4 srdR = u32x4{(unsigned)pR, (unsigned)(pR >> 32) & 0xFFFFu, n32 * 4u, 0x00020000u};
+    const unsigned ldsBase = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned *)lds;
+    // DMA side: this lane's rating of a step and its half of a 16-column block
+    const unsigned rhoL = (unsigned)lane >> 1, halfBytes = (unsigned)(lane & 1) * 16u;
+    // operand side: lane 4 q + p of 16-lane group g supplies the address of (rating 8 g + q, columns 4 p .. 4 p + 3)
+    const unsigned rdBase = ldsBase + (unsigned)g * 256u + (unsigned)((lane >> 2) & 3) * 32u + (unsigned)(lane & 3) * 8u;
+    // rating column: lane l < 32 writes the three planes of rating l into the landed slot(s) of the last block
+    const unsigned wrBase = ldsBase + (unsigned)(3 * L) * 1024u + (unsigned)(lane & 31) * 32u + (PACK ? 8u : (unsigned)kr * 2u);
+
+    u32x4 p1[NB], p2[NB], p3[NB];  // PACK: p1[L] is the packed operand, p2[L] / p3[L] unused
+    u32x2 tr[2][6];                // operand reads in flight: block bi in tr[bi & 1]
+    unsigned idNext = 0, idCur = 0, offH = OOB;
+    float rvNext = 0.0f, rvCur = 0.0f;
+
+    auto load_meta = [&](int64_t tId, int64_t tR) {  // id of this lane's rating of step tId, rating lane & 31 of step tR: IN FLIGHT on return
+      const unsigned oi = (((unsigned)tId << 5) + rhoL) * 4u, orr = (((unsigned)tR << 5) + (unsigned)(lane & 31)) * 4u;
+      asm volatile("buffer_load_dword %0, %2, %4, 0 offen\n\tbuffer_load_dword %1, %3, %5, 0 offen"
+                   : "=&v"(idNext), "=&v"(rvNext) : "v"(oi), "v"(orr), "s"(srdI), "s"(srdR) : "memory");
+    };
+    auto retire_meta = [&]() { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(idNext), "+v"(rvNext) : "n"(NS) : "memory"); };
+    auto take_meta = [&](int64_t tId) {  // the pair loaded one phase ago has landed (retired by that phase's counted waits)
+      asm volatile("" : "+v"(idNext), "+v"(rvNext));
+      idCur = idNext;
+      rvCur = rvNext;
+      const unsigned q0 = ((unsigned)tId << 5) + rhoL;
+      offH = q0 < n32 ? idCur * pitch + halfBytes : OOB;
+    };
+    auto gather_block = [&](int b) {  // the planes of block b of the step offH belongs to
+      if (PACK && b == L) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_void_ptr)(lds + (3 * L) * 256), 16, offH, (3 * L) * 32, 0, 0);
+      } else {
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_void_ptr)(lds + (3 * b + p) * 256), 16, offH, (3 * b + p) * 32, 0, 0);
+      }
+    };
+    auto write_rating_column = [&]() {  // planes of the ratings of the step whose last block has just landed
+      const unsigned u = __builtin_bit_cast(unsigned, rvCur);
+      const float s1 = rvCur - __builtin_bit_cast(float, u & 0xFFFF0000u);
+      const unsigned v = __builtin_bit_cast(unsigned, s1);
+      const float t1 = s1 - __builtin_bit_cast(float, v & 0xFFFF0000u);
+      const unsigned h = u >> 16, m = v >> 16, l = __builtin_bit_cast(unsigned, t1) >> 16;
+      if (lane < 32) {
+        if constexpr (PACK)  // columns 4, 9, 14 of the packed slot
+          asm volatile("ds_write_b16 %0, %1\n\tds_write_b16 %0, %2 offset:10\n\tds_write_b16 %0, %3 offset:20" ::"v"(wrBase), "v"(h), "v"(m), "v"(l) : "memory");
+        else
+          asm volatile("ds_write_b16 %0, %1\n\tds_write_b16 %0, %2 offset:1024\n\tds_write_b16 %0, %3 offset:2048" ::"v"(wrBase), "v"(h), "v"(m), "v"(l) : "memory");
+      }
+    };
+    // operand planes of block bi from its slots: transposing reads, IN FLIGHT on return -- nothing may touch t[] before the
+    // counted wait that retires them (take_block), not even a register copy (devtest/isa_lint.py checks)
+    auto read_block = [&](int bi, u32x2 (&t)[6]) {
+      const unsigned ra = rdBase + (unsigned)bi * 3072u;
+      if (PACK && bi == L)
+        asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:128" : "=&v"(t[0]), "=&v"(t[1]) : "v"(ra) : "memory");
+      else
+        asm volatile("ds_read_b64_tr_b16 %0, %6\n\tds_read_b64_tr_b16 %1, %6 offset:128\n\t"
+                     "ds_read_b64_tr_b16 %2, %6 offset:1024\n\tds_read_b64_tr_b16 %3, %6 offset:1152\n\t"
+                     "ds_read_b64_tr_b16 %4, %6 offset:2048\n\tds_read_b64_tr_b16 %5, %6 offset:2176"
+                     : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]) : "v"(ra) : "memory");
+    };
+    auto take_block = [&](int bi, u32x2 (&t)[6], auto PENDING_) {  // all LDS operations but the youngest PENDING have completed
+      constexpr int PENDING = decltype(PENDING_)::value;
+      if (PACK && bi == L) {
+        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(t[0]), "+v"(t[1]) : "n"(PENDING) : "memory");
+        p1[bi] = u32x4{t[0][0], t[0][1], t[1][0], t[1][1]};
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]) : "n"(PENDING) : "memory");
+        p1[bi] = u32x4{t[0][0], t[0][1], t[1][0], t[1][1]};
+        p2[bi] = u32x4{t[2][0], t[2][1], t[3][0], t[3][1]};
+        p3[bi] = u32x4{t[4][0], t[4][1], t[5][0], t[5][1]};
+      }
+    };
+    auto mma = [&](acc_t &t, const u32x4 &a, const u32x4 &b) {
+      t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), t, 0, 0, 0);
+    };
+    auto mma_row = [&](int bi) {
+      constexpr int NBF = PACK ? L : NB;  // block columns multiplied plane by plane
+      if (PACK && bi == L) {
+        mma(acc[tile_index(L, L, NB)], p1[L], p1[L]);  // the packed operand against itself: all nine plane products of the corner
+        return;
+      }
+#pragma unroll
+      for (int term = 0; term < 6; ++term) {
+#pragma unroll
+        for (int bj = bi; bj < NBF; ++bj) {
+          const u32x4 &pa = term == 0 ? p2[bi] : (term == 1 || term == 3 || term == 5) ? p1[bi] : (term == 2 ? p3[bi] : p2[bi]);
+          const u32x4 &pb = term == 0 ? p2[bj] : term == 1 ? p3[bj] : term == 2 ? p1[bj] : term == 3 ? p2[bj] : p1[bj];
+          mma(acc[tile_index(bi, bj, NB)], pa, pb);
+        }
+      }
+      if constexpr (PACK) {  // the last block column against the packed operand, smallest terms first (as GramX6D's PK3)
+        acc_t &t = acc[tile_index(bi, L, NB)];
+        mma(t, p3[bi], p1[L]);
+        mma(t, p2[bi], p1[L]);
+        mma(t, p1[bi], p1[L]);
+      }
+    };
+    // One phase: products of step s beside the operand reads of step s + 1 and the DMA of step s + 2.
+    auto phase = [&](int64_t s, auto MMA_, auto LOAD_) {
+      constexpr bool MMA = decltype(MMA_)::value, LOAD = decltype(LOAD_)::value;
+#pragma unroll
+      for (int bi = 0; bi < NB; ++bi) {
+        if constexpr (LOAD) {  // block bi of step s + 1 has landed
+          if (bi == 0) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W0) : "memory");
+            take_meta(s + 2);  // id of step s + 2, ratings of step s + 1: loaded in phase s - 1, retired by this wait
+            load_meta(s + 3, s + 2);
+          } else if (bi < L) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WMID) : "memory");
+          } else {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WLAST) : "memory");
+          }
+          if (bi == L) write_rating_column();
+        }
+        // (the MFMAs are pure operations to the compiler: without the barriers it hoists all of a phase's above the reads
+        // and the reads' latency is exposed once per block)
+        if constexpr (MMA && LOAD) __builtin_amdgcn_sched_barrier(0);
+        if constexpr (MMA) mma_row(bi);
+        if constexpr (MMA && LOAD) __builtin_amdgcn_sched_barrier(0);
+        if constexpr (LOAD) {
+          read_block(bi, tr[bi & 1]);  // step s + 1, behind the MFMAs of row bi + 1
+          if (bi > 0) {  // the reads of block bi - 1 have returned (LDS operations complete in order): its registers take them
+                         // (row bi - 1 has finished with the old ones), its slots take step s + 2
+            if (bi == L) take_block(bi - 1, tr[(bi - 1) & 1], std::integral_constant<int, RL + 3>{});  // (+ the three ds_write_b16)
+            else take_block(bi - 1, tr[(bi - 1) & 1], std::integral_constant<int, 6>{});
+            gather_block(bi - 1);
+          }
+        }
+      }
+      if constexpr (LOAD) {
+        take_block(L, tr[L & 1], std::integral_constant<int, 0>{});
+        gather_block(L);
+        // Everything but this phase's NS DMAs has completed -- in particular the two loads of ids / ratings issued behind the
+        // phase's first wait.  They are consumed in the NEXT phase, i.e. carried around the loop: a register copy the compiler
+        // places at the back edge must find them landed (a build without this wait copied them one operation too early:
+        // one row in 10^5 gathered through a stale id).
+#ifndef YCNR_X6P_NO_RETIRE  // (devtest: the build that copied an in-flight rating at the loop's back edge; isa_lint.py must flag it)
+        retire_meta();
+#endif
+      }
+    };
+    using yes = std::integral_constant<bool, true>;
+    using no = std::integral_constant<bool, false>;
+    // ids of steps 0 and 1 and the ratings of step 0, then the whole of step 0 into the slots (same issue order as a phase: the
+    // gathers last, so phase(-1) can use the same counted waits)
+    load_meta(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(idNext), "+v"(rvNext)::"memory");
+    take_meta(0);
+    const float rv0 = rvCur;
+    load_meta(1, 0);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(idNext), "+v"(rvNext)::"memory");
+    rvNext = rv0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) gather_block(b);
+    phase(-1, no{}, yes{});
+    for (int64_t s = 0; s + 1 < nsteps; ++s) phase(s, yes{}, yes{});
+    phase(nsteps - 1, yes{}, no{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing of this wave may land in LDS after it ends
+  }
+
+  // PACK: the corner tile (packed operand x packed operand) holds the plane products of live row i in rows i, i + 5, i + 10:
+  // fold them (through a 1 KB LDS image: once per row) and clear rows 5..15.  The columns are folded by
+  // GramX6D<NB, true, true>::extract_rhs like every tile of the last block column.
+  static __device__ __forceinline__ void fold_corner_rows(acc_t &tl, float *S, int lane) {
+    const int g = lane >> 4, c = lane & 15;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) S[(4 * g + t) * 16 + c] = tl[t];
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int i = 4 * g + t;
+      const float v = i <= 4 ? (S[i * 16 + c] + S[(i + 5) * 16 + c]) + S[(i + 10) * 16 + c] : 0.0f;
+      tl[t] = i <= 4 ? v : 0.0f;
+    }
+    __syncthreads();
+  }
+};
+
 template <int NB, bool PADRHS, bool PK3 = false>
 __global__ __launch_bounds__(64, 2) void als_gram_slab_x6d_kernel(StepArgs<float> a) {
   using G = GramX6D<NB, PADRHS, PK3>;
@@ -1942,6 +2239,35 @@ __global__ __launch_bounds__(64, 2) void als_gram_solve_x6d_kernel(StepArgs<floa
                                                 a.solved + (int64_t)u.row * a.k, u.row, a.err, lane);
   }
 #endif
+}
+
+// Kernel 1b'': the fused row kernel on the pre-split planes of the fixed matrix (GramX6P); the solve is unchanged and works
+// in the slots' LDS once the Gramian has drained (19 KB per wave at k = 100: eight waves per CU).
+// float32, k % 4 == 0, k <= 112, k % 16 != 0, plane matrix < 2 GB.
+template <int NB, bool PACK, bool E4>
+__global__ __launch_bounds__(64, 2) void als_gram_solve_x6p_kernel(StepArgs<float> a) {
+  using G = GramX6P<NB, PACK>;
+  using GD = GramX6D<NB, true, PACK>;  // (extract_rhs: the padded column leaves the tiles the same way)
+  using acc_t = typename G::acc_t;
+  static_assert(SolveMfmaF32<NB>::lds_bytes() <= (size_t)G::LDS_DWORDS * 4, "the solver's image must fit the slots");
+  __shared__ __attribute__((aligned(16))) unsigned ring[G::LDS_DWORDS];
+  const int lane = threadIdx.x;
+  const Unit u = a.units[a.firstFused + blockIdx.x];
+  acc_t acc[G::NT];
+#pragma unroll
+  for (int t = 0; t < G::NT; ++t) acc[t] = acc_t{0.0f, 0.0f, 0.0f, 0.0f};
+  float bacc[NB];
+#pragma unroll
+  for (int cb = 0; cb < NB; ++cb) bacc[cb] = 0.0f;
+  G::accumulate(acc, ring, a.indx, a.vals, a.planes, a.planesBytes, a.k, u.beg, u.end - u.beg, lane);
+  if constexpr (PACK) G::fold_corner_rows(acc[tile_index(NB - 1, NB - 1, NB)], reinterpret_cast<float *>(ring), lane);
+  GD::extract_rhs(acc, bacc, a.k, lane);
+  const float lam = (float)(a.lambda * (double)(u.end - u.beg));
+  if constexpr (E4) {
+    SolveMfmaF32<NB>::template run<true>(acc, bacc, reinterpret_cast<float *>(ring), a.k, lam, a.solved + (int64_t)u.row * a.k, u.row, a.err, lane);
+  } else {
+    SolveMfmaF32<NB>::run(acc, bacc, reinterpret_cast<float *>(ring), a.k, lam, a.solved + (int64_t)u.row * a.k, u.row, a.err, lane);
+  }
 }
 
 // Kernel 1c: the same row solve in its DUAL form, for rows with fewer ratings than factors.

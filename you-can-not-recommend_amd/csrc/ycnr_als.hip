@@ -157,10 +157,12 @@ struct Schedule {
 // Small uploads (below 2 M ratings: the ML-1M shape) are bound by their longest wave, not by slab traffic:
 // there the chunk shrinks, down to 256, so that one round of waves covers the half-step (ML-1M shape, k = 100:
 // 0.62 -> 0.54 ms per iteration with 512; 200 K x 20 K with 20 M ratings is fastest at 1024).
-int auto_chunk(int64_t nnz) {
+// nnz: ratings of the whole side; splitNnz: those of its rows above kDefaultChunk ratings (the rows that are split at all).
+// Both describe the side, not the shard: the cuts of a split row must not depend on how the rows are dealt to GPUs.
+int auto_chunk(int64_t nnz, int64_t splitNnz) {
   if (nnz < (int64_t)2048 * kDefaultChunk)
     return (int)((std::min<int64_t>(kDefaultChunk, std::max<int64_t>(256, nnz / 2048)) + 3) & ~(int64_t)3);
-  const int64_t c = nnz / (2048 * 16);
+  const int64_t c = splitNnz / (2048 * 16);
   return (int)((std::min<int64_t>(3072, std::max<int64_t>(kDefaultChunk, c)) + 3) & ~(int64_t)3);
 }
 
@@ -246,10 +248,18 @@ constexpr int kSideStreams = 6;  // most side streams a handle can have; side_st
 int side_streams() {
   static const int n = [] {
     const char *e = getenv("YCNR_SIDE_STREAMS");
-    return e ? std::max(1, std::min(kSideStreams, atoi(e))) : 2;
+    if (e) return std::max(1, std::min(kSideStreams, atoi(e)));
+    // one stream per dual class when every stream gets a hardware queue of its own (the row kernel's stream + five), else two:
+    // MAL scale, user half-step, same box: 13.20 ms with 4 queues / 2 side streams, 13.14 with 8 / 2, 12.84 with 8 / 5
+    const char *q = getenv("GPU_MAX_HW_QUEUES");
+    return q && atoi(q) >= 8 ? 5 : 2;
   }();
   return n;
 }
+// The runtime reads GPU_MAX_HW_QUEUES when it starts: a process that loads this library before its first HIP call gets 8
+// hardware queues unless its environment says otherwise (hosts that initialise HIP first set it themselves: bench.py,
+// python/ycnr_als/_lib.py, lib/ycnr_als.js).
+__attribute__((constructor)) void ycnr_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 constexpr int64_t kGraphMaxRatings = 2 * 1024 * 1024;  // uploads below this replay their half-step as a captured hipGraph ...
 constexpr int64_t kGraphMinRatings = 256 * 1024;       // ... unless they are so small that the graph launch itself costs more than four
                                                         // kernel launches (ML-100k shape: 0.124 ms per iteration launch by launch, 0.174 as graphs)
@@ -295,6 +305,8 @@ int launch_dual(StepArgs<float> args, const DualPlan &dp, hipStream_t stream) {
     if (x6) kd = als_dual_solve_kernel<M, true>;
     // (YCNR_DUAL_LDSPAD: occupancy experiments -- extra dynamic LDS per workgroup limits the workgroups a CU holds)
     static const size_t ldsPad = getenv("YCNR_DUAL_LDSPAD") ? (size_t)atoi(getenv("YCNR_DUAL_LDSPAD")) : 0;
+    if (ldsPad)
+      if (int rcl = set_max_lds(reinterpret_cast<const void *>(kd), SolveMfmaF32<M>::lds_bytes() + ldsPad)) return rcl;
     hipLaunchKernelGGL(kd, dim3((unsigned)dp.count[M]), dim3(64), SolveMfmaF32<M>::lds_bytes() + ldsPad, stream, args);
     HIP_TRY(hipGetLastError());
   }
@@ -355,6 +367,16 @@ YCNR_X6D(1, false) YCNR_X6D(2, false) YCNR_X6D(3, false) YCNR_X6D(4, false) YCNR
 YCNR_X6D(1, true) YCNR_X6D(2, true) YCNR_X6D(3, true) YCNR_X6D(4, true) YCNR_X6D(5, true) YCNR_X6D(6, true) YCNR_X6D(7, true)
 #undef YCNR_X6D
 
+// the fused row kernel on the pre-split planes of the fixed matrix (GramX6P): k % 4 == 0, 16 (NB - 1) < k < 16 NB, register solver;
+// k = 16 (NB - 1) + 4: the last block packed into one slot, the four edge columns eliminated first
+template <typename T, int NB>
+void (*fused_x6p_kernel(int))(StepArgs<T>) { return nullptr; }
+#define YCNR_X6P(NBV) \
+  template <>         \
+  void (*fused_x6p_kernel<float, NBV>(int k))(StepArgs<float>) { return (k % 4 || k >= 16 * NBV || k <= 16 * (NBV - 1)) ? nullptr : (NBV >= 2 && planes_pack(k)) ? als_gram_solve_x6p_kernel<NBV, (NBV >= 2), (NBV >= 2)> : als_gram_solve_x6p_kernel<NBV, false, false>; }
+YCNR_X6P(1) YCNR_X6P(2) YCNR_X6P(3) YCNR_X6P(4) YCNR_X6P(5) YCNR_X6P(6) YCNR_X6P(7)
+#undef YCNR_X6P
+
 // SLABX6: split chunks go through the bf16x6 Gramian kernel (plain slab layout), so the reduce
 // kernel reads plain slabs whatever form the fused kernel uses.
 template <typename T, int NB, bool LDS_SOLVER, bool EDGE, bool SLABX6>
@@ -373,8 +395,15 @@ int launch_nbe(StepArgs<T> args, int64_t nUnits, int64_t nSplitUnits, int64_t nS
   }
   if (SLABX6 && fused_x6d_kernel<T, NB, LDS_SOLVER>(args.k) && !env_flags().noX6d && !env_flags().noFusedX6d)
     k1 = fused_x6d_kernel<T, NB, LDS_SOLVER>(args.k);
+  size_t ldsRow = lds;  // dynamic LDS of the row kernel: the solver's image
+  if constexpr (SLABX6 && !LDS_SOLVER && NB <= 7) {
+    if (args.planes && fused_x6p_kernel<T, NB>(args.k)) {  // the half-step split the fixed matrix into planes
+      k1 = fused_x6p_kernel<T, NB>(args.k);
+      ldsRow = 0;  // (its solver works in the slots of the Gramian)
+    }
+  }
   const size_t pad = env_flags().k1LdsPad;  // experiments: limits blocks per CU
-  if (int rcl = set_max_lds(reinterpret_cast<const void *>(k1), lds + pad)) return rcl;
+  if (int rcl = set_max_lds(reinterpret_cast<const void *>(k1), ldsRow + pad)) return rcl;
   if (int rcl = set_max_lds(reinterpret_cast<const void *>(k2), lds)) return rcl;
   args.firstFused = (int32_t)nSplitUnits;
   if (ev) HIP_TRY(hipEventRecord(ev[0], stream));
@@ -404,7 +433,7 @@ int launch_nbe(StepArgs<T> args, int64_t nUnits, int64_t nSplitUnits, int64_t nS
     for (int i = 0; i < dp.nSide; ++i) HIP_TRY(hipEventRecord(dp.join[i], dp.side[i]));
   }
   if (nPrimal > 0) {
-    hipLaunchKernelGGL(k1, dim3((unsigned)nPrimal), dim3(64), lds + pad, stream, args);
+    hipLaunchKernelGGL(k1, dim3((unsigned)nPrimal), dim3(64), ldsRow + pad, stream, args);
     HIP_TRY(hipGetLastError());
   }
   if (ev) HIP_TRY(hipEventRecord(ev[2], stream));
@@ -670,6 +699,17 @@ bool use_slab_x6(const ycnr_als_options &o, int side) {
          fixedRows * o.factorsCount * 4 < ((int64_t)1 << 31);
 }
 
+// The fused row kernel on pre-split planes (GramX6P): float32 bf16x6 path, k % 4 == 0, k <= 112 with a padded column for
+// the right-hand side (k % 16 != 0), and a plane matrix (96 bytes per 16-column block and row) that stays cache-resident.
+constexpr int64_t kPlanesMaxBytes = (int64_t)64 << 20;
+bool use_planes(const ycnr_als_options &o, int side) {
+  static const bool off = getenv("YCNR_NO_X6P") != nullptr;
+  const int64_t fixedRows = side == YCNR_BY_USER ? o.totalItemsCount : o.totalUsersCount;
+  const int k = o.factorsCount;
+  return !off && use_slab_x6(o, side) && !(o.flags & YCNR_FLAG_LDS_SOLVER) && k % 4 == 0 && k <= 112 && k % 16 != 0 &&
+         fixedRows * planes_row_bytes(slab_nb(k), planes_pack(k)) <= kPlanesMaxBytes;
+}
+
 // registers (x 64 lanes x sizeof(T)) one split unit writes
 int64_t slab_regs(const ycnr_als_options &o, int side) {
   const int nb = slab_nb(o.factorsCount);
@@ -839,6 +879,9 @@ struct ycnr_als {
   }
   void *factors[2] = {nullptr, nullptr};
   bool ownFactors[2] = {false, false};
+  // GramX6P: the fixed matrix of a half-step split into bf16 planes once (als_split_planes_kernel), where it is small
+  // enough to stay cache-resident (the user half-step: the item matrix); planes[s] belongs to factors[s]
+  unsigned short *planes[2] = {nullptr, nullptr};
   int kPad = 0;                          // != 0: factorsCount padded to a multiple of 4 (k > 128, k % 4 != 0)
   float *padded[2] = {nullptr, nullptr};  // [rows x kPad] copies the kernels of that case work on
   bool autoChunk = false;  // options.chunkRatings was 0: sized per upload (auto_chunk)
@@ -1352,6 +1395,7 @@ int ycnr_als_destroy(ycnr_als *h) {
     h->rmse[s].release();
     if (h->ownFactors[s] && h->factors[s]) (void)hipFree(h->factors[s]);
     if (h->padded[s]) (void)hipFree(h->padded[s]);
+    if (h->planes[s]) (void)hipFree(h->planes[s]);
   }
   if (h->dErr) (void)hipFree(h->dErr);
   if (h->hErr) (void)hipHostFree(h->hErr);
@@ -1431,7 +1475,7 @@ static int upload_ratings(ycnr_als *h, Ratings &R, int64_t totalRows, int64_t op
 // Upload + schedule of one piece [rowBegin, rowEnd) of a side's rows into newR / S (both released
 // by the caller when this fails).
 static int build_part(ycnr_als *h, int side, const int64_t *rowPtr, const int32_t *indx, const void *vals, int64_t rowBegin,
-                      int64_t rowEnd, int memKind, Ratings &newR, Schedule &S, int64_t sideNnz) {
+                      int64_t rowEnd, int memKind, Ratings &newR, Schedule &S, int64_t sideNnz, int64_t sideSplitNnz) {
   std::vector<int64_t> hp;
   int rc = upload_ratings(h, newR, h->rows(side), h->rows(1 - side), rowPtr, indx, vals, rowBegin,
                           rowEnd, memKind, hp, side == YCNR_BY_USER ? "set_ratings(byUser)" : "set_ratings(byItem)");
@@ -1443,10 +1487,10 @@ static int build_part(ycnr_als *h, int side, const int64_t *rowPtr, const int32_
   const bool big = !gen && h->opt.factorsCount > kMaxFactors;
   // k > 128: a unit is a whole workgroup's work, so chunks are long (a slab is 140 KB at k = 256)
   // (an explicit options.chunkRatings is honoured there too: tests cut short rows into chunks with it)
-  // The automatic chunk length follows the ratings of the WHOLE side, not of this piece: where a split row is cut decides
-  // the order its partial sums are added in, so a length that depended on the piece would make the factors depend on how
-  // the rows are cut into shards and pieces (and a feedback re-cut would change them: round-3 review).
-  const int chunkRatings = h->autoChunk ? (gen ? kGenChunk : big ? kWgChunk : auto_chunk(sideNnz)) : h->opt.chunkRatings;
+  // The automatic chunk length follows the split rows of the WHOLE side (sideNnz: their ratings), not of this piece: where a
+  // split row is cut decides the order its partial sums are added in, so a length that depended on the piece would make the
+  // factors depend on how the rows are cut into shards and pieces (and a feedback re-cut would change them: round-3 review).
+  const int chunkRatings = h->autoChunk ? (gen ? kGenChunk : big ? kWgChunk : auto_chunk(sideNnz, sideSplitNnz)) : h->opt.chunkRatings;
   if (gen)
     build_schedule(hp.data(), rowBegin, rowEnd - rowBegin, chunkRatings, units, split, nSlabs, solved, dual_max_ratings(h->opt), 0);
   else
@@ -1604,22 +1648,32 @@ static int set_ratings_parts(ycnr_als *h, int side, const int64_t *rowPtr, const
     }
   } pend;
   pend.parts.resize((size_t)nParts);
-  // ratings of the whole side (rowPtr describes every row of it, whatever shard this handle solves)
-  int64_t ends[2] = {0, 0};
+  // The ratings of the WHOLE side that sit in rows long enough to be split (rowPtr describes every row of the side, whatever
+  // shard this handle solves): what the automatic chunk length is sized for.  MAL scale: nearly all of the item side's 121 M
+  // ratings (-> 3072), a few per cent of the user side's (-> 1024: its chunk kernel is a few hundred waves whose length is
+  // the kernel's; with the item side's 3072 it was a 300 us chain in front of every piece's row kernel).
   if (!rowPtr) return fail(YCNR_ERR_INVALID, "set_ratings: null rowPtr");
-  if (memKind == YCNR_MEM_DEVICE) {
-    HIP_TRY(hipMemcpy(&ends[0], rowPtr, sizeof(int64_t), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(&ends[1], rowPtr + h->rows(side), sizeof(int64_t), hipMemcpyDeviceToHost));
-  } else {
-    ends[0] = rowPtr[0];
-    ends[1] = rowPtr[h->rows(side)];
+  int64_t sideNnz = 0, sideSplitNnz = 0;
+  if (h->autoChunk) {
+    const int64_t nr = h->rows(side);
+    std::vector<int64_t> whole;
+    const int64_t *rp = rowPtr;
+    if (memKind == YCNR_MEM_DEVICE) {
+      whole.resize((size_t)nr + 1);
+      HIP_TRY(hipMemcpy(whole.data(), rowPtr, sizeof(int64_t) * ((size_t)nr + 1), hipMemcpyDeviceToHost));
+      rp = whole.data();
+    }
+    for (int64_t r = 0; r < nr; ++r) {
+      const int64_t n = rp[r + 1] - rp[r];
+      sideNnz += n > 0 ? n : 0;
+      if (n > kDefaultChunk) sideSplitNnz += n;
+    }
   }
-  const int64_t sideNnz = std::max<int64_t>(0, ends[1] - ends[0]);
   for (int i = 0; i < nParts; ++i) {
     Part &p = pend.parts[(size_t)i];
     hipError_t e = p.create_events();
     if (e != hipSuccess) return fail(YCNR_ERR_HIP, "set_ratings: hipEventCreate: %s", hipGetErrorString(e));
-    int rc = build_part(h, side, rowPtr, indx, vals, b[i], b[i + 1], memKind, p.R, p.S, sideNnz);
+    int rc = build_part(h, side, rowPtr, indx, vals, b[i], b[i + 1], memKind, p.R, p.S, sideNnz, sideSplitNnz);
     if (rc) return rc;
   }
   HIP_TRY(hipStreamSynchronize(h->stream));  // nothing in flight still reads the previous upload
@@ -1754,7 +1808,11 @@ int ycnr_als_bind_factors(ycnr_als *h, int side, void *p) {
 // kernels of one piece of the shard, on the handle's stream, timed by the piece's events
 // branches: the small-upload form (chunks -> reduce, row kernel and dual classes as parallel branches, no per-kernel
 // timing events) that ycnr_als_step_async captures into a hipGraph
-static int launch_part(ycnr_als *h, int side, Part &part, hipStream_t stream, bool branches = false) {
+// inOrder: every kernel of the piece on `stream`, one after the other (a piece of several: two pieces are in flight on the two
+// piece streams and fill each other's tails; side streams per piece cost a fork and a join per side stream, and a wait on an
+// event of ANOTHER hardware queue costs the step's stream tens of microseconds -- in the trace of one GPU's eighth of the
+// MAL-scale user side, 4 pieces, the joins were 100 - 300 us of gaps in a 2.2 ms half-step)
+static int launch_part(ycnr_als *h, int side, Part &part, hipStream_t stream, bool branches = false, bool inOrder = false) {
   const Ratings &R = part.R;
   const Schedule &S = part.S;
   hipEvent_t *ev = branches ? nullptr : part.ev;
@@ -1767,6 +1825,10 @@ static int launch_part(ycnr_als *h, int side, Part &part, hipStream_t stream, bo
                       (const float *)h->dZeros, solvedM, (float *)S.dSlabs, h->dErr, lambda, kk, 0, 0,
                       use_slab_x6(h->opt, side) ? (uint32_t)(h->rows(1 - side) * h->opt.factorsCount * 4) : 0u};
     if (h->kPad) a.kReal = h->opt.factorsCount;
+    if (h->planes[1 - side] && use_planes(h->opt, side)) {
+      a.planes = h->planes[1 - side];
+      a.planesBytes = (uint32_t)(h->rows(1 - side) * planes_row_bytes(slab_nb(h->opt.factorsCount), planes_pack(h->opt.factorsCount)));
+    }
     DualPlan dp;
     dp.noX6 = (h->opt.flags & YCNR_FLAG_NO_BF16X6) != 0;
     if (dual_max_ratings(h->opt) > 0) {
@@ -1775,7 +1837,7 @@ static int launch_part(ycnr_als *h, int side, Part &part, hipStream_t stream, bo
       dp.count = S.dualCount;
       // (the fork and join cost nine more runtime calls per half-step: with a few hundred rows,
       // where the half-step is bound by the launches themselves, they made it slower)
-      if ((S.dualRows >= kMinOverlapDualRows || (branches && S.dualRows > 0)) && !(h->opt.flags & YCNR_FLAG_NO_OVERLAP) && !env_flags().noOverlap) {
+      if ((S.dualRows >= kMinOverlapDualRows || (branches && S.dualRows > 0)) && !inOrder && !(h->opt.flags & YCNR_FLAG_NO_OVERLAP) && !env_flags().noOverlap) {
         dp.nSide = side_streams();
         for (int i = 0; i < dp.nSide; ++i) {
           dp.side[i] = h->sideStream[i];
@@ -1869,6 +1931,17 @@ int ycnr_als_step_async(ycnr_als *h, int side) {
     }
     if (int rcb = ipc_enter(h->comm)) return rcb;  // push transport: no peer is still preparing its replica
   }
+  // (behind the completion of a pending IPC half-step above: the planes are read from the matrix the peers were pushing into)
+  if (use_planes(h->opt, side)) {
+    // the fixed matrix of this half-step as bf16 planes, once for all its waves (12.7 K x 100 floats at MAL scale: microseconds)
+    const int s = 1 - side, nb = slab_nb(h->opt.factorsCount);
+    const bool pack = planes_pack(h->opt.factorsCount);
+    if (!h->planes[s]) HIP_TRY(hipMalloc(&h->planes[s], (size_t)h->rows(s) * (size_t)planes_row_bytes(nb, pack)));
+    const int64_t n = h->rows(s) * nb * 4;
+    hipLaunchKernelGGL(als_split_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, (const float *)h->factors[s], h->planes[s],
+                       h->rows(s), h->opt.factorsCount, nb, pack ? 1 : 0);
+    HIP_TRY(hipGetLastError());
+  }
   memset(&h->info, 0, sizeof h->info);
   // Small uploads (the ML-100k / ML-1M shapes): ~15 launches, forks and joins of a half-step whose kernels each fill a
   // fraction of the chip.  Captured once in the branch form (launch_part) and replayed: one launch per half-step.
@@ -1912,7 +1985,8 @@ int ycnr_als_step_async(ycnr_als *h, int side) {
   }
   for (size_t c = 0; c < parts.size() && !h->graphRun; ++c) {
     hipStream_t ps = twoStreams ? h->pieceStream[c & 1] : h->stream;
-    int rc = launch_part(h, side, parts[c], ps);
+    static const bool pieceSides = getenv("YCNR_PIECE_SIDE_STREAMS") != nullptr;  // A/B: round 3's form (side streams inside every piece)
+    int rc = launch_part(h, side, parts[c], ps, false, twoStreams && !pieceSides);
     if (rc) return rc;
     if (exchange) {
       part_ranges(h, side, (int)c, xb, xe);

@@ -6,6 +6,9 @@
 (function () {
   'use strict';
 
+  // read by the HIP runtime when it starts (first HIP call of the process): the row kernel and every dual class of a
+  // half-step on a hardware queue of their own (python/ycnr_als/_lib.py does the same)
+  if (!process.env.GPU_MAX_HW_QUEUES) process.env.GPU_MAX_HW_QUEUES = '8';
   var native = require('../addon/ycnr_als.node');
 
   // cpp_utils/cpp_utils.js:6-13

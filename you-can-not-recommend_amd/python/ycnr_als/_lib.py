@@ -6,6 +6,11 @@ every call that fails raises YcnrError carrying ycnr_last_error().
 import ctypes as C
 import os
 
+# The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default) and reads the variable when
+# it starts: with 8, the row kernel and every dual class of a half-step get a queue of their own (libycnr_als.so sets the
+# same default when it is loaded before the first HIP call; here for hosts that import this package first).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.normpath(os.path.join(_HERE, "..", "..", "csrc"))
 # YCNR_ALS_LIB selects another build of the same library (A/B tests of kernel variants)
