@@ -126,6 +126,8 @@ struct Schedule {
   Unit *dUnits = nullptr;
   SplitRow *dSplit = nullptr;
   void *dSlabs = nullptr;
+  FoldTask *dFold = nullptr;   // k <= 128: groups of slabs of rows with more than kFoldGroup slabs (als_slab_fold_kernel)
+  int64_t nFold = 0;
   float *dRowSlabs = nullptr;  // k > 240: the images of a batch of whole rows between their Gramian and their two-wave solve
   int64_t rowSlabRows = 0;
   int64_t nUnits = 0, nSplit = 0, nSlabs = 0, solvedRows = 0, fusedRatings = 0;
@@ -138,6 +140,9 @@ struct Schedule {
     if (dSplit) (void)hipFree(dSplit);
     if (dSlabs) (void)hipFree(dSlabs);
     if (dRowSlabs) (void)hipFree(dRowSlabs);
+    if (dFold) (void)hipFree(dFold);
+    dFold = nullptr;
+    nFold = 0;
     dRowSlabs = nullptr;
     rowSlabRows = 0;
     dUnits = nullptr;
@@ -284,6 +289,8 @@ struct DualPlan {
   // replayed (ycnr_als_step_async), so the forks and joins cost nothing per half-step.
   hipStream_t slabStream = nullptr;
   hipEvent_t slabJoin = nullptr;
+  const FoldTask *fold = nullptr;  // rows of many slabs: groups folded between the chunk kernel and the reduce
+  int64_t nFold = 0;
 };
 
 template <int M>
@@ -415,6 +422,10 @@ int launch_nbe(StepArgs<T> args, int64_t nUnits, int64_t nSplitUnits, int64_t nS
     HIP_TRY(hipStreamWaitEvent(dp.slabStream, dp.fork, 0));
     hipLaunchKernelGGL(k0, dim3((unsigned)nSplitUnits), dim3(64), 0, dp.slabStream, args);
     HIP_TRY(hipGetLastError());
+    if (dp.nFold > 0) {
+      hipLaunchKernelGGL((als_slab_fold_kernel<T, NB, EDGE && !SLABX6>), dim3((unsigned)dp.nFold), dim3(64), 0, dp.slabStream, args, dp.fold);
+      HIP_TRY(hipGetLastError());
+    }
     if (nSplit > 0) {
       hipLaunchKernelGGL(k2, dim3((unsigned)nSplit), dim3(64), lds, dp.slabStream, args);
       HIP_TRY(hipGetLastError());
@@ -423,6 +434,10 @@ int launch_nbe(StepArgs<T> args, int64_t nUnits, int64_t nSplitUnits, int64_t nS
   } else if (nSplitUnits > 0) {
     hipLaunchKernelGGL(k0, dim3((unsigned)nSplitUnits), dim3(64), 0, stream, args);
     HIP_TRY(hipGetLastError());
+    if (dp.nFold > 0) {
+      hipLaunchKernelGGL((als_slab_fold_kernel<T, NB, EDGE && !SLABX6>), dim3((unsigned)dp.nFold), dim3(64), 0, stream, args, dp.fold);
+      HIP_TRY(hipGetLastError());
+    }
   }
   if (ev) HIP_TRY(hipEventRecord(ev[1], stream));
   if (overlap) {  // dual classes first, on the side streams; then the row kernel on this one
@@ -882,6 +897,7 @@ struct ycnr_als {
   // GramX6P: the fixed matrix of a half-step split into bf16 planes once (als_split_planes_kernel), where it is small
   // enough to stay cache-resident (the user half-step: the item matrix); planes[s] belongs to factors[s]
   unsigned short *planes[2] = {nullptr, nullptr};
+  bool planesValid[2] = {false, false};  // the half-step in flight split factors[s] into planes[s]
   int kPad = 0;                          // != 0: factorsCount padded to a multiple of 4 (k > 128, k % 4 != 0)
   float *padded[2] = {nullptr, nullptr};  // [rows x kPad] copies the kernels of that case work on
   bool autoChunk = false;  // options.chunkRatings was 0: sized per upload (auto_chunk)
@@ -1352,7 +1368,9 @@ int ycnr_als_create(const ycnr_als_options *o, ycnr_als **out) {
   hipError_t e = hipStreamCreateWithFlags(&h->ownStream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreate(&h->evComputeEnd);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->evStepStart, hipEventDisableTiming);
-  for (int i = 0; i < side_streams() && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&h->sideStream[i], hipStreamNonBlocking);
+  // (the side streams of the one-piece half-step are created when a half-step first needs them: every stream a process creates
+  // takes a share of the runtime's 4 or 8 hardware queues, and a sharded run -- step's stream, two piece streams, the
+  // communicator's stream -- must not find one of its streams behind another's event waits on a shared queue)
   for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&h->pieceStream[i], hipStreamNonBlocking);
   for (int s = 0; s < 2 && e == hipSuccess; ++s) {
     e = hipMalloc(&h->factors[s], (size_t)h->rows(s) * o->factorsCount * h->ts());
@@ -1614,8 +1632,22 @@ static int build_part(ycnr_als *h, int side, const int64_t *rowPtr, const int32_
   if (S.nSplit) {
     // the reduce kernel takes the rows in this order, one wave each: rows with the most slabs first, so that
     // the 64-slab rows of the most popular items do not start when everything else has finished
-    if (!big && !gen)
+    if (!big && !gen) {
+      std::vector<FoldTask> fold;
+      for (SplitRow &sr : split) {
+        if (sr.nslabs <= kFoldGroup) continue;
+        const int groups = (sr.nslabs + kFoldGroup - 1) / kFoldGroup;
+        for (int gI = 0; gI < groups; ++gI) fold.push_back(FoldTask{sr.slab0 + gI * kFoldGroup, std::min(kFoldGroup, sr.nslabs - gI * kFoldGroup)});
+        sr.nslabs = groups;
+        sr.pad = kFoldGroup;
+      }
+      if (!fold.empty()) {
+        S.nFold = (int64_t)fold.size();
+        HIP_TRY(hipMalloc(&S.dFold, sizeof(FoldTask) * fold.size()));
+        HIP_TRY(hipMemcpy(S.dFold, fold.data(), sizeof(FoldTask) * fold.size(), hipMemcpyHostToDevice));
+      }
       std::stable_sort(split.begin(), split.end(), [](const SplitRow &x, const SplitRow &y) { return x.nslabs > y.nslabs; });
+    }
     HIP_TRY(hipMalloc(&S.dSplit, sizeof(SplitRow) * split.size()));
     HIP_TRY(hipMemcpy(S.dSplit, split.data(), sizeof(SplitRow) * split.size(), hipMemcpyHostToDevice));
     const size_t slabElems = gen ? (size_t)gen_slab_elems(slab_nb(h->opt.factorsCount))
@@ -1825,7 +1857,7 @@ static int launch_part(ycnr_als *h, int side, Part &part, hipStream_t stream, bo
                       (const float *)h->dZeros, solvedM, (float *)S.dSlabs, h->dErr, lambda, kk, 0, 0,
                       use_slab_x6(h->opt, side) ? (uint32_t)(h->rows(1 - side) * h->opt.factorsCount * 4) : 0u};
     if (h->kPad) a.kReal = h->opt.factorsCount;
-    if (h->planes[1 - side] && use_planes(h->opt, side)) {
+    if (h->planes[1 - side] && h->planesValid[1 - side] && use_planes(h->opt, side)) {
       a.planes = h->planes[1 - side];
       a.planesBytes = (uint32_t)(h->rows(1 - side) * planes_row_bytes(slab_nb(h->opt.factorsCount), planes_pack(h->opt.factorsCount)));
     }
@@ -1838,14 +1870,18 @@ static int launch_part(ycnr_als *h, int side, Part &part, hipStream_t stream, bo
       // (the fork and join cost nine more runtime calls per half-step: with a few hundred rows,
       // where the half-step is bound by the launches themselves, they made it slower)
       if ((S.dualRows >= kMinOverlapDualRows || (branches && S.dualRows > 0)) && !inOrder && !(h->opt.flags & YCNR_FLAG_NO_OVERLAP) && !env_flags().noOverlap) {
-        dp.nSide = side_streams();
+        // (a captured small half-step keeps two branches for its dual classes: every branch is a join, 30 - 60 us each)
+        dp.nSide = branches ? std::min(2, side_streams()) : side_streams();
         for (int i = 0; i < dp.nSide; ++i) {
+          if (!h->sideStream[i]) HIP_TRY(hipStreamCreateWithFlags(&h->sideStream[i], hipStreamNonBlocking));
           dp.side[i] = h->sideStream[i];
           dp.join[i] = part.join[i];
         }
       }
     }
     dp.fork = part.fork;
+    dp.fold = S.dFold;
+    dp.nFold = S.nFold;
     if (branches) {
       dp.slabStream = h->pieceStream[0];
       dp.slabJoin = part.slabJoin;
@@ -1871,6 +1907,8 @@ static int launch_part(ycnr_als *h, int side, Part &part, hipStream_t stream, bo
   if (is_gen(YCNR_F64, h->opt.factorsCount)) return launch_step_gen<double>(a, S.genBatches, stream, ev, DualPlan());
   DualPlan dpd;  // float64 has no dual classes; the chunk branch of the small-upload form applies
   dpd.fork = part.fork;
+  dpd.fold = S.dFold;
+  dpd.nFold = S.nFold;
   if (branches) {
     dpd.slabStream = h->pieceStream[0];
     dpd.slabJoin = part.slabJoin;
@@ -1932,16 +1970,26 @@ int ycnr_als_step_async(ycnr_als *h, int side) {
     if (int rcb = ipc_enter(h->comm)) return rcb;  // push transport: no peer is still preparing its replica
   }
   // (behind the completion of a pending IPC half-step above: the planes are read from the matrix the peers were pushing into)
-  if (use_planes(h->opt, side)) {
-    // the fixed matrix of this half-step as bf16 planes, once for all its waves (12.7 K x 100 floats at MAL scale: microseconds)
+  // the fixed matrix of this half-step as bf16 planes, once for all its waves (12.7 K x 100 floats at MAL scale: microseconds);
+  // a replayed graph holds the launch itself (it was captured in front of the piece's kernels)
+  // (not for uploads below kGraphMinRatings, whose half-step is a handful of launches: one more launch costs what the planes save)
+  int64_t sideRatings = 0;
+  for (const Part &p : parts) sideRatings += p.R.nnz;
+  const bool planesNow = use_planes(h->opt, side) && sideRatings >= kGraphMinRatings;
+  if (!planesNow) h->planesValid[1 - side] = false;
+  auto split_planes = [&]() -> int {
+    if (!planesNow) return YCNR_OK;
+    h->planesValid[1 - side] = true;
     const int s = 1 - side, nb = slab_nb(h->opt.factorsCount);
     const bool pack = planes_pack(h->opt.factorsCount);
-    if (!h->planes[s]) HIP_TRY(hipMalloc(&h->planes[s], (size_t)h->rows(s) * (size_t)planes_row_bytes(nb, pack)));
     const int64_t n = h->rows(s) * nb * 4;
     hipLaunchKernelGGL(als_split_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, (const float *)h->factors[s], h->planes[s],
                        h->rows(s), h->opt.factorsCount, nb, pack ? 1 : 0);
     HIP_TRY(hipGetLastError());
-  }
+    return YCNR_OK;
+  };
+  if (planesNow && !h->planes[1 - side])
+    HIP_TRY(hipMalloc(&h->planes[1 - side], (size_t)h->rows(1 - side) * (size_t)planes_row_bytes(slab_nb(h->opt.factorsCount), planes_pack(h->opt.factorsCount))));
   memset(&h->info, 0, sizeof h->info);
   // Small uploads (the ML-100k / ML-1M shapes): ~15 launches, forks and joins of a half-step whose kernels each fill a
   // fraction of the chip.  Captured once in the branch form (launch_part) and replayed: one launch per half-step.
@@ -1952,10 +2000,13 @@ int ycnr_als_step_async(ycnr_als *h, int side) {
                            parts[0].R.nnz < kGraphMaxRatings && parts[0].R.nnz >= kGraphMinRatings && h->stream == h->ownStream &&
                            !(h->opt.flags & (YCNR_FLAG_NO_OVERLAP | YCNR_FLAG_NO_GRAPH)) && !env_flags().noOverlap && !env_flags().noGraph;
     if (graphable && gs.state == 1) {
+      for (int i = 0; i < side_streams(); ++i)  // (not inside the capture)
+        if (!h->sideStream[i]) HIP_TRY(hipStreamCreateWithFlags(&h->sideStream[i], hipStreamNonBlocking));
       gs.state = -1;
       hipGraph_t g = nullptr;
       if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed) == hipSuccess) {
-        int rc = launch_part(h, side, parts[0], h->stream, true);
+        int rc = split_planes();
+        if (rc == YCNR_OK) rc = launch_part(h, side, parts[0], h->stream, true);
         hipError_t ce = hipMemcpyAsync(h->hErr, h->dErr, sizeof(ErrInfo), hipMemcpyDeviceToHost, h->stream);
         hipError_t ee = hipStreamEndCapture(h->stream, &g);
         if (rc == YCNR_OK && ce == hipSuccess && ee == hipSuccess && g && hipGraphInstantiate(&gs.exec, g, nullptr, nullptr, 0) == hipSuccess)
@@ -1974,6 +2025,8 @@ int ycnr_als_step_async(ycnr_als *h, int side) {
       h->graphRun = true;
     }
   }
+  if (!h->graphRun)
+    if (int rcs = split_planes()) return rcs;
   std::vector<int64_t> xb, xe;
   // several pieces: alternating over the two piece streams (unless YCNR_FLAG_NO_OVERLAP / the staged SHM stand-in,
   // whose exchange blocks the host); one piece: on the step's stream itself
@@ -1994,11 +2047,14 @@ int ycnr_als_step_async(ycnr_als *h, int side) {
                          parts[c].x0, parts[c].x1, &h->info.exchangeBytes);
       if (rc) return rc;
     }
-    if (twoStreams && c + 2 >= parts.size()) {  // the last piece of each stream joins the step's stream
-      HIP_TRY(hipEventRecord(parts[c].done, ps));
-      HIP_TRY(hipStreamWaitEvent(h->stream, parts[c].done, 0));
-    }
+    if (twoStreams && c + 2 >= parts.size()) HIP_TRY(hipEventRecord(parts[c].done, ps));  // the last piece of each stream
   }
+  // ... joins the step's stream -- enqueued only now, behind every piece's launches: streams share hardware queues (the
+  // runtime has 4 or 8 for all the streams of a process), a hardware queue is served in order, and a wait for piece c enqueued
+  // on the step's stream BEFORE the launches of piece c + 1 held those launches back whenever the two streams shared a queue
+  // (kernel trace of one GPU's eighth of the MAL-scale user side: the fourth piece started when the third had ended).
+  if (twoStreams && !h->graphRun)
+    for (size_t c = parts.size() >= 2 ? parts.size() - 2 : 0; c < parts.size(); ++c) HIP_TRY(hipStreamWaitEvent(h->stream, parts[c].done, 0));
   if (exchange) {
     HIP_TRY(hipEventRecord(h->evComputeEnd, h->stream));
     if (h->comm.transport != YCNR_COMM_SHM) HIP_TRY(hipStreamWaitEvent(h->stream, parts.back().x1, 0));  // (SHM is synchronous)
