@@ -218,16 +218,24 @@ def main():
         dual_by = i.dualRatings * bytes_rating + i.dualRows * (k * s + 8)
         # (priced on the fp32 pipe as a whole: the library reports one flop count per row class)
         dual_k = ("als_dual_solve_kernel", i.dualSolveMs, 0.0, i.dualFlops, dual_by)
+        slab_in_group = False
         if i.dualOverlapped:
-            # the dual kernels ran on side streams next to the row kernel: one group, one wall time
-            whole_rows = (("als_gram_solve_kernel+als_dual_solve_kernel", row_k[1] + dual_k[1], row_k[2], row_k[3] + dual_k[3],
-                           row_k[4] + dual_by),)
+            # the dual kernels ran on side streams next to the row kernel: one group, one wall time.  They are forked BEFORE
+            # the chunk kernel of the step's stream, so that kernel shares its interval with them too (with a side stream per
+            # dual class its own event interval is mostly their time): the group spans chunk kernel + row kernel + dual classes
+            slab_in_group = not gen_path and i.parts == 1 and i.gramSlabMs > 0
+            whole_rows = (("als_gram_solve_kernel+als_dual_solve_kernel" + ("+als_gram_slab_kernel" if slab_in_group else ""),
+                           row_k[1] + dual_k[1] + (i.gramSlabMs if slab_in_group else 0.0),
+                           row_k[2] + (chunk_ratings * gram_rating if slab_in_group else 0.0), row_k[3] + dual_k[3],
+                           row_k[4] + dual_by + (chunk_ratings * bytes_rating if slab_in_group else 0.0)),)
         else:
             whole_rows = (row_k, dual_k)
         if gen_path:
             # the any-k path reports its Gramian -> slab and slab -> solve kernels (batches of both) as one interval
             split_k = (("als_gen_gram_kernel+als_gen_solve_kernel", i.gramSlabMs + i.reduceSolveMs, 0.0,
                         chunk_ratings * gram_rating + i.splitRows * solve_row, chunk_ratings * bytes_rating + i.splitRows * (k * s + 8)),)
+        elif slab_in_group:
+            split_k = (("als_reduce_solve_kernel", i.reduceSolveMs, 0.0, i.splitRows * solve_row, i.splitRows * (k * s + 8)),)
         else:
             split_k = (("als_gram_slab_kernel", i.gramSlabMs, chunk_ratings * gram_rating, 0.0, chunk_ratings * bytes_rating),
                        ("als_reduce_solve_kernel", i.reduceSolveMs, 0.0, i.splitRows * solve_row, i.splitRows * (k * s + 8)))

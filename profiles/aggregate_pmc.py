@@ -23,6 +23,8 @@ import sys
 # kernel name fragment -> bench.py's entry (the workgroup-per-row kernels of k > 128, als_wg_*, fill the same roles)
 BENCH_NAME = (("gram_solve", "als_gram_solve_kernel"), ("dual_solve", "als_dual_solve_kernel"),
               ("gram_slab", "als_gram_slab_kernel"), ("reduce_solve", "als_reduce_solve_kernel"),
+              # round 4: rows of many slabs are folded in groups before the reduce; its traffic belongs to the reduce entry
+              ("slab_fold", "als_reduce_solve_kernel"),
               # k > 240: whole rows go Gramian -> slab -> few-wave solve in BATCHES (als_pair_kernels.hip.h); together they
               # are bench.py's als_gram_solve_kernel entry, one "launch" = all batches of a half-step
               ("gram_rowslab", "als_gram_solve_kernel"), ("slab_solve2", "als_gram_solve_kernel"))
@@ -57,7 +59,7 @@ def main():
         if seen:
             if "reduce_solve" in prev:
                 new_half = True
-            elif slab and "gram_slab" not in prev:
+            elif slab and "gram_slab" not in prev and "split_planes" not in prev:  # (the planes kernel opens a half-step in front of its slab kernel)
                 new_half = True
             elif n in seen and not slab and n != "batched_rows":
                 new_half = True
@@ -97,6 +99,11 @@ def main():
         if a and b:
             traffic[f"als_gram_solve_kernel+als_dual_solve_kernel[{side}]"] = {
                 "kb": a["kb"] / a["launches"] + b["kb"] / b["launches"], "launches": 1}
+        # round 4: with a side stream per dual class the chunk kernel of the step's stream shares the group's interval too
+        g, c = traffic.get(f"als_gram_solve_kernel+als_dual_solve_kernel[{side}]"), traffic.get(f"als_gram_slab_kernel[{side}]")
+        if g and c:
+            traffic[f"als_gram_solve_kernel+als_dual_solve_kernel+als_gram_slab_kernel[{side}]"] = {
+                "kb": g["kb"] / g["launches"] + c["kb"] / c["launches"], "launches": 1}
     tpath = os.path.join(here, "traffic.json")
     tj = json.load(open(tpath)) if os.path.exists(tpath) else {"workloads": {}}
     tj.setdefault("sources", {})[workload] = (f"profiles/{tag}_{workload}_pmc_by_kernel.json: (2 x FETCH_SIZE + WRITE_SIZE) KB per launch, "
