@@ -76,8 +76,8 @@ struct SplitRow {
   int64_t n;  // ratings of the row (for lambda * n)
   int32_t row;
   int32_t slab0;
-  int32_t nslabs;  // slabs to add (after als_slab_fold_kernel: sums of groups of slabs)
-  int32_t pad;     // > 1: the stride between them (kFoldGroup: the row was folded)
+  int32_t nslabs;
+  int32_t pad;
 };
 
 struct ErrInfo {
@@ -2736,29 +2736,7 @@ __global__ __launch_bounds__(64) void als_dual_quad_kernel(StepArgs<float> a, in
   }
 }
 
-// Kernel 2a (round 4): rows of many slabs are folded first -- one wave per group of kFoldGroup consecutive slabs adds them, in
-// slab order, into the group's first slab; the reduce kernel then adds the groups' sums in group order (SplitRow.pad = the
-// stride between them).  A 64-slab row was one wave reading 1.9 MB in sequence (the tail of the item half-step: 0.45 ms at MAL
-// scale for 1.2 GB of slabs, 0.16 ms of a rank's 1.5 ms); now its longest chain is 8 + 8 slabs.  The order of the sums is
-// fixed by the row's chunks, i.e. by the side, not by the launch or the number of GPUs.
-struct FoldTask {
-  int32_t first;  // slab that receives the sum of slabs [first, first + count)
-  int32_t count;
-};
-constexpr int kFoldGroup = 8;
-
-template <typename T, int NB, bool EDGE>
-__global__ __launch_bounds__(64) void als_slab_fold_kernel(StepArgs<T> a, const FoldTask *tasks) {
-  using G = typename GramSel<T, NB, EDGE>::type;
-  const int lane = threadIdx.x;
-  const FoldTask t = tasks[blockIdx.x];
-  typename G::State st;
-  G::init(st);
-  for (int sl = 0; sl < t.count; ++sl) G::add_slab(st, a.slabs + (int64_t)(t.first + sl) * (G::slab_regs() * 64) + lane);
-  G::store_slab(st, a.slabs + (int64_t)t.first * (G::slab_regs() * 64) + lane);
-}
-
-// Kernel 2: one wave per split row -- sum its slabs (or the sums of its groups of slabs) in slab order, then solve.
+// Kernel 2: one wave per split row -- sum its slabs in slab order, then solve.
 template <typename T, int NB, bool LDS_SOLVER, bool EDGE, bool E4 = false>
 __global__ __launch_bounds__(64) void als_reduce_solve_kernel(StepArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -2768,8 +2746,7 @@ __global__ __launch_bounds__(64) void als_reduce_solve_kernel(StepArgs<T> a) {
   const SplitRow sr = a.split[blockIdx.x];
   typename G::State st;
   G::init(st);
-  const int stride = sr.pad > 1 ? sr.pad : 1;
-  for (int sl = 0; sl < sr.nslabs; ++sl) G::add_slab(st, a.slabs + (int64_t)(sr.slab0 + sl * stride) * (G::slab_regs() * 64) + lane);
+  for (int sl = 0; sl < sr.nslabs; ++sl) G::add_slab(st, a.slabs + (int64_t)(sr.slab0 + sl) * (G::slab_regs() * 64) + lane);
   acc_t acc[G::NT];
   T bacc[NB];
   G::to_tiles(st, acc, bacc, reinterpret_cast<T *>(smem), lane);

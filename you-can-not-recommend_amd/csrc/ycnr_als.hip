@@ -126,8 +126,6 @@ struct Schedule {
   Unit *dUnits = nullptr;
   SplitRow *dSplit = nullptr;
   void *dSlabs = nullptr;
-  FoldTask *dFold = nullptr;   // k <= 128: groups of slabs of rows with more than kFoldGroup slabs (als_slab_fold_kernel)
-  int64_t nFold = 0;
   float *dRowSlabs = nullptr;  // k > 240: the images of a batch of whole rows between their Gramian and their two-wave solve
   int64_t rowSlabRows = 0;
   int64_t nUnits = 0, nSplit = 0, nSlabs = 0, solvedRows = 0, fusedRatings = 0;
@@ -140,9 +138,6 @@ struct Schedule {
     if (dSplit) (void)hipFree(dSplit);
     if (dSlabs) (void)hipFree(dSlabs);
     if (dRowSlabs) (void)hipFree(dRowSlabs);
-    if (dFold) (void)hipFree(dFold);
-    dFold = nullptr;
-    nFold = 0;
     dRowSlabs = nullptr;
     rowSlabRows = 0;
     dUnits = nullptr;
@@ -289,8 +284,6 @@ struct DualPlan {
   // replayed (ycnr_als_step_async), so the forks and joins cost nothing per half-step.
   hipStream_t slabStream = nullptr;
   hipEvent_t slabJoin = nullptr;
-  const FoldTask *fold = nullptr;  // rows of many slabs: groups folded between the chunk kernel and the reduce
-  int64_t nFold = 0;
 };
 
 template <int M>
@@ -422,10 +415,6 @@ int launch_nbe(StepArgs<T> args, int64_t nUnits, int64_t nSplitUnits, int64_t nS
     HIP_TRY(hipStreamWaitEvent(dp.slabStream, dp.fork, 0));
     hipLaunchKernelGGL(k0, dim3((unsigned)nSplitUnits), dim3(64), 0, dp.slabStream, args);
     HIP_TRY(hipGetLastError());
-    if (dp.nFold > 0) {
-      hipLaunchKernelGGL((als_slab_fold_kernel<T, NB, EDGE && !SLABX6>), dim3((unsigned)dp.nFold), dim3(64), 0, dp.slabStream, args, dp.fold);
-      HIP_TRY(hipGetLastError());
-    }
     if (nSplit > 0) {
       hipLaunchKernelGGL(k2, dim3((unsigned)nSplit), dim3(64), lds, dp.slabStream, args);
       HIP_TRY(hipGetLastError());
@@ -434,10 +423,6 @@ int launch_nbe(StepArgs<T> args, int64_t nUnits, int64_t nSplitUnits, int64_t nS
   } else if (nSplitUnits > 0) {
     hipLaunchKernelGGL(k0, dim3((unsigned)nSplitUnits), dim3(64), 0, stream, args);
     HIP_TRY(hipGetLastError());
-    if (dp.nFold > 0) {
-      hipLaunchKernelGGL((als_slab_fold_kernel<T, NB, EDGE && !SLABX6>), dim3((unsigned)dp.nFold), dim3(64), 0, stream, args, dp.fold);
-      HIP_TRY(hipGetLastError());
-    }
   }
   if (ev) HIP_TRY(hipEventRecord(ev[1], stream));
   if (overlap) {  // dual classes first, on the side streams; then the row kernel on this one
@@ -1632,22 +1617,8 @@ static int build_part(ycnr_als *h, int side, const int64_t *rowPtr, const int32_
   if (S.nSplit) {
     // the reduce kernel takes the rows in this order, one wave each: rows with the most slabs first, so that
     // the 64-slab rows of the most popular items do not start when everything else has finished
-    if (!big && !gen) {
-      std::vector<FoldTask> fold;
-      for (SplitRow &sr : split) {
-        if (sr.nslabs <= kFoldGroup) continue;
-        const int groups = (sr.nslabs + kFoldGroup - 1) / kFoldGroup;
-        for (int gI = 0; gI < groups; ++gI) fold.push_back(FoldTask{sr.slab0 + gI * kFoldGroup, std::min(kFoldGroup, sr.nslabs - gI * kFoldGroup)});
-        sr.nslabs = groups;
-        sr.pad = kFoldGroup;
-      }
-      if (!fold.empty()) {
-        S.nFold = (int64_t)fold.size();
-        HIP_TRY(hipMalloc(&S.dFold, sizeof(FoldTask) * fold.size()));
-        HIP_TRY(hipMemcpy(S.dFold, fold.data(), sizeof(FoldTask) * fold.size(), hipMemcpyHostToDevice));
-      }
+    if (!big && !gen)
       std::stable_sort(split.begin(), split.end(), [](const SplitRow &x, const SplitRow &y) { return x.nslabs > y.nslabs; });
-    }
     HIP_TRY(hipMalloc(&S.dSplit, sizeof(SplitRow) * split.size()));
     HIP_TRY(hipMemcpy(S.dSplit, split.data(), sizeof(SplitRow) * split.size(), hipMemcpyHostToDevice));
     const size_t slabElems = gen ? (size_t)gen_slab_elems(slab_nb(h->opt.factorsCount))
@@ -1880,8 +1851,6 @@ static int launch_part(ycnr_als *h, int side, Part &part, hipStream_t stream, bo
       }
     }
     dp.fork = part.fork;
-    dp.fold = S.dFold;
-    dp.nFold = S.nFold;
     if (branches) {
       dp.slabStream = h->pieceStream[0];
       dp.slabJoin = part.slabJoin;
@@ -1907,8 +1876,6 @@ static int launch_part(ycnr_als *h, int side, Part &part, hipStream_t stream, bo
   if (is_gen(YCNR_F64, h->opt.factorsCount)) return launch_step_gen<double>(a, S.genBatches, stream, ev, DualPlan());
   DualPlan dpd;  // float64 has no dual classes; the chunk branch of the small-upload form applies
   dpd.fork = part.fork;
-  dpd.fold = S.dFold;
-  dpd.nFold = S.nFold;
   if (branches) {
     dpd.slabStream = h->pieceStream[0];
     dpd.slabJoin = part.slabJoin;
