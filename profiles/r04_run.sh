@@ -25,6 +25,8 @@ import json
 d=json.loads(open('gpurun_out/${TAG}_${wl}_emulate8.json').read().strip().splitlines()[-1])
 for c in ('cost_model_cut','after_feedback_recut'):
     x=d[c]; print(c, 'user', x['byUser']['compute_ms'], 'item', x['byItem']['compute_ms'], 'slowest', x['iteration_ms_slowest_rank'])" || tail -3 gpurun_out/${TAG}_${wl}_emulate8.err ;;
+    prof) wl=$1; shift; bash profiles/collect.sh ${TAG}_$wl $wl ;;
+    prep) timeout -k 10 900 python prep_bench.py > gpurun_out/${TAG}_prep_bench.json 2> gpurun_out/${TAG}_prep_bench.err; cut -c1-700 gpurun_out/${TAG}_prep_bench.json ;;
     trace) name=$1; shift; args=$1; shift
       # kernel trace with timestamps of one bench command (args quoted as one word)
       rocprofv3 --kernel-trace --stats -d gpurun_out/${TAG}_trace_$name -o t -- python3 bench.py $args --no-cpu-baseline > gpurun_out/${TAG}_trace_$name.json 2> gpurun_out/${TAG}_trace_$name.err

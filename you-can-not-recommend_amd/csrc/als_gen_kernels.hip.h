@@ -9,9 +9,9 @@
 // with the same 16 x 16 MFMA tiles (v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64: exact IEEE fma chains):
 //
 //   als_gen_gram_kernel   one 256-thread workgroup per unit (a row, or a chunk of a long row): upper tiles of
-//                         Y^T Y and b = Y^T r into the unit's slab.  A wave takes a strip of four tiles of one
-//                         block row at a time: operands straight from global memory in MFMA layout (lane (g, c):
-//                         factor 16 cb + c of rating n0 + g -- one element, any k, no alignment demands).
+//                         Y^T Y and b = Y^T r into the unit's slab.  A wave takes a square of 4 x 4 tiles at a time
+//                         (round 4; strips of four tiles before): operands straight from global memory in MFMA layout
+//                         (lane (g, c): factor 16 cb + c of rating n0 + g -- one element, any k, no alignment demands).
 //   als_gen_solve_kernel  one workgroup per row: slabs summed in slab order into the first (fixed order: results do
 //                         not depend on launch geometry), + lambda n I, then per block step
 //                            wave 0: diagonal tile -> L (16 pivots) and W = L^-1 through a small LDS image
@@ -32,7 +32,6 @@ namespace ycnr {
 
 constexpr int kGenWaves = 4;
 constexpr int kGenThreads = kGenWaves * 64;
-constexpr int kGenStrip = 4;  // tiles of one block row a wave accumulates at a time
 
 __host__ __device__ constexpr int64_t gen_slab_elems(int nb) { return (int64_t)tile_count(nb) * 256 + (int64_t)nb * 16; }
 
@@ -62,6 +61,12 @@ __device__ __forceinline__ void gen_st_tile(T *tile, int lane, const typename Mf
   for (int t = 0; t < 4; ++t) tile[t * 64 + lane] = v[t];
 }
 
+// Work item of a wave: a SQUARE of kGenSq x kGenSq tiles (block rows bi0.., block columns bj0.., bi0 <= bj0; on the diagonal only
+// the upper tiles).  Per 4-rating step it loads kGenSq A values and kGenSq B values for kGenSq^2 MFMAs -- round 3's strips of
+// four tiles of ONE block row loaded 5 values per 4 MFMAs and walked the unit's ratings 3.7 x as often (k = 512: 132 strips
+// against 36 squares), every walk re-reading the gathered rows from L2: the kernel was bound by that traffic.
+constexpr int kGenSq = 4;
+
 template <typename T>
 __global__ __launch_bounds__(kGenThreads) void als_gen_gram_kernel(GenArgs<T> ga) {
   using Tr = MfmaTraits<T>;
@@ -75,41 +80,57 @@ __global__ __launch_bounds__(kGenThreads) void als_gen_gram_kernel(GenArgs<T> ga
   T *slab = a.slabs + (int64_t)(u.slab - ga.slabBase) * gen_slab_elems(NB);
   T *bout = slab + (int64_t)tile_count(NB) * 256;
   const int64_t nsteps = (n + 3) >> 2;
-  // work items: (bi, strip of kGenStrip tiles starting at bj0), bi <= bj0, dealt round-robin over the waves
   int item = 0;
-  for (int bi = 0; bi < NB; ++bi) {
-    for (int bj0 = bi; bj0 < NB; bj0 += kGenStrip, ++item) {
+  for (int bi0 = 0; bi0 < NB; bi0 += kGenSq) {
+    for (int bj0 = bi0; bj0 < NB; bj0 += kGenSq, ++item) {
       if ((item % kGenWaves) != wave) continue;
-      acc_t acc[kGenStrip];
+      const bool diag = bj0 == bi0;
+      acc_t acc[kGenSq][kGenSq];
 #pragma unroll
-      for (int s = 0; s < kGenStrip; ++s) acc[s] = acc_t{T(0), T(0), T(0), T(0)};
-      T bacc = T(0);
-      const int colA = 16 * bi + c;
+      for (int i = 0; i < kGenSq; ++i)
+#pragma unroll
+        for (int j = 0; j < kGenSq; ++j) acc[i][j] = acc_t{T(0), T(0), T(0), T(0)};
+      T bacc[kGenSq];
+#pragma unroll
+      for (int i = 0; i < kGenSq; ++i) bacc[i] = T(0);
       for (int64_t st = 0; st < nsteps; ++st) {
         const int64_t q = (st << 2) + g;
         const bool live = q < n;
         const int64_t qc = u.beg + (live ? q : n - 1);
         const T *row = a.fixed + (int64_t)a.indx[qc] * k;
         const T r = live ? a.vals[qc] : T(0);
-        const T ya = (live && colA < k) ? row[colA] : T(0);
-        if (bj0 == bi) bacc = fma(ya, r, bacc);  // b rides with the strip that holds the diagonal tile
+        T ya[kGenSq], yb[kGenSq];
 #pragma unroll
-        for (int s = 0; s < kGenStrip; ++s) {
-          const int bj = bj0 + s;
-          if (bj < NB) {  // wave-uniform
-            const int colB = 16 * bj + c;
-            const T yb = (live && colB < k) ? row[colB] : T(0);
-            acc[s] = Tr::mma(ya, yb, acc[s]);
+        for (int i = 0; i < kGenSq; ++i) {
+          const int colA = 16 * (bi0 + i) + c, colB = 16 * (bj0 + i) + c;
+          ya[i] = (live && colA < k) ? row[colA] : T(0);
+          yb[i] = diag ? ya[i] : ((live && colB < k) ? row[colB] : T(0));
+        }
+        if (diag) {  // b rides with the squares on the diagonal (wave-uniform)
+#pragma unroll
+          for (int i = 0; i < kGenSq; ++i) bacc[i] = fma(ya[i], r, bacc[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < kGenSq; ++i) {
+#pragma unroll
+          for (int j = 0; j < kGenSq; ++j) {
+            if (bi0 + i < NB && bj0 + j < NB && (!diag || j >= i))  // wave-uniform
+              acc[i][j] = Tr::mma(ya[i], yb[j], acc[i][j]);
           }
         }
       }
 #pragma unroll
-      for (int s = 0; s < kGenStrip; ++s)
-        if (bj0 + s < NB) gen_st_tile<T>(slab + (int64_t)tile_index(bi, bj0 + s, NB) * 256, lane, acc[s]);
-      if (bj0 == bi) {
-        bacc += gen_shfl_xor<T>(bacc, 16);
-        bacc += gen_shfl_xor<T>(bacc, 32);
-        if (g == 0) bout[16 * bi + c] = bacc;
+      for (int i = 0; i < kGenSq; ++i) {
+#pragma unroll
+        for (int j = 0; j < kGenSq; ++j)
+          if (bi0 + i < NB && bj0 + j < NB && (!diag || j >= i))
+            gen_st_tile<T>(slab + (int64_t)tile_index(bi0 + i, bj0 + j, NB) * 256, lane, acc[i][j]);
+        if (diag && bi0 + i < NB) {
+          T bs = bacc[i];
+          bs += gen_shfl_xor<T>(bs, 16);
+          bs += gen_shfl_xor<T>(bs, 32);
+          if (g == 0) bout[16 * (bi0 + i) + c] = bs;
+        }
       }
     }
   }
