@@ -64,7 +64,9 @@ __device__ __forceinline__ void gen_st_tile(T *tile, int lane, const typename Mf
 // Work item of a wave: a SQUARE of kGenSq x kGenSq tiles (block rows bi0.., block columns bj0.., bi0 <= bj0; on the diagonal only
 // the upper tiles).  Per 4-rating step it loads kGenSq A values and kGenSq B values for kGenSq^2 MFMAs -- round 3's strips of
 // four tiles of ONE block row loaded 5 values per 4 MFMAs and walked the unit's ratings 3.7 x as often (k = 512: 132 strips
-// against 36 squares), every walk re-reading the gathered rows from L2: the kernel was bound by that traffic.
+// against 36 squares), every walk re-reading the gathered rows from L2: the kernel was bound by that traffic.  200 K x 20 K,
+// 20 M ratings: k = 512 float32 902 -> 606 ms per iteration, k = 256 float64 513 -> 460.  (Operands requested one step
+// ahead by hand: 702 ms -- the registers cost a wave per SIMD.)
 constexpr int kGenSq = 4;
 
 template <typename T>
