@@ -26,6 +26,10 @@ d=json.loads(open('gpurun_out/${TAG}_${wl}_emulate8.json').read().strip().splitl
 for c in ('cost_model_cut','after_feedback_recut'):
     x=d[c]; print(c, 'user', x['byUser']['compute_ms'], 'item', x['byItem']['compute_ms'], 'slowest', x['iteration_ms_slowest_rank'])" || tail -3 gpurun_out/${TAG}_${wl}_emulate8.err ;;
     prof) wl=$1; shift; bash profiles/collect.sh ${TAG}_$wl $wl ;;
+    stats) name=$1; shift; args=$1; shift
+      # per-kernel averages of one bench command (args quoted as one word)
+      R=$PWD; (cd /tmp && timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats_$name -o p -- python3 $R/bench.py $args --steps 1 --warmup 1 --no-cpu-baseline > $R/gpurun_out/${TAG}_stats_$name.log 2>&1)
+      python3 profiles/kernel_times.py gpurun_out/${TAG}_stats_$name ;;
     prep) timeout -k 10 900 python prep_bench.py > gpurun_out/${TAG}_prep_bench.json 2> gpurun_out/${TAG}_prep_bench.err; cut -c1-700 gpurun_out/${TAG}_prep_bench.json ;;
     trace) name=$1; shift; args=$1; shift
       # kernel trace with timestamps of one bench command (args quoted as one word)

@@ -61,66 +61,187 @@ __device__ __forceinline__ void gen_st_tile(T *tile, int lane, const typename Mf
   for (int t = 0; t < 4; ++t) tile[t * 64 + lane] = v[t];
 }
 
-// Work item of a wave: a SQUARE of kGenSq x kGenSq tiles (block rows bi0.., block columns bj0.., bi0 <= bj0; on the diagonal only
-// the upper tiles).  Per 4-rating step it loads kGenSq A values and kGenSq B values for kGenSq^2 MFMAs -- round 3's strips of
-// four tiles of ONE block row loaded 5 values per 4 MFMAs and walked the unit's ratings 3.7 x as often (k = 512: 132 strips
-// against 36 squares), every walk re-reading the gathered rows from L2: the kernel was bound by that traffic.  200 K x 20 K,
-// 20 M ratings: k = 512 float32 902 -> 606 ms per iteration, k = 256 float64 513 -> 460.  (Operands requested one step
-// ahead by hand: 702 ms -- the registers cost a wave per SIMD.)
+// Gramian of a unit (round 4, second form).  The first form let every wave gather its operands itself, one element per lane and
+// MFMA operand, a square of 4 x 4 tiles at a time: each step waited for an index and then for the values behind it (two trips
+// to the cache per 16 MFMAs, nothing requested ahead), and a k = 512 unit was walked 36 times.  Here the workgroup stages
+// PANELS of R ratings x k factors in LDS (whole 16-byte loads where every row of the fixed matrix is 16-byte aligned; the
+// values of panel p + 1 and the ids of panel p + 2 are requested before panel p is multiplied; two LDS buffers, one barrier
+// per panel) and every wave keeps ONE square of kGenSq x kGenSq tiles in registers per pass over the unit's ratings, its operands
+// read from the panel in MFMA layout (lane (g, c): factor 16 cb + c of rating 4 s + g; the row pitch P puts the four lane
+// groups on different banks).  Passes = squares / waves: 5 at k = 512 with eight waves, 2 at k = 256 with five.
+// 200 K x 20 K, 20 M ratings, per iteration: k = 512 float32 902 (strips) -> 606 (squares from cache) -> see DESIGN.md.
 constexpr int kGenSq = 4;
+constexpr int kGenGramMaxWaves = 8;
+#ifndef YCNR_GEN_GRAM_WAVES_PER_SIMD
+#define YCNR_GEN_GRAM_WAVES_PER_SIMD 2  // one workgroup of eight waves per CU
+#endif
 
-template <typename T>
-__global__ __launch_bounds__(kGenThreads) void als_gen_gram_kernel(GenArgs<T> ga) {
+template <typename T, int V>
+struct alignas(sizeof(T) * V) GenVec {
+  T e[V];
+};
+
+__host__ __device__ constexpr int gen_squares(int nb) {
+  const int m = (nb + kGenSq - 1) / kGenSq;
+  return m * (m + 1) / 2;
+}
+// row pitch of a panel in elements: a multiple of 16, P * sizeof(T) = 64 bytes modulo 256 (float32) / 128 modulo 256 (float64)
+__host__ __device__ constexpr int gen_panel_pitch(int nb, size_t ts) {
+  const int mod = (int)(256 / ts);
+  return nb * 16 + ((16 - (nb * 16) % mod) + mod) % mod;
+}
+template <typename T, int V>
+constexpr int gen_loader_slots() { return V == 1 ? 8 : 4; }
+__host__ __device__ constexpr size_t gen_gram_lds_bytes(int R, int P, size_t ts) { return (size_t)2 * R * ((size_t)P + 1) * ts; }
+
+template <typename T, int V>
+__global__ __launch_bounds__(64 * kGenGramMaxWaves, YCNR_GEN_GRAM_WAVES_PER_SIMD) void als_gen_gram_kernel(GenArgs<T> ga, int R, int P) {
   using Tr = MfmaTraits<T>;
   using acc_t = typename Tr::acc_t;
+  using Vec = GenVec<T, V>;
+  constexpr int MAXI = gen_loader_slots<T, V>();
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const StepArgs<T> &a = ga.a;
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nthr = blockDim.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), W = nthr >> 6;
   const int NB = ga.nb, k = a.k;
   const Unit u = a.units[ga.firstUnit + blockIdx.x];
   const int64_t n = u.end - u.beg;
   T *slab = a.slabs + (int64_t)(u.slab - ga.slabBase) * gen_slab_elems(NB);
   T *bout = slab + (int64_t)tile_count(NB) * 256;
-  const int64_t nsteps = (n + 3) >> 2;
-  int item = 0;
-  for (int bi0 = 0; bi0 < NB; bi0 += kGenSq) {
-    for (int bj0 = bi0; bj0 < NB; bj0 += kGenSq, ++item) {
-      if ((item % kGenWaves) != wave) continue;
-      const bool diag = bj0 == bi0;
-      acc_t acc[kGenSq][kGenSq];
+  T *buf0 = reinterpret_cast<T *>(smem), *buf1 = buf0 + (int64_t)R * P, *rb0 = buf1 + (int64_t)R * P, *rb1 = rb0 + R;
+  // (columns k .. P - 1 of both buffers stay zero: the loader never writes them)
+  for (int i = tid; i < 2 * R * (P + 1); i += nthr) buf0[i] = T(0);
+  // loader slots of this thread: (rating of the panel) << 16 | (vector of the row); the same in every panel.  Every load is
+  // unconditional, from a clamped (valid) address -- a load under a lane condition is followed by the select that merges its
+  // result, and the wait for it, right where it is issued: four trips to memory per panel one after the other -- and what
+  // a slot without a rating loaded is replaced by zero when it is written to LDS.
+  const int kv = k / V, total = R * kv;
+  int rc[MAXI];
+  unsigned slotOk = 0;
 #pragma unroll
-      for (int i = 0; i < kGenSq; ++i)
+  for (int i = 0; i < MAXI; ++i) {
+    const int v = tid + i * nthr;
+    rc[i] = v < total ? (((v / kv) << 16) | (v % kv)) : 0;
+    slotOk |= v < total ? 1u << i : 0u;
+  }
+  auto ld_idx = [&](int64_t p, int i) -> int32_t {
+    const int64_t q = p * R + (rc[i] >> 16);
+    return a.indx[u.beg + (q < n ? q : n - 1)];
+  };
+  auto live_mask = [&](int64_t p) -> unsigned {
+    unsigned m = 0;
 #pragma unroll
-        for (int j = 0; j < kGenSq; ++j) acc[i][j] = acc_t{T(0), T(0), T(0), T(0)};
-      T bacc[kGenSq];
+    for (int i = 0; i < MAXI; ++i) m |= (p * R + (rc[i] >> 16) < n) ? 1u << i : 0u;
+    return m & slotOk;
+  };
+  auto ld_val = [&](int32_t id, int i) -> Vec {
+    return *reinterpret_cast<const Vec *>(a.fixed + (int64_t)id * k + (int64_t)(rc[i] & 0xffff) * V);
+  };
+  auto st_val = [&](T *B, Vec v, int i, unsigned live) {
+    if (!((live >> i) & 1u)) {
 #pragma unroll
-      for (int i = 0; i < kGenSq; ++i) bacc[i] = T(0);
-      for (int64_t st = 0; st < nsteps; ++st) {
-        const int64_t q = (st << 2) + g;
-        const bool live = q < n;
-        const int64_t qc = u.beg + (live ? q : n - 1);
-        const T *row = a.fixed + (int64_t)a.indx[qc] * k;
-        const T r = live ? a.vals[qc] : T(0);
-        T ya[kGenSq], yb[kGenSq];
+      for (int e = 0; e < V; ++e) v.e[e] = T(0);
+    }
+    if ((slotOk >> i) & 1u) *reinterpret_cast<Vec *>(B + (int64_t)(rc[i] >> 16) * P + (rc[i] & 0xffff) * V) = v;
+  };
+  const int rslot = tid < R ? tid : R - 1;
+  auto ld_r = [&](int64_t p) -> T {
+    const int64_t q = p * R + rslot;
+    return a.vals[u.beg + (q < n ? q : n - 1)];
+  };
+  auto st_r = [&](T *rbuf, T r, int64_t p) {
+    if (tid < R) rbuf[tid] = (p * R + tid < n) ? r : T(0);
+  };
+  const int64_t np = (n + R - 1) / R;
+  const int nSq = gen_squares(NB);
+  __syncthreads();
+  for (int item0 = 0; item0 < nSq; item0 += W) {
+    // this wave's square of the pass (wave-uniform)
+    const int item = item0 + wave;
+    const bool active = item < nSq;
+    int bi0 = 0, bj0 = 0;
+    {
+      int it = 0;
+      for (int x = 0; x < NB; x += kGenSq)
+        for (int y = x; y < NB; y += kGenSq, ++it)
+          if (it == item) {
+            bi0 = x;
+            bj0 = y;
+          }
+    }
+    const bool diag = bj0 == bi0;
+    acc_t acc[kGenSq][kGenSq];
 #pragma unroll
-        for (int i = 0; i < kGenSq; ++i) {
-          const int colA = 16 * (bi0 + i) + c, colB = 16 * (bj0 + i) + c;
-          ya[i] = (live && colA < k) ? row[colA] : T(0);
-          yb[i] = diag ? ya[i] : ((live && colB < k) ? row[colB] : T(0));
-        }
-        if (diag) {  // b rides with the squares on the diagonal (wave-uniform)
+    for (int i = 0; i < kGenSq; ++i)
 #pragma unroll
-          for (int i = 0; i < kGenSq; ++i) bacc[i] = fma(ya[i], r, bacc[i]);
-        }
+      for (int j = 0; j < kGenSq; ++j) acc[i][j] = acc_t{T(0), T(0), T(0), T(0)};
+    T bacc[kGenSq];
 #pragma unroll
-        for (int i = 0; i < kGenSq; ++i) {
+    for (int i = 0; i < kGenSq; ++i) bacc[i] = T(0);
+    // panel 0 into buffer 0, the ids of panel 1 in flight
+    int32_t idn[MAXI];
 #pragma unroll
-          for (int j = 0; j < kGenSq; ++j) {
-            if (bi0 + i < NB && bj0 + j < NB && (!diag || j >= i))  // wave-uniform
-              acc[i][j] = Tr::mma(ya[i], yb[j], acc[i][j]);
+    for (int i = 0; i < MAXI; ++i) idn[i] = ld_idx(0, i);
+    {
+      Vec v0[MAXI];
+#pragma unroll
+      for (int i = 0; i < MAXI; ++i) v0[i] = ld_val(idn[i], i);
+      const unsigned live0 = live_mask(0);
+#pragma unroll
+      for (int i = 0; i < MAXI; ++i) st_val(buf0, v0[i], i, live0);
+      st_r(rb0, ld_r(0), 0);
+    }
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) idn[i] = ld_idx(1, i);
+    __syncthreads();
+    for (int64_t p = 0; p < np; ++p) {
+      const T *B = (p & 1) ? buf1 : buf0, *rb = (p & 1) ? rb1 : rb0;
+      T *Bn = (p & 1) ? buf0 : buf1, *rbn = (p & 1) ? rb0 : rb1;
+      const bool more = p + 1 < np;  // workgroup-uniform
+      Vec vn[MAXI];
+      T rn = T(0);
+      if (more) {
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) vn[i] = ld_val(idn[i], i);
+        rn = ld_r(p + 1);
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) idn[i] = ld_idx(p + 2, i);
+      }
+      if (active) {
+        for (int s4 = 0; s4 < R; s4 += 4) {
+          const T *rowp = B + (int64_t)(s4 + g) * P + c;
+          T ya[kGenSq], yb[kGenSq];
+#pragma unroll
+          for (int i = 0; i < kGenSq; ++i) {
+            ya[i] = bi0 + i < NB ? rowp[16 * (bi0 + i)] : T(0);
+            yb[i] = diag ? ya[i] : (bj0 + i < NB ? rowp[16 * (bj0 + i)] : T(0));
+          }
+          if (diag) {  // b rides with the squares on the diagonal (wave-uniform)
+            const T r = rb[s4 + g];
+#pragma unroll
+            for (int i = 0; i < kGenSq; ++i) bacc[i] = fma(ya[i], r, bacc[i]);
+          }
+#pragma unroll
+          for (int i = 0; i < kGenSq; ++i) {
+#pragma unroll
+            for (int j = 0; j < kGenSq; ++j) {
+              if (bi0 + i < NB && bj0 + j < NB && (!diag || j >= i))  // wave-uniform
+                acc[i][j] = Tr::mma(ya[i], yb[j], acc[i][j]);
+            }
           }
         }
       }
+      if (more) {
+        const unsigned liveN = live_mask(p + 1);
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) st_val(Bn, vn[i], i, liveN);
+        st_r(rbn, rn, p + 1);
+      }
+      __syncthreads();
+    }
+    if (active) {
 #pragma unroll
       for (int i = 0; i < kGenSq; ++i) {
 #pragma unroll
@@ -168,9 +289,9 @@ struct GenSolve {
   }
 
   // One wave.  d: the diagonal tile (C/D layout).  On return Wt (LDS, [col][row], stride LDW) holds W = L^-1 with
-  // D = L L^T, and the return value is W in C/D layout.  nreal: pivots that are real (the rest are rows of the
+  // D = L L^T, and the return value is W in C/D layout.  (Padded pivots are rows of the
   // identity).  dmin collects the smallest real pivot.
-  static __device__ __forceinline__ acc_t diag_invert(const acc_t &d, T *Dt, T *Wt, int lane, int nreal, T &dmin) {
+  static __device__ __forceinline__ acc_t diag_invert(const acc_t &d, T *Dt, T *Wt, int lane, T &dmin) {
     const int g = lane >> 4, c = lane & 15;
 #pragma unroll
     for (int t = 0; t < 4; ++t) Dt[Tr::cd_row(lane, t) * LDW + c] = d[t];
@@ -182,19 +303,19 @@ struct GenSolve {
       const T v = Dt[c * LDW + m];
       R[m] = xlane ? (c == m ? T(1) : T(0)) : v;
     }
+    // (no branch on nreal: a padded pivot is a row of the identity -- dp = 1, every s = 0, the step changes nothing -- and a
+    // branch per pivot made hipcc carry R as one 16-wide vector copied at every join: 860 spilled registers in float32)
 #pragma unroll
     for (int p = 0; p < 16; ++p) {
-      if (p < nreal) {  // wave-uniform
-        T dp = readlane(R[p], p);
-        dmin = dp < dmin ? dp : dmin;
-        if (!(dp > T(0))) dp = T(1);
-        const T rs = T(1) / sqrt(dp);
-        R[p] *= rs;
+      T dp = readlane(R[p], p);
+      dmin = dp < dmin ? dp : dmin;
+      if (!(dp > T(0))) dp = T(1);
+      const T rs = T(1) / sqrt(dp);
+      R[p] *= rs;
 #pragma unroll
-        for (int j = p + 1; j < 16; ++j) {
-          const T s = readlane(R[p], j);  // L[j][p]
-          R[j] = fma(-R[p], s, R[j]);
-        }
+      for (int j = p + 1; j < 16; ++j) {
+        const T s = readlane(R[p], j);  // L[j][p]
+        R[j] = fma(-R[p], s, R[j]);
       }
     }
     if (g == 1) {
@@ -208,8 +329,10 @@ struct GenSolve {
   }
 };
 
-template <typename T>
-__global__ __launch_bounds__(kGenThreads) void als_gen_solve_kernel(GenArgs<T> ga) {
+// PANEL_LDS: the panel U[J][.] of the current block step is kept in LDS too (NB KB in float32), so that the trailing update
+// reads only the tiles it changes from global memory.
+template <typename T, bool PANEL_LDS>
+__global__ __launch_bounds__(kGenThreads, 3) void als_gen_solve_kernel(GenArgs<T> ga) {
   using GS = GenSolve<T>;
   using Tr = MfmaTraits<T>;
   using acc_t = typename Tr::acc_t;
@@ -223,15 +346,46 @@ __global__ __launch_bounds__(kGenThreads) void als_gen_solve_kernel(GenArgs<T> g
   T *Dt = reinterpret_cast<T *>(smem), *Wt = Dt + 16 * LDW;
   T *bvec = Wt + 16 * LDW, *zvec = bvec + NB * 16, *xvec = zvec + NB * 16;
   int *flag = reinterpret_cast<int *>(xvec + NB * 16);
+  T *panL = xvec + NB * 16 + 16;  // PANEL_LDS: tile bj of the panel at panL + 256 bj, in register order
   const SplitRow sr = a.split[ga.firstSplit + blockIdx.x];
   const int64_t se = gen_slab_elems(NB);
   T *S = a.slabs + (int64_t)(sr.slab0 - ga.slabBase) * se;
   // ---- slabs summed in slab order into the first; the right-hand side into LDS
   const int64_t ne = (int64_t)NT * 256;
-  for (int64_t i = tid; i < ne; i += kGenThreads) {
-    T v = S[i];
-    for (int sl = 1; sl < sr.nslabs; ++sl) v += S[(int64_t)sl * se + i];
-    S[i] = v;
+  {
+    // (16-byte vectors, four of them requested before the first is stored: the loop used to wait for every element behind
+    // the store of the one before it -- a round trip to HBM per element, about 1 ms of a k = 512 row)
+    constexpr int VE = 16 / (int)sizeof(T), UN = 4;
+    using V4 = GenVec<T, VE>;
+    V4 *S4 = reinterpret_cast<V4 *>(S);  // slabs are 16-byte aligned: gen_slab_elems is a multiple of 16 elements
+    const int64_t nv = ne / VE, sev = se / VE;
+    for (int64_t i0 = tid; i0 < nv; i0 += (int64_t)UN * kGenThreads) {
+      V4 v[UN];
+#pragma unroll
+      for (int x = 0; x < UN; ++x) {
+        const int64_t i = i0 + (int64_t)x * kGenThreads;
+        v[x] = S4[i < nv ? i : nv - 1];
+      }
+      for (int sl = 1; sl < sr.nslabs; ++sl) {
+        V4 w[UN];
+#pragma unroll
+        for (int x = 0; x < UN; ++x) {
+          const int64_t i = i0 + (int64_t)x * kGenThreads;
+          w[x] = S4[(int64_t)sl * sev + (i < nv ? i : nv - 1)];
+        }
+#pragma unroll
+        for (int x = 0; x < UN; ++x)
+#pragma unroll
+          for (int e = 0; e < VE; ++e) v[x].e[e] += w[x].e[e];
+      }
+      if (sr.nslabs > 1) {
+#pragma unroll
+        for (int x = 0; x < UN; ++x) {
+          const int64_t i = i0 + (int64_t)x * kGenThreads;
+          if (i < nv) S4[i] = v[x];
+        }
+      }
+    }
   }
   for (int i = tid; i < NB * 16; i += kGenThreads) {
     T v = S[ne + i];
@@ -268,9 +422,7 @@ __global__ __launch_bounds__(kGenThreads) void als_gen_solve_kernel(GenArgs<T> g
     T *TJJ = S + (int64_t)tile_index(J, J, NB) * 256;
     if (wave == 0) {
       const acc_t d = gen_ld_tile<T>(TJJ, lane);
-      int nreal = k - 16 * J;
-      nreal = nreal > 16 ? 16 : nreal;
-      const acc_t W = GS::diag_invert(d, Dt, Wt, lane, nreal, dmin);
+      const acc_t W = GS::diag_invert(d, Dt, Wt, lane, dmin);
       gen_st_tile<T>(TJJ, lane, W);
     }
     __syncthreads();
@@ -279,38 +431,74 @@ __global__ __launch_bounds__(kGenThreads) void als_gen_solve_kernel(GenArgs<T> g
       T Aop[4];  // A operand of MFMA q: W[i = c][kk], kk = the C/D row of register q
 #pragma unroll
       for (int q = 0; q < 4; ++q) Aop[q] = Wt[Tr::cd_row(lane, q) * LDW + c];
-      for (int bj = J + 1 + wave; bj <= NB; bj += kGenWaves) {
-        const bool rhs = bj == NB;
-        T *tl = S + (int64_t)tile_index(J, rhs ? J : bj, NB) * 256;
-        const acc_t B = rhs ? ld_rhs(bvec, J) : gen_ld_tile<T>(tl, lane);
+      // (this wave's tiles PB at a time, all requested before the first is multiplied)
+      constexpr int PB = 4;
+      for (int bj0 = J + 1 + wave; bj0 < NB; bj0 += PB * kGenWaves) {
+        acc_t B[PB];
+#pragma unroll
+        for (int x = 0; x < PB; ++x) {
+          const int bj = bj0 + x * kGenWaves;
+          B[x] = gen_ld_tile<T>(S + (int64_t)tile_index(J, bj < NB ? bj : NB - 1, NB) * 256, lane);
+        }
+#pragma unroll
+        for (int x = 0; x < PB; ++x) {
+          const int bj = bj0 + x * kGenWaves;
+          acc_t P = acc_t{T(0), T(0), T(0), T(0)};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) P = Tr::mma(Aop[q], B[x][q], P);
+          if (bj < NB) {  // wave-uniform
+            gen_st_tile<T>(S + (int64_t)tile_index(J, bj, NB) * 256, lane, P);  // (kept for the back substitution)
+            if constexpr (PANEL_LDS) gen_st_tile<T>(panL + bj * 256, lane, P);
+          }
+        }
+      }
+      if (wave == (NB - J - 1) % kGenWaves) {  // z_J = W b_J
+        const acc_t B = ld_rhs(bvec, J);
         acc_t P = acc_t{T(0), T(0), T(0), T(0)};
 #pragma unroll
         for (int q = 0; q < 4; ++q) P = Tr::mma(Aop[q], B[q], P);
-        if (rhs) st_rhs(zvec, J, P);
-        else gen_st_tile<T>(tl, lane, P);
+        st_rhs(zvec, J, P);
       }
     }
     __syncthreads();
     if (J + 1 == NB) break;
-    // ---- trailing update: T[bi][bj] -= U[J][bi]^T U[J][bj] (bj >= bi > J), b_bi -= U[J][bi]^T z_J; a block row per wave
+    // ---- trailing update: T[bi][bj] -= U[J][bi]^T U[J][bj] (bj >= bi > J), b_bi -= U[J][bi]^T z_J.  The tiles of a block row
+    // go to the waves GB at a time, all GB requested before the first is multiplied (round 3 loaded, multiplied and stored
+    // one tile at a time, every tile a round trip to the cache behind the one before it: 4.4 ms per k = 512 row).
     {
+      constexpr int GB = sizeof(T) == 8 ? 4 : 8;
       const acc_t Z = ld_rhs(zvec, J);
-      for (int bi = J + 1 + wave; bi < NB; bi += kGenWaves) {
-        acc_t nPi = gen_ld_tile<T>(S + (int64_t)tile_index(J, bi, NB) * 256, lane);
+      const T *pan;
+      if constexpr (PANEL_LDS) pan = panL;
+      else pan = S + ((int64_t)tile_index(J, J, NB) - J) * 256;  // tile (J, bj) at pan + 256 bj
+      int chunk = 0;
+      for (int bi = J + 1; bi < NB; ++bi) {
+        T *trow = S + ((int64_t)tile_index(bi, bi, NB) - bi) * 256;  // tile (bi, bj) at trow + 256 bj
+        for (int bj0 = bi; bj0 < NB; bj0 += GB, ++chunk) {
+          if ((chunk % kGenWaves) != wave) continue;  // wave-uniform
+          acc_t nPi = gen_ld_tile<T>(pan + bi * 256, lane);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) nPi[q] = -nPi[q];
-        for (int bj = bi; bj < NB; ++bj) {
-          const acc_t Pj = gen_ld_tile<T>(S + (int64_t)tile_index(J, bj, NB) * 256, lane);
-          T *tl = S + (int64_t)tile_index(bi, bj, NB) * 256;
-          acc_t t = gen_ld_tile<T>(tl, lane);
+          for (int q = 0; q < 4; ++q) nPi[q] = -nPi[q];
+          acc_t t[GB], Pj[GB];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) t = Tr::mma(nPi[q], Pj[q], t);
-          gen_st_tile<T>(tl, lane, t);
+          for (int x = 0; x < GB; ++x) t[x] = gen_ld_tile<T>(trow + (bj0 + x < NB ? bj0 + x : NB - 1) * 256, lane);
+#pragma unroll
+          for (int x = 0; x < GB; ++x) Pj[x] = gen_ld_tile<T>(pan + (bj0 + x < NB ? bj0 + x : NB - 1) * 256, lane);
+#pragma unroll
+          for (int x = 0; x < GB; ++x) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t[x] = Tr::mma(nPi[q], Pj[x][q], t[x]);
+          }
+#pragma unroll
+          for (int x = 0; x < GB; ++x)
+            if (bj0 + x < NB) gen_st_tile<T>(trow + (bj0 + x) * 256, lane, t[x]);
+          if (bj0 == bi) {  // the right-hand side of block row bi goes with the row's first tiles
+            acc_t tb = ld_rhs(bvec, bi);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tb = Tr::mma(nPi[q], Z[q], tb);
+            st_rhs(bvec, bi, tb);
+          }
         }
-        acc_t t = ld_rhs(bvec, bi);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) t = Tr::mma(nPi[q], Z[q], t);
-        st_rhs(bvec, bi, t);
       }
     }
     __syncthreads();
@@ -356,8 +544,9 @@ __global__ __launch_bounds__(kGenThreads) void als_gen_solve_kernel(GenArgs<T> g
   }
 }
 
-__host__ __device__ constexpr size_t gen_solve_lds_bytes(int nb, size_t ts) {
-  return (2 * 16 * (ts == 8 ? 18 : 20) + 3 * (size_t)nb * 16) * ts + 64;
+__host__ __device__ constexpr size_t gen_solve_lds_bytes(int nb, size_t ts, bool panelLds) {
+  return (2 * 16 * (ts == 8 ? 18 : 20) + 3 * (size_t)nb * 16 + 16 + (panelLds ? (size_t)nb * 256 : 0)) * ts + 64;
 }
+constexpr size_t kGenPanelLdsMax = 36 * 1024;  // panels up to this size live in LDS (k = 512 float32, k = 256 float64: four workgroups per CU)
 
 }  // namespace ycnr

@@ -620,17 +620,37 @@ int launch_step_big(const StepArgs<float> &args, int64_t nUnits, int64_t nSplitU
 template <typename T>
 int launch_step_gen(const StepArgs<T> &args, const std::vector<GenBatch> &batches, hipStream_t stream, hipEvent_t *ev, const DualPlan &dp) {
   GenArgs<T> ga{args, (args.k + 15) / 16, 0, 0, 0};
-  const size_t lds = gen_solve_lds_bytes(ga.nb, sizeof(T));
+  const bool panelLds = (size_t)ga.nb * 256 * sizeof(T) <= kGenPanelLdsMax;
+  const size_t lds = gen_solve_lds_bytes(ga.nb, sizeof(T), panelLds);
   if (lds > 160 * 1024) return fail(YCNR_ERR_UNSUPPORTED, "factorsCount %d: the right-hand side does not fit a CU's LDS", args.k);
-  if (int rc = set_max_lds(reinterpret_cast<const void *>(als_gen_solve_kernel<T>), lds)) return rc;
+  const void *solveFn = panelLds ? reinterpret_cast<const void *>(als_gen_solve_kernel<T, true>) : reinterpret_cast<const void *>(als_gen_solve_kernel<T, false>);
+  if (int rc = set_max_lds(solveFn, lds)) return rc;
+  // Gramian: 16-byte loads when every row of the fixed matrix starts on a 16-byte boundary, single elements otherwise;
+  // the waves of a workgroup share the squares of a pass evenly; R ratings per panel: as many as two buffers of <= 72 KB
+  // (two workgroups per CU) and the loader's slots allow, at least 4
+  constexpr int V = 16 / (int)sizeof(T);
+  const bool vec = args.k % V == 0 && (reinterpret_cast<uintptr_t>(args.fixed) & 15) == 0;
+  const int nSq = gen_squares(ga.nb), passes = (nSq + kGenGramMaxWaves - 1) / kGenGramMaxWaves;
+  const int waves = std::max(2, (nSq + passes - 1) / passes), nthr = 64 * waves;
+  const int P = gen_panel_pitch(ga.nb, sizeof(T));
+  const int slots = vec ? gen_loader_slots<T, V>() : gen_loader_slots<T, 1>();
+  int R = 32;
+  while (R > 4 && (gen_gram_lds_bytes(R, P, sizeof(T)) > 72 * 1024 || (int64_t)R * (args.k / (vec ? V : 1)) > (int64_t)slots * nthr)) R >>= 1;
+  const size_t gramLds = gen_gram_lds_bytes(R, P, sizeof(T));
+  if (gramLds > 150 * 1024 || (int64_t)R * (args.k / (vec ? V : 1)) > (int64_t)slots * nthr)
+    return fail(YCNR_ERR_UNSUPPORTED, "factorsCount %d: a panel of four ratings does not fit a CU's LDS", args.k);
+  const void *gramFn = vec ? reinterpret_cast<const void *>(als_gen_gram_kernel<T, V>) : reinterpret_cast<const void *>(als_gen_gram_kernel<T, 1>);
+  if (int rc = set_max_lds(gramFn, gramLds)) return rc;
   if (ev) HIP_TRY(hipEventRecord(ev[0], stream));
   for (const GenBatch &b : batches) {
     ga.slabBase = b.slabBase;
     ga.firstUnit = b.slabBase;  // units of split rows are numbered like their slabs
     ga.firstSplit = b.firstSplit;
-    hipLaunchKernelGGL(als_gen_gram_kernel<T>, dim3((unsigned)b.nSlabs), dim3(kGenThreads), 0, stream, ga);
+    if (vec) hipLaunchKernelGGL((als_gen_gram_kernel<T, V>), dim3((unsigned)b.nSlabs), dim3(nthr), gramLds, stream, ga, R, P);
+    else hipLaunchKernelGGL((als_gen_gram_kernel<T, 1>), dim3((unsigned)b.nSlabs), dim3(nthr), gramLds, stream, ga, R, P);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(als_gen_solve_kernel<T>, dim3((unsigned)b.nSplit), dim3(kGenThreads), lds, stream, ga);
+    if (panelLds) hipLaunchKernelGGL((als_gen_solve_kernel<T, true>), dim3((unsigned)b.nSplit), dim3(kGenThreads), lds, stream, ga);
+    else hipLaunchKernelGGL((als_gen_solve_kernel<T, false>), dim3((unsigned)b.nSplit), dim3(kGenThreads), lds, stream, ga);
     HIP_TRY(hipGetLastError());
   }
   if (ev) {
