@@ -228,14 +228,15 @@ def test_every_row_length_class(als, k):
 
 
 @pytest.mark.parametrize("k,dt", [(129, np.float64), (200, np.float64), (256, np.float64), (320, np.float64), (512, np.float64),
-                                  (257, np.float32), (320, np.float32), (333, np.float32), (512, np.float32)])
+                                  (257, np.float32), (320, np.float32), (333, np.float32), (512, np.float32), (600, np.float32)])
 def test_any_factors_count(als, oracle, k, dt, monkeypatch):
     """The reference accepts any factorsCount in either precision (lib/emf/EmfBase.js:112, config/config-base.js:31;
     lib/emf/EmfWorker.js:200-246).  Beyond what registers and LDS hold -- float64 above 128 factors, float32 above
     256 -- the normal matrix lives in global memory (als_gen_kernels.hip.h): rows of every kind (empty, 1 rating,
     fewer ratings than factors -- the float32 dual classes --, more, split over several chunks and several
     BATCHES of the slab arena) against the float64 oracle, both half-steps, the level-1 portion op, bitwise
-    repeatability."""
+    repeatability.  float32 up to 512 factors and float64 up to 256 take the left-looking solve, the larger ones the
+    right-looking one; k % 4 != 0 (float32) / k % 2 != 0 (float64) the element-wise panel loader."""
     monkeypatch.setenv("YCNR_GEN_ARENA_MB", "8")  # a k = 512 image is 0.5 / 1 MB: several batches
     users, items = 60, 400
     # (float32: rows of at most 192 ratings take the dual classes, whatever k; the longer ones the any-k kernels)

@@ -64,11 +64,13 @@ __device__ __forceinline__ void gen_st_tile(T *tile, int lane, const typename Mf
 // Gramian of a unit (round 4, second form).  The first form let every wave gather its operands itself, one element per lane and
 // MFMA operand, a square of 4 x 4 tiles at a time: each step waited for an index and then for the values behind it (two trips
 // to the cache per 16 MFMAs, nothing requested ahead), and a k = 512 unit was walked 36 times.  Here the workgroup stages
-// PANELS of R ratings x k factors in LDS (whole 16-byte loads where every row of the fixed matrix is 16-byte aligned; the
-// values of panel p + 1 and the ids of panel p + 2 are requested before panel p is multiplied; two LDS buffers, one barrier
-// per panel) and every wave keeps ONE square of kGenSq x kGenSq tiles in registers per pass over the unit's ratings, its operands
-// read from the panel in MFMA layout (lane (g, c): factor 16 cb + c of rating 4 s + g; the row pitch P puts the four lane
-// groups on different banks).  Passes = squares / waves: 5 at k = 512 with eight waves, 2 at k = 256 with five.
+// PANELS of R ratings x k factors in LDS (whole 16-byte loads where every row of the fixed matrix is 16-byte aligned; two LDS
+// buffers, one barrier per panel; while panel p is multiplied the values of panels p + 1 and p + 2 are in registers or in
+// flight and the ids of panel p + 3 requested: with one panel ahead a CU had 32 KB in flight, and the gathers' latency under
+// load -- 3 us -- bounded the kernel at 2 TB/s) and every wave keeps ONE rectangle of kGenSq x (SQW kGenSq) tiles in registers per
+// pass over the unit's ratings, its operands read from the panel in MFMA layout (lane (g, c): factor 16 cb + c of rating
+// 4 s + g; the row pitch P puts the four lane groups on different banks).  float32: 4 x 8 tiles, three passes of seven
+// waves at k = 512; float64: 4 x 4, two passes of five at k = 256.
 // 200 K x 20 K, 20 M ratings, per iteration: k = 512 float32 902 (strips) -> 606 (squares from cache) -> see DESIGN.md.
 constexpr int kGenSq = 4;
 constexpr int kGenGramMaxWaves = 8;
@@ -81,10 +83,17 @@ struct alignas(sizeof(T) * V) GenVec {
   T e[V];
 };
 
-__host__ __device__ constexpr int gen_squares(int nb) {
-  const int m = (nb + kGenSq - 1) / kGenSq;
-  return m * (m + 1) / 2;
+// rectangles of a matrix of nb block columns: block rows in fours, from the diagonal to the right in steps of 4 sqw
+__host__ __device__ constexpr int gen_items(int nb, int sqw) {
+  int n = 0;
+  for (int x = 0; x < nb; x += kGenSq) n += (nb - x + kGenSq * sqw - 1) / (kGenSq * sqw);
+  return n;
 }
+#ifndef YCNR_GEN_SQW_F32
+#define YCNR_GEN_SQW_F32 1  // (2 -- 4 x 8 tiles, three passes of seven waves at k = 512 -- measured slower: 269 against 241 ms per iteration)
+#endif
+template <typename T>
+constexpr int gen_sqw() { return sizeof(T) == 4 ? YCNR_GEN_SQW_F32 : 1; }
 // row pitch of a panel in elements: a multiple of 16, P * sizeof(T) = 64 bytes modulo 256 (float32) / 128 modulo 256 (float64)
 __host__ __device__ constexpr int gen_panel_pitch(int nb, size_t ts) {
   const int mod = (int)(256 / ts);
@@ -100,6 +109,7 @@ __global__ __launch_bounds__(64 * kGenGramMaxWaves, YCNR_GEN_GRAM_WAVES_PER_SIMD
   using acc_t = typename Tr::acc_t;
   using Vec = GenVec<T, V>;
   constexpr int MAXI = gen_loader_slots<T, V>();
+  constexpr int SQW = gen_sqw<T>(), CW = SQW * kGenSq;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const StepArgs<T> &a = ga.a;
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
@@ -155,98 +165,141 @@ __global__ __launch_bounds__(64 * kGenGramMaxWaves, YCNR_GEN_GRAM_WAVES_PER_SIMD
     if (tid < R) rbuf[tid] = (p * R + tid < n) ? r : T(0);
   };
   const int64_t np = (n + R - 1) / R;
-  const int nSq = gen_squares(NB);
+  const int nItems = gen_items(NB, SQW);
   __syncthreads();
-  for (int item0 = 0; item0 < nSq; item0 += W) {
-    // this wave's square of the pass (wave-uniform)
+  for (int item0 = 0; item0 < nItems; item0 += W) {
+    // this wave's rectangle of the pass (wave-uniform)
     const int item = item0 + wave;
-    const bool active = item < nSq;
+    const bool active = item < nItems;
     int bi0 = 0, bj0 = 0;
     {
       int it = 0;
       for (int x = 0; x < NB; x += kGenSq)
-        for (int y = x; y < NB; y += kGenSq, ++it)
+        for (int y = x; y < NB; y += CW, ++it)
           if (it == item) {
             bi0 = x;
             bj0 = y;
           }
     }
     const bool diag = bj0 == bi0;
-    acc_t acc[kGenSq][kGenSq];
+    int ca[kGenSq], cb[CW];  // operand columns, clamped to the matrix: tiles beyond its edge are computed and not stored
+#pragma unroll
+    for (int i = 0; i < kGenSq; ++i) ca[i] = 16 * (bi0 + i < NB ? bi0 + i : NB - 1);
+#pragma unroll
+    for (int j = 0; j < CW; ++j) cb[j] = 16 * (bj0 + j < NB ? bj0 + j : NB - 1);
+    acc_t acc[kGenSq][CW];
 #pragma unroll
     for (int i = 0; i < kGenSq; ++i)
 #pragma unroll
-      for (int j = 0; j < kGenSq; ++j) acc[i][j] = acc_t{T(0), T(0), T(0), T(0)};
+      for (int j = 0; j < CW; ++j) acc[i][j] = acc_t{T(0), T(0), T(0), T(0)};
     T bacc[kGenSq];
 #pragma unroll
     for (int i = 0; i < kGenSq; ++i) bacc[i] = T(0);
-    // panel 0 into buffer 0, the ids of panel 1 in flight
+    // panel 0 into buffer 0, panel 1 into registers, the ids of panel 2 in flight
     int32_t idn[MAXI];
+    Vec vA[MAXI], vB[MAXI];
+    T rA = T(0), rB = T(0);
 #pragma unroll
     for (int i = 0; i < MAXI; ++i) idn[i] = ld_idx(0, i);
-    {
-      Vec v0[MAXI];
 #pragma unroll
-      for (int i = 0; i < MAXI; ++i) v0[i] = ld_val(idn[i], i);
-      const unsigned live0 = live_mask(0);
-#pragma unroll
-      for (int i = 0; i < MAXI; ++i) st_val(buf0, v0[i], i, live0);
-      st_r(rb0, ld_r(0), 0);
-    }
+    for (int i = 0; i < MAXI; ++i) vA[i] = ld_val(idn[i], i);
+    rA = ld_r(0);
 #pragma unroll
     for (int i = 0; i < MAXI; ++i) idn[i] = ld_idx(1, i);
+    {
+      const unsigned live0 = live_mask(0);
+#pragma unroll
+      for (int i = 0; i < MAXI; ++i) st_val(buf0, vA[i], i, live0);
+      st_r(rb0, rA, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) vB[i] = ld_val(idn[i], i);
+    rB = ld_r(1);
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) idn[i] = ld_idx(2, i);
     __syncthreads();
-    for (int64_t p = 0; p < np; ++p) {
+    // one panel: request panel p + 2 into (vX, rX), multiply panel p, write panel p + 1 from (vY, rY) into the other buffer
+    auto panel = [&](int64_t p, Vec(&vX)[MAXI], T &rX, Vec(&vY)[MAXI], T &rY) {
       const T *B = (p & 1) ? buf1 : buf0, *rb = (p & 1) ? rb1 : rb0;
       T *Bn = (p & 1) ? buf0 : buf1, *rbn = (p & 1) ? rb0 : rb1;
-      const bool more = p + 1 < np;  // workgroup-uniform
-      Vec vn[MAXI];
-      T rn = T(0);
-      if (more) {
+      if (p + 2 < np) {  // workgroup-uniform
 #pragma unroll
-        for (int i = 0; i < MAXI; ++i) vn[i] = ld_val(idn[i], i);
-        rn = ld_r(p + 1);
+        for (int i = 0; i < MAXI; ++i) vX[i] = ld_val(idn[i], i);
+        rX = ld_r(p + 2);
 #pragma unroll
-        for (int i = 0; i < MAXI; ++i) idn[i] = ld_idx(p + 2, i);
+        for (int i = 0; i < MAXI; ++i) idn[i] = ld_idx(p + 3, i);
       }
+      // Straight-line code, the same MFMAs per step for every rectangle: tiles beyond the matrix edge are computed from clamped
+      // (valid) columns and the lower tiles of a rectangle on the diagonal from their transposes' operands -- none of them
+      // is stored.  With a condition per tile every MFMA sat in a basic block of its own behind a scalar branch and a
+      // wait; with one loop for whole rectangles and one for cut ones the accumulators were allocated twice.
       if (active) {
-        for (int s4 = 0; s4 < R; s4 += 4) {
-          const T *rowp = B + (int64_t)(s4 + g) * P + c;
-          T ya[kGenSq], yb[kGenSq];
+        if constexpr (sizeof(T) == 4) {
+          // (the operands of step s + 1 are read from LDS before the MFMAs of step s are issued; float64 has no registers for it)
+          const T *rowp = B + (int64_t)g * P + c;
+          T ya[kGenSq], yb[CW], r;
 #pragma unroll
-          for (int i = 0; i < kGenSq; ++i) {
-            ya[i] = bi0 + i < NB ? rowp[16 * (bi0 + i)] : T(0);
-            yb[i] = diag ? ya[i] : (bj0 + i < NB ? rowp[16 * (bj0 + i)] : T(0));
+          for (int i = 0; i < kGenSq; ++i) ya[i] = rowp[ca[i]];
+#pragma unroll
+          for (int j = 0; j < CW; ++j) yb[j] = rowp[cb[j]];
+          r = rb[g];  // b rides with the rectangles on the diagonal (the others do not store it)
+          for (int s4 = 0; s4 < R; s4 += 4) {
+            const int sn = s4 + 4 < R ? s4 + 4 : s4;  // (the last step reads its own operands again)
+            const T *rown = B + (int64_t)(sn + g) * P + c;
+            T yan[kGenSq], ybn[CW];
+#pragma unroll
+            for (int i = 0; i < kGenSq; ++i) yan[i] = rown[ca[i]];
+#pragma unroll
+            for (int j = 0; j < CW; ++j) ybn[j] = rown[cb[j]];
+            const T rn = rb[sn + g];
+#pragma unroll
+            for (int i = 0; i < kGenSq; ++i) bacc[i] = fma(ya[i], r, bacc[i]);
+#pragma unroll
+            for (int i = 0; i < kGenSq; ++i)
+#pragma unroll
+              for (int j = 0; j < CW; ++j) acc[i][j] = Tr::mma(ya[i], yb[j], acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < kGenSq; ++i) ya[i] = yan[i];
+#pragma unroll
+            for (int j = 0; j < CW; ++j) yb[j] = ybn[j];
+            r = rn;
           }
-          if (diag) {  // b rides with the squares on the diagonal (wave-uniform)
+        } else {
+          for (int s4 = 0; s4 < R; s4 += 4) {
+            const T *rowp = B + (int64_t)(s4 + g) * P + c;
+            T ya[kGenSq], yb[CW];
+#pragma unroll
+            for (int i = 0; i < kGenSq; ++i) ya[i] = rowp[ca[i]];
+#pragma unroll
+            for (int j = 0; j < CW; ++j) yb[j] = rowp[cb[j]];
             const T r = rb[s4 + g];
 #pragma unroll
             for (int i = 0; i < kGenSq; ++i) bacc[i] = fma(ya[i], r, bacc[i]);
-          }
 #pragma unroll
-          for (int i = 0; i < kGenSq; ++i) {
+            for (int i = 0; i < kGenSq; ++i)
 #pragma unroll
-            for (int j = 0; j < kGenSq; ++j) {
-              if (bi0 + i < NB && bj0 + j < NB && (!diag || j >= i))  // wave-uniform
-                acc[i][j] = Tr::mma(ya[i], yb[j], acc[i][j]);
-            }
+              for (int j = 0; j < CW; ++j) acc[i][j] = Tr::mma(ya[i], yb[j], acc[i][j]);
           }
         }
       }
-      if (more) {
+      if (p + 1 < np) {
         const unsigned liveN = live_mask(p + 1);
 #pragma unroll
-        for (int i = 0; i < MAXI; ++i) st_val(Bn, vn[i], i, liveN);
-        st_r(rbn, rn, p + 1);
+        for (int i = 0; i < MAXI; ++i) st_val(Bn, vY[i], i, liveN);
+        st_r(rbn, rY, p + 1);
       }
       __syncthreads();
+    };
+    for (int64_t p = 0; p < np; p += 2) {
+      panel(p, vA, rA, vB, rB);
+      if (p + 1 < np) panel(p + 1, vB, rB, vA, rA);
     }
     if (active) {
 #pragma unroll
       for (int i = 0; i < kGenSq; ++i) {
 #pragma unroll
-        for (int j = 0; j < kGenSq; ++j)
-          if (bi0 + i < NB && bj0 + j < NB && (!diag || j >= i))
+        for (int j = 0; j < CW; ++j)
+          if (bi0 + i < NB && bj0 + j < NB && bj0 + j >= bi0 + i)
             gen_st_tile<T>(slab + (int64_t)tile_index(bi0 + i, bj0 + j, NB) * 256, lane, acc[i][j]);
         if (diag && bi0 + i < NB) {
           T bs = bacc[i];
@@ -542,6 +595,243 @@ __global__ __launch_bounds__(kGenThreads, 3) void als_gen_solve_kernel(GenArgs<T
     atomicAdd(&a.err->count, 1);
     a.err->firstRow = sr.row;
   }
+}
+
+// ---- The solve, LEFT-looking by blocks of PW block rows (round 4).  The right-looking kernel above reads and writes the
+// whole trailing matrix once per block step: 11 MB of traffic per k = 512 row, and with several hundred rows in flight (0.5 MB
+// each) none of it stays in a cache -- 490 GB per iteration of the 200 K x 20 K benchmark, the kernel ran at the speed of HBM.
+// Here a block of PW rows of the factor is computed at a time, its tiles in REGISTERS (wave w of LW owns the block
+// columns Jb + w, Jb + w + LW, ...: MAXC tiles per row):
+//   1. acc[r][x] = A[Jb + r][bj_x], the slabs of the row summed in slab order while they are loaded, + lambda n on the diagonal
+//   2. for every finished row I < Jb:  acc[r][x] -= U[I][Jb + r]^T U[I][bj_x]   (U streamed from global memory, the next
+//      row's tiles requested before this one's are multiplied) -- the matrix is read ~ NB / (2 PW) times instead of NB / 3
+//      times read AND written, and nothing of it is written twice
+//   3. the PW rows of the block one after the other: the owner of the diagonal tile factors it (16 pivots) and publishes
+//      W = L^-1; every wave turns its tiles of the row into U[J][.] = W acc, stores them (final) and, the PW - 1 tiles next
+//      to the diagonal, publishes them in LDS for the update of the block's remaining rows.  Two barriers per row.
+// The right-hand side rides on the last wave as a tile with the vector in column 0.  Tiles that lie left of the diagonal
+// or beyond the matrix edge are loaded from clamped addresses, multiplied like the others and never stored.
+// PW: block rows per block; LW: waves per workgroup (MAXC = ceil(NB / LW) column tiles per wave and row); DB: the next finished
+// row's tiles are requested before this one's are multiplied (twice the operand registers); WPS: waves per SIMD the
+// registers are bounded for.  float32: 4 rows, 8 waves, one workgroup per CU; float64 (twice the registers per tile): 2 rows,
+// 4 waves, three workgroups per CU.
+template <typename T, int MAXC, int PW, int LW, bool DB, int WPS>
+__global__ __launch_bounds__(64 * LW, WPS) void als_gen_solve_left_kernel(GenArgs<T> ga) {
+  using GS = GenSolve<T>;
+  using Tr = MfmaTraits<T>;
+  using acc_t = typename Tr::acc_t;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const StepArgs<T> &a = ga.a;
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int NB = ga.nb, k = a.k, NT = tile_count(NB);
+  const int kDiag = a.kReal > 0 ? a.kReal : k;
+  constexpr int LDW = GS::LDW, WB = LW - 1, NTHR = 64 * LW;
+  T *Dt = reinterpret_cast<T *>(smem), *Wt = Dt + 16 * LDW;
+  T *bvec = Wt + 16 * LDW, *zvec = bvec + NB * 16, *xvec = zvec + NB * 16;
+  int *flag = reinterpret_cast<int *>(xvec + NB * 16);
+  T *blk = xvec + NB * 16 + 16;  // blk[r][r2]: tile U[Jb + r][Jb + r2] of the current block, in register order
+  const SplitRow sr = a.split[ga.firstSplit + blockIdx.x];
+  const int64_t se = gen_slab_elems(NB);
+  T *S = a.slabs + (int64_t)(sr.slab0 - ga.slabBase) * se;
+  const int64_t ne = (int64_t)NT * 256;
+  for (int i = tid; i < NB * 16; i += NTHR) {
+    T v = S[ne + i];
+    for (int sl = 1; sl < sr.nslabs; ++sl) v += S[(int64_t)sl * se + ne + i];
+    bvec[i] = v;
+  }
+  if (tid == 0) *flag = 0;
+  __syncthreads();
+  const T lam = (T)(a.lambda * (double)sr.n);
+  T dmin = T(3.0e38);
+  const bool c0 = c == 0;
+  auto ld_rhs = [&](const T *vec, int b) {  // block b of a vector as a tile with the vector in column 0
+    acc_t v;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) v[t] = c0 ? vec[b * 16 + Tr::cd_row(lane, t)] : T(0);
+    return v;
+  };
+  auto st_rhs = [&](T *vec, int b, const acc_t &v) {
+    if (c0) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) vec[b * 16 + Tr::cd_row(lane, t)] = v[t];
+    }
+  };
+  auto neg = [](acc_t v) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = -v[q];
+    return v;
+  };
+  for (int Jb = 0; Jb < NB; Jb += PW) {
+    int bjx[MAXC];  // this wave's block columns, clamped to the matrix
+#pragma unroll
+    for (int x = 0; x < MAXC; ++x) bjx[x] = Jb + wave + LW * x < NB ? Jb + wave + LW * x : NB - 1;
+    // ---- 1. the block's rows of A
+    acc_t acc[PW][MAXC], tb[PW];
+#pragma unroll
+    for (int r = 0; r < PW; ++r) {
+      const int bi = Jb + r < NB ? Jb + r : NB - 1;
+#pragma unroll
+      for (int x = 0; x < MAXC; ++x) {
+        const int bj = bjx[x] > bi ? bjx[x] : bi;
+        const T *tl = S + (int64_t)tile_index(bi, bj, NB) * 256;
+        acc_t v = gen_ld_tile<T>(tl, lane);
+        for (int sl = 1; sl < sr.nslabs; ++sl) {
+          const acc_t w = gen_ld_tile<T>(tl + (int64_t)sl * se, lane);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) v[t] += w[t];
+        }
+        if (bj == bi) {  // (wave-uniform) + lambda n on the real diagonal, 1 on the padded one
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            if (Tr::cd_row(lane, t) == c) v[t] += (16 * bi + c < kDiag) ? lam : T(1);
+        }
+        acc[r][x] = v;
+      }
+      tb[r] = ld_rhs(bvec, bi);
+    }
+    // ---- 2. minus the finished rows
+    if (Jb > 0) {
+      acc_t Pi[PW], Pj[MAXC], Pin[DB ? PW : 1], Pjn[DB ? MAXC : 1];
+      auto fetch = [&](int I, acc_t(&pi)[PW], acc_t(&pj)[MAXC]) {
+        const T *rowI = S + ((int64_t)tile_index(I, I, NB) - I) * 256;  // tile (I, bj) at rowI + 256 bj
+#pragma unroll
+        for (int r = 0; r < PW; ++r) pi[r] = gen_ld_tile<T>(rowI + (Jb + r < NB ? Jb + r : NB - 1) * 256, lane);
+#pragma unroll
+        for (int x = 0; x < MAXC; ++x) pj[x] = gen_ld_tile<T>(rowI + bjx[x] * 256, lane);
+      };
+      const int nx = (NB - Jb + LW - 1) / LW;  // column slots in use in this block (the same for every wave: a wave whose last one lies beyond the edge multiplies a clamped tile)
+      auto apply = [&](int I, acc_t(&pi)[PW], acc_t(&pj)[MAXC]) {
+        acc_t nP[PW];
+#pragma unroll
+        for (int r = 0; r < PW; ++r) nP[r] = neg(pi[r]);
+#pragma unroll
+        for (int x = 0; x < MAXC; ++x) {
+          if (x < nx) {  // workgroup-uniform
+#pragma unroll
+            for (int r = 0; r < PW; ++r)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) acc[r][x] = Tr::mma(nP[r][q], pj[x][q], acc[r][x]);
+          }
+        }
+        if (wave == WB) {
+          const acc_t Z = ld_rhs(zvec, I);
+#pragma unroll
+          for (int r = 0; r < PW; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tb[r] = Tr::mma(nP[r][q], Z[q], tb[r]);
+        }
+      };
+      if constexpr (DB) {
+        fetch(0, Pi, Pj);
+        for (int I = 0; I < Jb; I += 2) {
+          if (I + 1 < Jb) fetch(I + 1, Pin, Pjn);
+          apply(I, Pi, Pj);
+          if (I + 1 < Jb) {
+            if (I + 2 < Jb) fetch(I + 2, Pi, Pj);
+            apply(I + 1, Pin, Pjn);
+          }
+        }
+      } else {
+        for (int I = 0; I < Jb; ++I) {
+          fetch(I, Pi, Pj);
+          apply(I, Pi, Pj);
+        }
+      }
+    }
+    // ---- 3. the rows of the block
+#pragma unroll
+    for (int r = 0; r < PW; ++r) {
+      const int J = Jb + r;
+      if (J < NB) {  // workgroup-uniform
+        if (wave == r) {  // (the diagonal tile of row J is this wave's first tile of the row)
+          const acc_t W = GS::diag_invert(acc[r][0], Dt, Wt, lane, dmin);
+          gen_st_tile<T>(S + (int64_t)tile_index(J, J, NB) * 256, lane, W);
+        }
+        __syncthreads();
+        T Aop[4];  // A operand of MFMA q: W[i = c][kk], kk = the C/D row of register q
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Aop[q] = Wt[Tr::cd_row(lane, q) * LDW + c];
+#pragma unroll
+        for (int x = 0; x < MAXC; ++x) {
+          const acc_t B = acc[r][x];
+          acc_t P = acc_t{T(0), T(0), T(0), T(0)};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) P = Tr::mma(Aop[q], B[q], P);
+          acc[r][x] = P;
+          const int bj = Jb + wave + LW * x;
+          if (bj > J && bj < NB) {  // wave-uniform
+            gen_st_tile<T>(S + (int64_t)tile_index(J, bj, NB) * 256, lane, P);
+            if (x == 0 && wave < PW) gen_st_tile<T>(blk + (r * PW + wave) * 256, lane, P);
+          }
+        }
+        acc_t ZJ = acc_t{T(0), T(0), T(0), T(0)};
+        if (wave == WB) {  // z_J = W b_J
+#pragma unroll
+          for (int q = 0; q < 4; ++q) ZJ = Tr::mma(Aop[q], tb[r][q], ZJ);
+          st_rhs(zvec, J, ZJ);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r2 = r + 1; r2 < PW; ++r2) {
+          if (Jb + r2 < NB) {
+            const acc_t nP = neg(gen_ld_tile<T>(blk + (r * PW + r2) * 256, lane));
+#pragma unroll
+            for (int x = 0; x < MAXC; ++x)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) acc[r2][x] = Tr::mma(nP[q], acc[r][x][q], acc[r2][x]);
+            if (wave == WB) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) tb[r2] = Tr::mma(nP[q], ZJ[q], tb[r2]);
+            }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- back substitution, right-looking: x_J = W_J^T z_J; z_bi -= U[bi][J] x_J for bi < J
+  for (int J = NB - 1; J >= 0; --J) {
+    if (wave == 0) {
+      const acc_t W = gen_ld_tile<T>(S + (int64_t)tile_index(J, J, NB) * 256, lane);
+      T s = T(0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) s = fma(W[t], zvec[J * 16 + Tr::cd_row(lane, t)], s);  // sum_r W[r][c] z[r], this group's rows
+      s = GS::group_sum(s);
+      if (g == 0) xvec[J * 16 + c] = s;
+    }
+    __syncthreads();
+    if (J == 0) break;
+    {
+      const T xc = xvec[J * 16 + c];
+      for (int bi = wave; bi < J; bi += LW) {
+        const acc_t U = gen_ld_tile<T>(S + (int64_t)tile_index(bi, J, NB) * 256, lane);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const T dsum = GS::row_sum(U[t] * xc);  // (U x)[row of register t]
+          if (c0) zvec[bi * 16 + Tr::cd_row(lane, t)] -= dsum;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  T *out = a.solved + (int64_t)sr.row * k;
+  T chk = T(0);
+  for (int i = tid; i < k; i += NTHR) {
+    const T x = xvec[i];
+    out[i] = x;
+    chk = fma(x, T(0), chk);
+  }
+  if (!(chk == T(0))) atomicOr(flag, 1);                       // NaN / Inf in the input ends up in x
+  if (lane == 0 && !(dmin > T(0))) atomicOr(flag, 1);          // a real pivot was not positive
+  __syncthreads();
+  if (tid == 0 && *flag) {
+    atomicAdd(&a.err->count, 1);
+    a.err->firstRow = sr.row;
+  }
+}
+__host__ __device__ constexpr size_t gen_solve_left_lds_bytes(int nb, size_t ts, int pw) {
+  return (2 * 16 * (ts == 8 ? 18 : 20) + 3 * (size_t)nb * 16 + 16 + (size_t)pw * pw * 256) * ts + 64;
 }
 
 __host__ __device__ constexpr size_t gen_solve_lds_bytes(int nb, size_t ts, bool panelLds) {

@@ -625,12 +625,32 @@ int launch_step_gen(const StepArgs<T> &args, const std::vector<GenBatch> &batche
   if (lds > 160 * 1024) return fail(YCNR_ERR_UNSUPPORTED, "factorsCount %d: the right-hand side does not fit a CU's LDS", args.k);
   const void *solveFn = panelLds ? reinterpret_cast<const void *>(als_gen_solve_kernel<T, true>) : reinterpret_cast<const void *>(als_gen_solve_kernel<T, false>);
   if (int rc = set_max_lds(solveFn, lds)) return rc;
+  // the left-looking solve where a block of four rows fits the registers of eight waves: float32 up to k = 512, float64 up to 256 (beyond: the right-looking kernel)
+  // (YCNR_GEN_RIGHT_LOOKING: the right-looking kernel everywhere, for A/B runs)
+  static const bool rightOnly = getenv("YCNR_GEN_RIGHT_LOOKING") != nullptr;
+  const void *leftFn = nullptr;
+  int leftWaves = 8, leftPw = 4;
+  if (!rightOnly) {
+    if constexpr (sizeof(T) == 4) {
+      const int maxc = (ga.nb + 7) / 8;
+      leftFn = maxc <= 2 ? reinterpret_cast<const void *>(als_gen_solve_left_kernel<T, 2, 4, 8, true, 2>)
+               : maxc <= 4 ? reinterpret_cast<const void *>(als_gen_solve_left_kernel<T, 4, 4, 8, true, 2>) : nullptr;
+    } else if (ga.nb <= 16) {
+      // (k = 256, 200 K x 20 K, per iteration: right-looking 301 ms; 4 rows x 8 waves as in float32, one workgroup per CU: 347;
+      // 2 rows x 8 waves, two per CU: 277; 2 rows x 4 waves, three per CU: 253)
+      leftFn = reinterpret_cast<const void *>(als_gen_solve_left_kernel<T, 4, 2, 4, false, 3>);
+      leftWaves = 4, leftPw = 2;
+    }
+  }
+  const size_t leftLds = gen_solve_left_lds_bytes(ga.nb, sizeof(T), leftPw);
+  if (leftFn)
+    if (int rc = set_max_lds(leftFn, leftLds)) return rc;
   // Gramian: 16-byte loads when every row of the fixed matrix starts on a 16-byte boundary, single elements otherwise;
-  // the waves of a workgroup share the squares of a pass evenly; R ratings per panel: as many as two buffers of <= 72 KB
+  // the waves of a workgroup share the rectangles of a pass evenly; R ratings per panel: as many as two buffers of <= 72 KB
   // (two workgroups per CU) and the loader's slots allow, at least 4
   constexpr int V = 16 / (int)sizeof(T);
   const bool vec = args.k % V == 0 && (reinterpret_cast<uintptr_t>(args.fixed) & 15) == 0;
-  const int nSq = gen_squares(ga.nb), passes = (nSq + kGenGramMaxWaves - 1) / kGenGramMaxWaves;
+  const int nSq = gen_items(ga.nb, gen_sqw<T>()), passes = (nSq + kGenGramMaxWaves - 1) / kGenGramMaxWaves;
   const int waves = std::max(2, (nSq + passes - 1) / passes), nthr = 64 * waves;
   const int P = gen_panel_pitch(ga.nb, sizeof(T));
   const int slots = vec ? gen_loader_slots<T, V>() : gen_loader_slots<T, 1>();
@@ -649,8 +669,14 @@ int launch_step_gen(const StepArgs<T> &args, const std::vector<GenBatch> &batche
     if (vec) hipLaunchKernelGGL((als_gen_gram_kernel<T, V>), dim3((unsigned)b.nSlabs), dim3(nthr), gramLds, stream, ga, R, P);
     else hipLaunchKernelGGL((als_gen_gram_kernel<T, 1>), dim3((unsigned)b.nSlabs), dim3(nthr), gramLds, stream, ga, R, P);
     HIP_TRY(hipGetLastError());
-    if (panelLds) hipLaunchKernelGGL((als_gen_solve_kernel<T, true>), dim3((unsigned)b.nSplit), dim3(kGenThreads), lds, stream, ga);
-    else hipLaunchKernelGGL((als_gen_solve_kernel<T, false>), dim3((unsigned)b.nSplit), dim3(kGenThreads), lds, stream, ga);
+    if (leftFn) {
+      void *kargs[] = {(void *)&ga};
+      HIP_TRY(hipLaunchKernel(leftFn, dim3((unsigned)b.nSplit), dim3(64 * leftWaves), kargs, leftLds, stream));
+    } else if (panelLds) {
+      hipLaunchKernelGGL((als_gen_solve_kernel<T, true>), dim3((unsigned)b.nSplit), dim3(kGenThreads), lds, stream, ga);
+    } else {
+      hipLaunchKernelGGL((als_gen_solve_kernel<T, false>), dim3((unsigned)b.nSplit), dim3(kGenThreads), lds, stream, ga);
+    }
     HIP_TRY(hipGetLastError());
   }
   if (ev) {
