@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--workload", default="mal", choices=sorted(WORKLOADS))
     ap.add_argument("--double", action="store_true", help="useDoublePrecision")
     ap.add_argument("--chunk", type=int, default=0, help="ratings per split work unit (0 = library default)")
+    ap.add_argument("--factors", type=int, default=0, help="experiments: factorsCount instead of the workload's (the line is then NOT the workload's metric; config.factors says so)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for functional tests)")
@@ -121,6 +122,8 @@ def main():
     if args.emulate_world > 1:
         return emulate_world(args, local_rank)
     users, items, nnz_target, k, max_rating, zipf_a, sigma, desc = WORKLOADS[args.workload]
+    if args.factors:
+        k, desc = args.factors, desc + f" [factorsCount overridden: {args.factors}]"
     dev = torch.device("cuda", local_rank)
     t0 = time.time()
     tdt = torch.float64 if args.double else torch.float32
@@ -470,6 +473,8 @@ def emulate_world(args, local_rank):
     from ycnr_als.emf import Dataset, EmfLord, rebalanced_ranges
     W = args.emulate_world
     users, items, nnz_target, k, max_rating, zipf_a, sigma, desc = WORKLOADS[args.workload]
+    if args.factors:
+        k, desc = args.factors, desc + f" [factorsCount overridden: {args.factors}]"
     dev = torch.device("cuda", local_rank)
     tdt = torch.float64 if args.double else torch.float32
     by_user, by_item = synth_ratings(users, items, nnz_target, max_rating=max_rating, seed=20260004, device=dev, dtype=tdt,
