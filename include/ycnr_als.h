@@ -245,6 +245,13 @@ int ycnr_als_step(ycnr_als *h, int side);
 int ycnr_als_step_async(ycnr_als *h, int side);
 int ycnr_als_sync(ycnr_als *h);
 int ycnr_als_last_step_info(ycnr_als *h, ycnr_als_step_info *info);
+/* Half-steps of both sides may be in flight at once (ycnr_als_step_async(BY_USER), ycnr_als_step_async(BY_ITEM),
+ * ycnr_als_sync: EmfLord.alsTrainIter, lib/emf/EmfLord.js:954-958, without the host in between); ycnr_als_sync completes
+ * every half-step in flight and keeps the step info of each side: this returns that of the last completed half-step of ONE
+ * side (ycnr_als_last_step_info: of the last one enqueued).  Rows that were not positive definite are counted since the
+ * last sync and reported with the last half-step completed.  (The hosts of this repository await each step: measured,
+ * csrc/devtest/tried/NOTES_r04.md.) */
+int ycnr_als_step_info_of(ycnr_als *h, int side, ycnr_als_step_info *info);
 
 /* ---- multi-GPU: row shards + exchange -------------------------------------------
  *

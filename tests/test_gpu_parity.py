@@ -331,6 +331,43 @@ def test_graph_replay_does_not_change_results(als, dt):
     assert np.array_equal(res["graph"][0], res["launches"][0]) and np.array_equal(res["graph"][1], res["launches"][1])
 
 
+@pytest.mark.parametrize("users,items,density", [(3000, 1200, 0.1), (400, 300, 0.2)])
+def test_iteration_in_flight_equals_two_awaited_steps(als, users, items, density):
+    """AlsDevice.iteration() -- both half-steps of EmfLord.alsTrainIter (lib/emf/EmfLord.js:954-958) enqueued before the host
+    waits, ycnr_als_step_info_of for the infos -- against step('byUser'); step('byItem'): the same factors bit for bit over
+    four iterations (first launch by launch, then captured, then replayed as graphs at the larger size; plain launches at the
+    smaller), the infos of the two sides kept apart, numeric errors of a half-step in flight reported by the sync."""
+    from ycnr_als import YcnrError, _lib
+    k = 36
+    bu, bi, U, V = make_problem(users, items, k, density=density, seed=91, dtype=np.float32, empty_rows=(4,))
+    res = {}
+    for name in ("awaited", "in flight"):
+        dev = als.AlsDevice(k, users, items, chunkRatings=32)
+        dev.set_ratings("byUser", bu.rowPtr, bu.indx, bu.vals)
+        dev.set_ratings("byItem", bi.rowPtr, bi.indx, bi.vals)
+        dev.set_factors("byUser", U)
+        dev.set_factors("byItem", V)
+        for _ in range(4):
+            iu, ii = (dev.step("byUser"), dev.step("byItem")) if name == "awaited" else dev.iteration()
+            assert (iu.side, ii.side) == (_lib.BY_USER, _lib.BY_ITEM)
+            assert iu.ratings == bu.nnz and ii.ratings == bi.nnz and iu.rows == users - 1
+            assert iu.numericErrors == 0 and ii.numericErrors == 0 and iu.totalMs > 0 and ii.totalMs > 0
+        res[name] = (dev.get_factors("byUser"), dev.get_factors("byItem"))
+        if name == "in flight":
+            bad = res[name][1].copy()
+            bad[7, 3] = np.nan
+            dev.set_factors("byItem", bad)
+            with pytest.raises(YcnrError) as e:
+                dev.iteration()
+            assert e.value.code == _lib.ERR_NUMERIC
+            dev.set_factors("byUser", U)
+            dev.set_factors("byItem", V)
+            iu, ii = dev.iteration()
+            assert iu.numericErrors == 0 and ii.numericErrors == 0
+        dev.destroy()
+    assert np.array_equal(res["awaited"][0], res["in flight"][0]) and np.array_equal(res["awaited"][1], res["in flight"][1])
+
+
 @pytest.mark.parametrize("k", [4, 8, 12, 16, 24, 32, 48, 52, 80, 96, 108, 112])
 def test_lds_dma_gramian_every_block_count(als, k):
     """The LDS-DMA staged bf16x6 Gramian (k % 4 == 0, k <= 112) at every block count, with the

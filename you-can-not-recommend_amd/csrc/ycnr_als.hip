@@ -946,9 +946,17 @@ struct ycnr_als {
   ErrInfo *hErr = nullptr;
   int32_t errSeen = 0;
   void *dZeros = nullptr;  // the zero "factor row" read for ratings past a unit's end
-  ycnr_als_step_info info{};
-  bool infoPending = false;
-  int infoSide = 0;
+  ycnr_als_step_info info{};  // of the half-step being enqueued / completed
+  bool infoPending = false;   // some half-step has been enqueued and not completed by ycnr_als_sync
+  int infoSide = 0;           // side of the last half-step enqueued
+  // Half-steps of BOTH sides may be in flight (ycnr_als_step_async twice, then ycnr_als_sync: a whole iteration without the
+  // host in between).  What ycnr_als_sync needs of each, in the order they were enqueued:
+  struct Pending {
+    ycnr_als_step_info info{};
+    bool graphRun = false, exchanged = false;
+  } pend[2];
+  int pendOrder[2] = {0, 0}, nPend = 0;
+  ycnr_als_step_info infoOf[2] = {};  // the last completed half-step of each side
 
   int64_t rows(int side) const { return side == YCNR_BY_USER ? opt.totalUsersCount : opt.totalItemsCount; }
   size_t ts() const { return tsize(opt.dtype); }
@@ -2096,6 +2104,15 @@ int ycnr_als_step_async(ycnr_als *h, int side) {
   }
   h->infoPending = true;
   h->infoSide = side;
+  // (the same side twice without a sync: its events have been re-recorded, the earlier half-step's times are gone)
+  int np = 0;
+  for (int i = 0; i < h->nPend; ++i)
+    if (h->pendOrder[i] != side) h->pendOrder[np++] = h->pendOrder[i];
+  h->pendOrder[np++] = side;
+  h->nPend = np;
+  h->pend[side].info = h->info;
+  h->pend[side].graphRun = h->graphRun;
+  h->pend[side].exchanged = h->exchangedInStep;
   return YCNR_OK;
 }
 
@@ -2104,9 +2121,16 @@ int ycnr_als_sync(ycnr_als *h) {
   HIP_TRY(hipSetDevice(h->opt.device));
   HIP_TRY(hipStreamSynchronize(h->stream));
   if (int rcf = ipc_finish(h->comm)) return rcf;  // IPC: every rank's pushes have landed everywhere
-  if (h->infoPending) {
-    h->infoPending = false;
-    const std::vector<Part> &parts = h->parts[h->infoSide];
+  const int nPend = h->infoPending ? h->nPend : 0;
+  h->infoPending = false;
+  h->nPend = 0;
+  for (int pi = 0; pi < nPend; ++pi) {
+    const int pside = h->pendOrder[pi];
+    const bool last = pi + 1 == nPend;
+    h->info = h->pend[pside].info;
+    h->graphRun = h->pend[pside].graphRun;
+    h->exchangedInStep = h->pend[pside].exchanged;
+    const std::vector<Part> &parts = h->parts[pside];
     float ms = 0;
     if (h->graphRun && !parts.empty()) {
       // one interval for the whole half-step: chunks -> reduce, the row kernel and the dual classes ran as branches of one graph
@@ -2147,10 +2171,13 @@ int ycnr_als_sync(ycnr_als *h) {
         }
       }
     }
+    // (the error counter is cumulative and copied at the end of every half-step: with two half-steps in flight the rows
+    // counted since the last sync are reported with the last one)
     ErrInfo ei = *h->hErr;  // copied by the step's stream, which has drained
-    ei.count -= h->errSeen;
+    ei.count = last ? ei.count - h->errSeen : 0;
     h->errSeen += ei.count;
     h->info.numericErrors = ei.count;
+    h->infoOf[pside] = h->info;
 #ifdef YCNR_WG_STAMPS
     if (const char *path = getenv("YCNR_DUMP_STAMPS")) {
       std::vector<unsigned char> buf(kErrBytes);
@@ -2178,6 +2205,15 @@ int ycnr_als_last_step_info(ycnr_als *h, ycnr_als_step_info *info) {
   if (!h || !info) return fail(YCNR_ERR_INVALID, "null argument");
   if (h->infoPending) return fail(YCNR_ERR_STATE, "last_step_info: call ycnr_als_sync first");
   *info = h->info;
+  return YCNR_OK;
+}
+
+int ycnr_als_step_info_of(ycnr_als *h, int side, ycnr_als_step_info *info) {
+  if (!h || !info) return fail(YCNR_ERR_INVALID, "null argument");
+  if (side != YCNR_BY_USER && side != YCNR_BY_ITEM) return fail(YCNR_ERR_INVALID, "bad side %d", side);
+  if (h->infoPending) return fail(YCNR_ERR_STATE, "step_info_of: call ycnr_als_sync first");
+  if (h->infoOf[side].struct_size == 0) return fail(YCNR_ERR_STATE, "step_info_of: no half-step of this side has been completed");
+  *info = h->infoOf[side];
   return YCNR_OK;
 }
 

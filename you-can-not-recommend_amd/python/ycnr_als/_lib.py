@@ -34,7 +34,7 @@ EXPORTS = [
     "ycnr_als_create", "ycnr_als_destroy", "ycnr_als_set_stream", "ycnr_als_set_ratings",
     "ycnr_als_set_rmse_ratings", "ycnr_als_set_factors", "ycnr_als_get_factors", "ycnr_als_factors_ptr",
     "ycnr_als_bind_factors", "ycnr_als_step", "ycnr_als_step_async", "ycnr_als_sync",
-    "ycnr_als_last_step_info", "ycnr_als_rmse",
+    "ycnr_als_last_step_info", "ycnr_als_step_info_of", "ycnr_als_rmse",
     "ycnr_split_to_sets", "ycnr_rating_stats", "ycnr_csr_from_triplets", "ycnr_csr_transpose",
     "ycnr_recommend_items",
     "ycnr_comm_unique_id", "ycnr_als_comm_init", "ycnr_als_comm_destroy", "ycnr_als_set_ratings_sharded",
@@ -136,6 +136,8 @@ def load():
     L.ycnr_als_sync.argtypes = [vp]
     L.ycnr_als_last_step_info.restype = i32
     L.ycnr_als_last_step_info.argtypes = [vp, C.POINTER(StepInfo)]
+    L.ycnr_als_step_info_of.restype = i32
+    L.ycnr_als_step_info_of.argtypes = [vp, i32, C.POINTER(StepInfo)]
     L.ycnr_als_rmse.restype = i32
     L.ycnr_als_rmse.argtypes = [vp, i32, dbl, i32, vp, vp]
     L.ycnr_split_to_sets.restype = i32

@@ -301,6 +301,20 @@ class AlsDevice:
     def sync(self):
         check(self._L.ycnr_als_sync(self._h))
 
+    def step_info(self, side):
+        """StepInfo of the last completed half-step of one side (after sync)."""
+        info = _lib.StepInfo()
+        check(self._L.ycnr_als_step_info_of(self._h, SIDES[side], C.byref(info)))
+        return info
+
+    def iteration(self):
+        """EmfLord.alsTrainIter (EmfLord.js:954-958) without the host between the two half-steps: both enqueued, one sync.
+        Returns (StepInfo byUser, StepInfo byItem)."""
+        self.step_async("byUser")
+        self.step_async("byItem")
+        self.sync()
+        return self.step_info("byUser"), self.step_info("byItem")
+
     def last_step_info(self):
         info = _lib.StepInfo()
         check(self._L.ycnr_als_last_step_info(self._h, C.byref(info)))
