@@ -67,10 +67,10 @@ __device__ __forceinline__ void gen_st_tile(T *tile, int lane, const typename Mf
 // PANELS of R ratings x k factors in LDS (whole 16-byte loads where every row of the fixed matrix is 16-byte aligned; two LDS
 // buffers, one barrier per panel; while panel p is multiplied the values of panels p + 1 and p + 2 are in registers or in
 // flight and the ids of panel p + 3 requested: with one panel ahead a CU had 32 KB in flight, and the gathers' latency under
-// load -- 3 us -- bounded the kernel at 2 TB/s) and every wave keeps ONE rectangle of kGenSq x (SQW kGenSq) tiles in registers per
+// load -- 3 us -- bounded the kernel at 2 TB/s) and every wave keeps ONE rectangle of SR x CW tiles in registers per
 // pass over the unit's ratings, its operands read from the panel in MFMA layout (lane (g, c): factor 16 cb + c of rating
-// 4 s + g; the row pitch P puts the four lane groups on different banks).  float32: 4 x 8 tiles, three passes of seven
-// waves at k = 512; float64: 4 x 4, two passes of five at k = 256.
+// 4 s + g; the row pitch P puts the four lane groups on different banks).  float32: 4 x 4 tiles, five passes of eight
+// waves at k = 512; float64: 2 x 4, three passes of seven at k = 256.
 // 200 K x 20 K, 20 M ratings, per iteration: k = 512 float32 902 (strips) -> 606 (squares from cache) -> see DESIGN.md.
 constexpr int kGenSq = 4;
 constexpr int kGenGramMaxWaves = 8;
@@ -83,12 +83,16 @@ struct alignas(sizeof(T) * V) GenVec {
   T e[V];
 };
 
-// rectangles of a matrix of nb block columns: block rows in fours, from the diagonal to the right in steps of 4 sqw
-__host__ __device__ constexpr int gen_items(int nb, int sqw) {
+// rectangles of sr x cw tiles over a matrix of nb block columns: block rows sr at a time, from the diagonal to the right in steps of cw
+__host__ __device__ constexpr int gen_items(int nb, int sr, int cw) {
   int n = 0;
-  for (int x = 0; x < nb; x += kGenSq) n += (nb - x + kGenSq * sqw - 1) / (kGenSq * sqw);
+  for (int x = 0; x < nb; x += sr) n += (nb - x + cw - 1) / cw;
   return n;
 }
+// block rows of a wave's rectangle: float64 tiles take twice the registers, and 2 x 4 tiles leave room for two waves per SIMD
+// of an eight-wave workgroup (k = 256: 20 rectangles, three passes of seven waves; 4 x 4 ran five waves on four SIMDs)
+template <typename T>
+constexpr int gen_rect_rows() { return sizeof(T) == 4 ? 4 : 2; }
 #ifndef YCNR_GEN_SQW_F32
 #define YCNR_GEN_SQW_F32 1  // (2 -- 4 x 8 tiles, three passes of seven waves at k = 512 -- measured slower: 269 against 241 ms per iteration)
 #endif
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(64 * kGenGramMaxWaves, YCNR_GEN_GRAM_WAVES_PER_SIMD
   using acc_t = typename Tr::acc_t;
   using Vec = GenVec<T, V>;
   constexpr int MAXI = gen_loader_slots<T, V>();
-  constexpr int SQW = gen_sqw<T>(), CW = SQW * kGenSq;
+  constexpr int SR = gen_rect_rows<T>(), CW = gen_sqw<T>() * kGenSq;  // a wave's rectangle: SR x CW tiles
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const StepArgs<T> &a = ga.a;
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
@@ -165,7 +169,7 @@ __global__ __launch_bounds__(64 * kGenGramMaxWaves, YCNR_GEN_GRAM_WAVES_PER_SIMD
     if (tid < R) rbuf[tid] = (p * R + tid < n) ? r : T(0);
   };
   const int64_t np = (n + R - 1) / R;
-  const int nItems = gen_items(NB, SQW);
+  const int nItems = gen_items(NB, SR, CW);
   __syncthreads();
   for (int item0 = 0; item0 < nItems; item0 += W) {
     // this wave's rectangle of the pass (wave-uniform)
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(64 * kGenGramMaxWaves, YCNR_GEN_GRAM_WAVES_PER_SIMD
     int bi0 = 0, bj0 = 0;
     {
       int it = 0;
-      for (int x = 0; x < NB; x += kGenSq)
+      for (int x = 0; x < NB; x += SR)
         for (int y = x; y < NB; y += CW, ++it)
           if (it == item) {
             bi0 = x;
@@ -182,19 +186,19 @@ __global__ __launch_bounds__(64 * kGenGramMaxWaves, YCNR_GEN_GRAM_WAVES_PER_SIMD
           }
     }
     const bool diag = bj0 == bi0;
-    int ca[kGenSq], cb[CW];  // operand columns, clamped to the matrix: tiles beyond its edge are computed and not stored
+    int ca[SR], cb[CW];  // operand columns, clamped to the matrix: tiles beyond its edge are computed and not stored
 #pragma unroll
-    for (int i = 0; i < kGenSq; ++i) ca[i] = 16 * (bi0 + i < NB ? bi0 + i : NB - 1);
+    for (int i = 0; i < SR; ++i) ca[i] = 16 * (bi0 + i < NB ? bi0 + i : NB - 1);
 #pragma unroll
     for (int j = 0; j < CW; ++j) cb[j] = 16 * (bj0 + j < NB ? bj0 + j : NB - 1);
-    acc_t acc[kGenSq][CW];
+    acc_t acc[SR][CW];
 #pragma unroll
-    for (int i = 0; i < kGenSq; ++i)
+    for (int i = 0; i < SR; ++i)
 #pragma unroll
       for (int j = 0; j < CW; ++j) acc[i][j] = acc_t{T(0), T(0), T(0), T(0)};
-    T bacc[kGenSq];
+    T bacc[SR];
 #pragma unroll
-    for (int i = 0; i < kGenSq; ++i) bacc[i] = T(0);
+    for (int i = 0; i < SR; ++i) bacc[i] = T(0);
     // panel 0 into buffer 0, panel 1 into registers, the ids of panel 2 in flight
     int32_t idn[MAXI];
     Vec vA[MAXI], vB[MAXI];
@@ -237,29 +241,29 @@ __global__ __launch_bounds__(64 * kGenGramMaxWaves, YCNR_GEN_GRAM_WAVES_PER_SIMD
         if constexpr (sizeof(T) == 4) {
           // (the operands of step s + 1 are read from LDS before the MFMAs of step s are issued; float64 has no registers for it)
           const T *rowp = B + (int64_t)g * P + c;
-          T ya[kGenSq], yb[CW], r;
+          T ya[SR], yb[CW], r;
 #pragma unroll
-          for (int i = 0; i < kGenSq; ++i) ya[i] = rowp[ca[i]];
+          for (int i = 0; i < SR; ++i) ya[i] = rowp[ca[i]];
 #pragma unroll
           for (int j = 0; j < CW; ++j) yb[j] = rowp[cb[j]];
           r = rb[g];  // b rides with the rectangles on the diagonal (the others do not store it)
           for (int s4 = 0; s4 < R; s4 += 4) {
             const int sn = s4 + 4 < R ? s4 + 4 : s4;  // (the last step reads its own operands again)
             const T *rown = B + (int64_t)(sn + g) * P + c;
-            T yan[kGenSq], ybn[CW];
+            T yan[SR], ybn[CW];
 #pragma unroll
-            for (int i = 0; i < kGenSq; ++i) yan[i] = rown[ca[i]];
+            for (int i = 0; i < SR; ++i) yan[i] = rown[ca[i]];
 #pragma unroll
             for (int j = 0; j < CW; ++j) ybn[j] = rown[cb[j]];
             const T rn = rb[sn + g];
 #pragma unroll
-            for (int i = 0; i < kGenSq; ++i) bacc[i] = fma(ya[i], r, bacc[i]);
+            for (int i = 0; i < SR; ++i) bacc[i] = fma(ya[i], r, bacc[i]);
 #pragma unroll
-            for (int i = 0; i < kGenSq; ++i)
+            for (int i = 0; i < SR; ++i)
 #pragma unroll
               for (int j = 0; j < CW; ++j) acc[i][j] = Tr::mma(ya[i], yb[j], acc[i][j]);
 #pragma unroll
-            for (int i = 0; i < kGenSq; ++i) ya[i] = yan[i];
+            for (int i = 0; i < SR; ++i) ya[i] = yan[i];
 #pragma unroll
             for (int j = 0; j < CW; ++j) yb[j] = ybn[j];
             r = rn;
@@ -267,16 +271,16 @@ __global__ __launch_bounds__(64 * kGenGramMaxWaves, YCNR_GEN_GRAM_WAVES_PER_SIMD
         } else {
           for (int s4 = 0; s4 < R; s4 += 4) {
             const T *rowp = B + (int64_t)(s4 + g) * P + c;
-            T ya[kGenSq], yb[CW];
+            T ya[SR], yb[CW];
 #pragma unroll
-            for (int i = 0; i < kGenSq; ++i) ya[i] = rowp[ca[i]];
+            for (int i = 0; i < SR; ++i) ya[i] = rowp[ca[i]];
 #pragma unroll
             for (int j = 0; j < CW; ++j) yb[j] = rowp[cb[j]];
             const T r = rb[s4 + g];
 #pragma unroll
-            for (int i = 0; i < kGenSq; ++i) bacc[i] = fma(ya[i], r, bacc[i]);
+            for (int i = 0; i < SR; ++i) bacc[i] = fma(ya[i], r, bacc[i]);
 #pragma unroll
-            for (int i = 0; i < kGenSq; ++i)
+            for (int i = 0; i < SR; ++i)
 #pragma unroll
               for (int j = 0; j < CW; ++j) acc[i][j] = Tr::mma(ya[i], yb[j], acc[i][j]);
           }
@@ -296,7 +300,7 @@ __global__ __launch_bounds__(64 * kGenGramMaxWaves, YCNR_GEN_GRAM_WAVES_PER_SIMD
     }
     if (active) {
 #pragma unroll
-      for (int i = 0; i < kGenSq; ++i) {
+      for (int i = 0; i < SR; ++i) {
 #pragma unroll
         for (int j = 0; j < CW; ++j)
           if (bi0 + i < NB && bj0 + j < NB && bj0 + j >= bi0 + i)

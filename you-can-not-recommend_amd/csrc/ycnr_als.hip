@@ -650,7 +650,7 @@ int launch_step_gen(const StepArgs<T> &args, const std::vector<GenBatch> &batche
   // (two workgroups per CU) and the loader's slots allow, at least 4
   constexpr int V = 16 / (int)sizeof(T);
   const bool vec = args.k % V == 0 && (reinterpret_cast<uintptr_t>(args.fixed) & 15) == 0;
-  const int nSq = gen_items(ga.nb, gen_sqw<T>()), passes = (nSq + kGenGramMaxWaves - 1) / kGenGramMaxWaves;
+  const int nSq = gen_items(ga.nb, gen_rect_rows<T>(), gen_sqw<T>() * kGenSq), passes = (nSq + kGenGramMaxWaves - 1) / kGenGramMaxWaves;
   const int waves = std::max(2, (nSq + passes - 1) / passes), nthr = 64 * waves;
   const int P = gen_panel_pitch(ga.nb, sizeof(T));
   const int slots = vec ? gen_loader_slots<T, V>() : gen_loader_slots<T, 1>();
