@@ -2289,8 +2289,15 @@ __global__ __launch_bounds__(64, 2) void als_gram_solve_x6p_kernel(StepArgs<floa
 #ifndef YCNR_DUAL7_WAVES
 #define YCNR_DUAL7_WAVES 1
 #endif
+// The 5-block class (65 ... 80 ratings, the largest of the MAL shape's dual classes) at THREE waves per SIMD: with the next K-step's raw
+// values double-buffered it takes 224 registers; in the row-by-row form of the classes above 6 blocks (operand planes single-
+// buffered, AHEAD = false) and with the ratings loaded behind the Gramian loop (LATE_RHS) it takes 168, no scratch.
+// MAL user half-step 12.23 -> 12.13 ms (interleaved A/B, same box); classes 3 / 4 one wave higher (5 / 4) spill 20 bytes.
+#ifndef YCNR_DUAL5_WAVES
+#define YCNR_DUAL5_WAVES 3
+#endif
 template <int NBN, bool X6>
-__global__ __launch_bounds__(64, NBN == 3 ? 4 : NBN == 4 ? 3 : NBN == 7 ? YCNR_DUAL7_WAVES : 1) void als_dual_solve_kernel(StepArgs<float> a) {
+__global__ __launch_bounds__(64, NBN == 3 ? 4 : NBN == 4 ? 3 : NBN == 5 ? YCNR_DUAL5_WAVES : NBN == 7 ? YCNR_DUAL7_WAVES : 1) void als_dual_solve_kernel(StepArgs<float> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using Sv = SolveMfmaF32<NBN>;
   using Tr = MfmaTraits<float>;
@@ -2311,7 +2318,7 @@ __global__ __launch_bounds__(64, NBN == 3 ? 4 : NBN == 4 ? 3 : NBN == 7 ? YCNR_D
 #ifdef YCNR_DUAL_EARLY_RHS  // devtest: the round-3 form (with YCNR_DUAL7_WAVES=2: 24 bytes of scratch per lane in the 7-block class)
   constexpr bool LATE_RHS = false;
 #else
-  constexpr bool LATE_RHS = NBN >= 7;
+  constexpr bool LATE_RHS = NBN >= 7 || (NBN == 5 && YCNR_DUAL5_WAVES >= 3);
 #endif
 #pragma unroll
   for (int ba = 0; ba < NBN; ++ba) {
@@ -2386,7 +2393,7 @@ __global__ __launch_bounds__(64, NBN == 3 ? 4 : NBN == 4 ? 3 : NBN == 7 ? YCNR_D
     // split into the same registers while the rows below still multiply, and its raw values are requested one row
     // ahead (the scheme of GramX6D).  Before: every block loaded just before its split, one wave per SIMD, nothing to
     // hide the loads behind.
-    constexpr bool AHEAD = NBN <= 6;
+    constexpr bool AHEAD = NBN <= 6 && !(NBN == 5 && YCNR_DUAL5_WAVES >= 3);
     auto split8 = [&](const float4 &z0, const float4 &z1, u32x4 &o1, u32x4 &o2, u32x4 &o3) {
       const float x[8] = {z0.x, z0.y, z0.z, z0.w, z1.x, z1.y, z1.z, z1.w};
       unsigned h[4], m[4], l[4];
