@@ -2744,8 +2744,20 @@ __global__ __launch_bounds__(64) void als_dual_quad_kernel(StepArgs<float> a, in
 }
 
 // Kernel 2: one wave per split row -- sum its slabs in slab order, then solve.
-template <typename T, int NB, bool LDS_SOLVER, bool EDGE, bool E4 = false>
-__global__ __launch_bounds__(64) void als_reduce_solve_kernel(StepArgs<T> a) {
+// Waves per SIMD the reduce + solve kernel's registers are bounded for.  Left to itself (one) hipcc takes 332 registers at k = 100
+// -- every load of a slab gets a register of its own -- and the kernel runs one wave per SIMD.  That is what rows of many
+// slabs want (the 64-slab items of the MAL shape bound the kernel by their own sum: 0.45 ms unbounded, 0.50 ms at three
+// waves per SIMD).  FEW: no row of the upload has more than kFewSlabs slabs -- the small shapes, where the kernel is a
+// wave of solves: bounded to 168 registers (no scratch where listed) three waves share a SIMD; ML-1M shape user half-step
+// 0.193 -> 0.182 ms.
+constexpr int kFewSlabs = 8;
+template <typename T, int NB, bool LDS_SOLVER, bool E4, bool FEW>
+constexpr int reduce_waves() {
+  if (!FEW || sizeof(T) != 4 || LDS_SOLVER) return 1;
+  return NB <= 6 ? 3 : NB == 7 ? (E4 ? 3 : 2) : 1;
+}
+template <typename T, int NB, bool LDS_SOLVER, bool EDGE, bool E4 = false, bool FEW = false>
+__global__ __launch_bounds__(64, (reduce_waves<T, NB, LDS_SOLVER, E4, FEW>())) void als_reduce_solve_kernel(StepArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using G = typename GramSel<T, NB, EDGE>::type;
   using acc_t = typename G::acc_t;

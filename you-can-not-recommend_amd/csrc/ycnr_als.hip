@@ -129,6 +129,7 @@ struct Schedule {
   float *dRowSlabs = nullptr;  // k > 240: the images of a batch of whole rows between their Gramian and their two-wave solve
   int64_t rowSlabRows = 0;
   int64_t nUnits = 0, nSplit = 0, nSlabs = 0, solvedRows = 0, fusedRatings = 0;
+  int32_t maxRowSlabs = 0;  // most slabs any split row has
   // whole-row units: [nSlabs, nSlabs + nPrimal) primal form, then dual classes m = kMaxDualBlocks..1
   int64_t nPrimal = 0, dualFirst[kMaxDualBlocks + 1] = {}, dualCount[kMaxDualBlocks + 1] = {};
   int64_t dualRows = 0, dualRatings = 0;
@@ -144,6 +145,7 @@ struct Schedule {
     dSplit = nullptr;
     dSlabs = nullptr;
     nUnits = nSplit = nSlabs = solvedRows = fusedRatings = nPrimal = dualRows = dualRatings = 0;
+    maxRowSlabs = 0;
     dualFlops = 0;
     genBatches.clear();
     for (int m = 0; m <= kMaxDualBlocks; ++m) dualFirst[m] = dualCount[m] = 0;
@@ -267,6 +269,7 @@ constexpr int64_t kMinOverlapDualRows = 1024;  // fewer dual-form rows than this
 
 struct DualPlan {
   bool noX6 = false;     // YCNR_FLAG_NO_BF16X6: float32-MFMA Gramian in the dual kernels too
+  bool fewSlabs = false; // no split row of the piece has more than kFewSlabs slabs (als_reduce_solve_kernel<..., FEW>)
   int64_t nPrimal = -1;  // < 0: no dual classes, every whole row goes through the primal kernel
   const int64_t *first = nullptr, *count = nullptr;
   // Side streams (unless YCNR_FLAG_NO_OVERLAP): the dual classes are independent of the row
@@ -387,10 +390,13 @@ int launch_nbe(StepArgs<T> args, int64_t nUnits, int64_t nSplitUnits, int64_t nS
   if (SLABX6 && slab_x6d_kernel<T, NB>(args.k) && !env_flags().noX6d) k0 = slab_x6d_kernel<T, NB>(args.k);
   void (*k1)(StepArgs<T>) = als_gram_solve_kernel<T, NB, LDS_SOLVER, EDGE, false>;
   void (*k2)(StepArgs<T>) = als_reduce_solve_kernel<T, NB, LDS_SOLVER, EDGE && !SLABX6, false>;
+  if constexpr (std::is_same<T, float>::value && !LDS_SOLVER)
+    if (dp.fewSlabs) k2 = als_reduce_solve_kernel<T, NB, LDS_SOLVER, EDGE && !SLABX6, false, true>;
   if constexpr (std::is_same<T, float>::value && NB >= 2 && !LDS_SOLVER) {
     if (edge4_k<NB, LDS_SOLVER>(args.k)) {
       k1 = als_gram_solve_kernel<T, NB, LDS_SOLVER, EDGE, true>;
       k2 = als_reduce_solve_kernel<T, NB, LDS_SOLVER, EDGE && !SLABX6, true>;
+      if (dp.fewSlabs) k2 = als_reduce_solve_kernel<T, NB, LDS_SOLVER, EDGE && !SLABX6, true, true>;
     }
   }
   if (SLABX6 && fused_x6d_kernel<T, NB, LDS_SOLVER>(args.k) && !env_flags().noX6d && !env_flags().noFusedX6d)
@@ -1636,6 +1642,8 @@ static int build_part(ycnr_als *h, int side, const int64_t *rowPtr, const int32_
   }
   S.nUnits = (int64_t)units.size();
   S.nSplit = (int64_t)split.size();
+  S.maxRowSlabs = 0;
+  for (const SplitRow &sr : split) S.maxRowSlabs = std::max(S.maxRowSlabs, sr.nslabs);
   S.nSlabs = nSlabs;
   S.solvedRows = solved;
   S.fusedRatings = 0;
@@ -1888,6 +1896,7 @@ static int launch_part(ycnr_als *h, int side, Part &part, hipStream_t stream, bo
     }
     DualPlan dp;
     dp.noX6 = (h->opt.flags & YCNR_FLAG_NO_BF16X6) != 0;
+    dp.fewSlabs = S.maxRowSlabs <= kFewSlabs;
     if (dual_max_ratings(h->opt) > 0) {
       dp.nPrimal = S.nPrimal;
       dp.first = S.dualFirst;
