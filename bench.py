@@ -194,10 +194,10 @@ def main():
             for sd in ("byUser", "byItem")}
 
     def x6_of(side):
-        # bf16x6 Gramian: the LDS-DMA kernels (k % 4 == 0, k <= 112, fixed matrix < 2 GB) and the
+        # bf16x6 Gramian: the LDS-DMA kernels (k % 4 == 0, k <= 128, fixed matrix < 2 GB) and the
         # workgroup-per-row kernels of k > 128 (als_wg_*, any fixed matrix size)
         fixed_rows = items if side == "byUser" else users
-        return (not args.double) and (128 < k <= 256 or (k % 4 == 0 and k <= 112 and fixed_rows * k * 4 < 2 ** 31))
+        return (not args.double) and (128 < k <= 256 or (k % 4 == 0 and k <= 128 and fixed_rows * k * 4 < 2 ** 31))
 
     gen_path = k > (128 if args.double else 256)  # als_gen_kernels.hip.h: float32 / float64 MFMA, matrix in global memory
     for st in lord.stepTimes:

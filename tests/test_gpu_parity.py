@@ -368,9 +368,9 @@ def test_iteration_in_flight_equals_two_awaited_steps(als, users, items, density
     assert np.array_equal(res["awaited"][0], res["in flight"][0]) and np.array_equal(res["awaited"][1], res["in flight"][1])
 
 
-@pytest.mark.parametrize("k", [4, 8, 12, 16, 24, 32, 48, 52, 80, 96, 108, 112])
+@pytest.mark.parametrize("k", [4, 8, 12, 16, 24, 32, 48, 52, 80, 96, 108, 112, 116, 120, 124, 128])
 def test_lds_dma_gramian_every_block_count(als, k):
-    """The LDS-DMA staged bf16x6 Gramian (k % 4 == 0, k <= 112) at every block count, with the
+    """The LDS-DMA staged bf16x6 Gramian (k % 4 == 0, k <= 128; eight blocks at one wave per SIMD) at every block count, with the
     right-hand side in the padded column (k % 16 != 0) and on the VALU (k % 16 == 0): whole rows of
     1..4 steps including exact multiples of 32 ratings (fused row kernel; the dual form is switched
     off so that short rows take it too) and split rows (chunk kernel + reduce)."""

@@ -2137,7 +2137,7 @@ struct GramX6P {
 };
 
 template <int NB, bool PADRHS, bool PK3 = false>
-__global__ __launch_bounds__(64, 2) void als_gram_slab_x6d_kernel(StepArgs<float> a) {
+__global__ __launch_bounds__(64, NB <= 7 ? 2 : 1) void als_gram_slab_x6d_kernel(StepArgs<float> a) {
   using G = GramX6D<NB, PADRHS, PK3>;
   using acc_t = typename G::acc_t;
   constexpr int NT = G::NT;
@@ -2204,7 +2204,7 @@ __global__ __launch_bounds__(64, sizeof(T) == 8 ? 1 : YCNR_FUSED_WAVES_PER_SIMD)
 // Kernel 1b': the fused row kernel with the bf16x6 / LDS-DMA Gramian (GramX6D) in place of the
 // float32-MFMA one; the solve is unchanged.  float32, k % 4 == 0, k <= 112, fixed matrix < 2 GB.
 template <int NB, bool PADRHS, bool LDS_SOLVER, bool E4 = false, bool PK3 = false>
-__global__ __launch_bounds__(64, 2) void als_gram_solve_x6d_kernel(StepArgs<float> a) {
+__global__ __launch_bounds__(64, NB <= 7 ? 2 : 1) void als_gram_solve_x6d_kernel(StepArgs<float> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using G = GramX6D<NB, PADRHS, PK3>;
   using acc_t = typename G::acc_t;
@@ -2246,7 +2246,7 @@ __global__ __launch_bounds__(64, 2) void als_gram_solve_x6d_kernel(StepArgs<floa
 // in the slots' LDS once the Gramian has drained (19 KB per wave at k = 100: eight waves per CU).
 // float32, k % 4 == 0, k <= 112, k % 16 != 0, plane matrix < 2 GB.
 template <int NB, bool PACK, bool E4>
-__global__ __launch_bounds__(64, 2) void als_gram_solve_x6p_kernel(StepArgs<float> a) {
+__global__ __launch_bounds__(64, NB <= 7 ? 2 : 1) void als_gram_solve_x6p_kernel(StepArgs<float> a) {
   using G = GramX6P<NB, PACK>;
   using GD = GramX6D<NB, true, PACK>;  // (extract_rhs: the padded column leaves the tiles the same way)
   using acc_t = typename G::acc_t;

@@ -347,13 +347,14 @@ YCNR_X6(1) YCNR_X6(2) YCNR_X6(3) YCNR_X6(4) YCNR_X6(5) YCNR_X6(6) YCNR_X6(7) YCN
 template <int NB>
 bool pk3_k(int k) { return k == 16 * (NB - 1) + 4 && !env_flags().noPk3; }
 
-// the same Gramian with the gather staged through LDS by LDS-DMA: fits two waves per SIMD up to k = 112
+// the same Gramian with the gather staged through LDS by LDS-DMA: two waves per SIMD up to k = 112, one from 116 to 128 (round 4:
+// these eight-block sizes used to fall to the float32-MFMA kernels -- MAL shape, k = 128: 58.9 ms per iteration against 23.4 at k = 112)
 template <typename T, int NB>
 void (*slab_x6d_kernel(int))(StepArgs<T>) { return nullptr; }
 #define YCNR_X6D(NBV) \
   template <>         \
   void (*slab_x6d_kernel<float, NBV>(int k))(StepArgs<float>) { return k % 4 ? nullptr : k < 16 * NBV ? (pk3_k<NBV>(k) ? als_gram_slab_x6d_kernel<NBV, true, true> : als_gram_slab_x6d_kernel<NBV, true, false>) : als_gram_slab_x6d_kernel<NBV, false>; }
-YCNR_X6D(1) YCNR_X6D(2) YCNR_X6D(3) YCNR_X6D(4) YCNR_X6D(5) YCNR_X6D(6) YCNR_X6D(7)
+YCNR_X6D(1) YCNR_X6D(2) YCNR_X6D(3) YCNR_X6D(4) YCNR_X6D(5) YCNR_X6D(6) YCNR_X6D(7) YCNR_X6D(8)
 #undef YCNR_X6D
 
 // k = 16 (NB - 1) + 4 in float32 with the register solver: the instantiations that eliminate the four edge
@@ -366,7 +367,7 @@ void (*fused_x6d_kernel(int))(StepArgs<T>) { return nullptr; }
 #define YCNR_X6D(NBV, LDSV) \
   template <>               \
   void (*fused_x6d_kernel<float, NBV, LDSV>(int k))(StepArgs<float>) { return k % 4 ? nullptr : k < 16 * NBV ? (edge4_k<NBV, LDSV>(k) ? (pk3_k<NBV>(k) ? als_gram_solve_x6d_kernel<NBV, true, LDSV, true, true> : als_gram_solve_x6d_kernel<NBV, true, LDSV, true, false>) : (pk3_k<NBV>(k) ? als_gram_solve_x6d_kernel<NBV, true, LDSV, false, true> : als_gram_solve_x6d_kernel<NBV, true, LDSV, false, false>)) : als_gram_solve_x6d_kernel<NBV, false, LDSV, false>; }
-YCNR_X6D(1, false) YCNR_X6D(2, false) YCNR_X6D(3, false) YCNR_X6D(4, false) YCNR_X6D(5, false) YCNR_X6D(6, false) YCNR_X6D(7, false)
+YCNR_X6D(1, false) YCNR_X6D(2, false) YCNR_X6D(3, false) YCNR_X6D(4, false) YCNR_X6D(5, false) YCNR_X6D(6, false) YCNR_X6D(7, false) YCNR_X6D(8, false)
 YCNR_X6D(1, true) YCNR_X6D(2, true) YCNR_X6D(3, true) YCNR_X6D(4, true) YCNR_X6D(5, true) YCNR_X6D(6, true) YCNR_X6D(7, true)
 #undef YCNR_X6D
 
@@ -377,7 +378,7 @@ void (*fused_x6p_kernel(int))(StepArgs<T>) { return nullptr; }
 #define YCNR_X6P(NBV) \
   template <>         \
   void (*fused_x6p_kernel<float, NBV>(int k))(StepArgs<float>) { return (k % 4 || k >= 16 * NBV || k <= 16 * (NBV - 1)) ? nullptr : (NBV >= 2 && planes_pack(k)) ? als_gram_solve_x6p_kernel<NBV, (NBV >= 2), (NBV >= 2)> : als_gram_solve_x6p_kernel<NBV, false, false>; }
-YCNR_X6P(1) YCNR_X6P(2) YCNR_X6P(3) YCNR_X6P(4) YCNR_X6P(5) YCNR_X6P(6) YCNR_X6P(7)
+YCNR_X6P(1) YCNR_X6P(2) YCNR_X6P(3) YCNR_X6P(4) YCNR_X6P(5) YCNR_X6P(6) YCNR_X6P(7) YCNR_X6P(8)
 #undef YCNR_X6P
 
 // SLABX6: split chunks go through the bf16x6 Gramian kernel (plain slab layout), so the reduce
@@ -402,7 +403,7 @@ int launch_nbe(StepArgs<T> args, int64_t nUnits, int64_t nSplitUnits, int64_t nS
   if (SLABX6 && fused_x6d_kernel<T, NB, LDS_SOLVER>(args.k) && !env_flags().noX6d && !env_flags().noFusedX6d)
     k1 = fused_x6d_kernel<T, NB, LDS_SOLVER>(args.k);
   size_t ldsRow = lds;  // dynamic LDS of the row kernel: the solver's image
-  if constexpr (SLABX6 && !LDS_SOLVER && NB <= 7) {
+  if constexpr (SLABX6 && !LDS_SOLVER && NB <= 8) {
     if (args.planes && fused_x6p_kernel<T, NB>(args.k)) {  // the half-step split the fixed matrix into planes
       k1 = fused_x6p_kernel<T, NB>(args.k);
       ldsRow = 0;  // (its solver works in the slots of the Gramian)
@@ -751,14 +752,14 @@ bool use_slab_x6(const ycnr_als_options &o, int side) {
          fixedRows * o.factorsCount * 4 < ((int64_t)1 << 31);
 }
 
-// The fused row kernel on pre-split planes (GramX6P): float32 bf16x6 path, k % 4 == 0, k <= 112 with a padded column for
+// The fused row kernel on pre-split planes (GramX6P): float32 bf16x6 path, k % 4 == 0, k <= 124 with a padded column for
 // the right-hand side (k % 16 != 0), and a plane matrix (96 bytes per 16-column block and row) that stays cache-resident.
 constexpr int64_t kPlanesMaxBytes = (int64_t)64 << 20;
 bool use_planes(const ycnr_als_options &o, int side) {
   static const bool off = getenv("YCNR_NO_X6P") != nullptr;
   const int64_t fixedRows = side == YCNR_BY_USER ? o.totalItemsCount : o.totalUsersCount;
   const int k = o.factorsCount;
-  return !off && use_slab_x6(o, side) && !(o.flags & YCNR_FLAG_LDS_SOLVER) && k % 4 == 0 && k <= 112 && k % 16 != 0 &&
+  return !off && use_slab_x6(o, side) && !(o.flags & YCNR_FLAG_LDS_SOLVER) && k % 4 == 0 && k <= 124 && k % 16 != 0 &&
          fixedRows * planes_row_bytes(slab_nb(k), planes_pack(k)) <= kPlanesMaxBytes;
 }
 
