@@ -44,7 +44,8 @@ def problem(k=36, users=900, items=400, seed=3, density=0.08):
 # (k, users, items, seed, density): the default small problem; k = 100 (bf16x6 row kernel, packed last block, dual classes);
 # k = 256 with rows of ~190 ratings either side of the primal / dual crossover (Gramian -> slab -> four-wave solve in
 # batches, dual classes on the side streams) and items of ~330 ratings
-SHAPES = {"k36": (36, 900, 400, 3, 0.08), "k100": (100, 1200, 500, 4, 0.15), "k256": (256, 700, 400, 5, 0.47)}
+# k = 50 (float32, factorsCount % 4 != 0: the kernels work on copies padded to 52 columns, every piece unpads its rows before its exchange)
+SHAPES = {"k36": (36, 900, 400, 3, 0.08), "k100": (100, 1200, 500, 4, 0.15), "k256": (256, 700, 400, 5, 0.47), "k50": (50, 1000, 450, 6, 0.12)}
 
 
 def reference_iteration(als, k, users, items, bu, bi, U, V):
@@ -166,7 +167,7 @@ def _rank_main(rank, world, uid, pieces, out, transport="shm", device=0, shape="
 
 
 @pytest.mark.parametrize("transport,world,pieces,shape", [("shm", 2, 1, "k36"), ("shm", 3, 4, "k36"), ("ipc", 2, 1, "k36"), ("ipc", 3, 4, "k36"),
-                                                          ("ipc", 2, 3, "k100"), ("ipc", 2, 3, "k256"), ("shm", 3, 2, "k256")])
+                                                          ("ipc", 2, 3, "k100"), ("ipc", 2, 3, "k256"), ("shm", 3, 2, "k256"), ("ipc", 2, 3, "k50")])
 def test_ranks_of_one_node_on_one_gpu(als, transport, world, pieces, shape):
     """Several ranks sharing cuda:0: 'shm' stages rows through the host, 'ipc' is the device-to-device path -- every
     rank maps its peers' replicas (hipIpcOpenMemHandle) and pushes its solved rows into them piece by piece on

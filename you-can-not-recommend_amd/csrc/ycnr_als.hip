@@ -936,7 +936,8 @@ struct ycnr_als {
   // enough to stay cache-resident (the user half-step: the item matrix); planes[s] belongs to factors[s]
   unsigned short *planes[2] = {nullptr, nullptr};
   bool planesValid[2] = {false, false};  // the half-step in flight split factors[s] into planes[s]
-  int kPad = 0;                          // != 0: factorsCount padded to a multiple of 4 (k > 128, k % 4 != 0)
+  int kPad = 0;                          // != 0: float32, factorsCount % 4 != 0: the kernels work on copies padded to a multiple of 4
+  ycnr_als_options copt{};               // opt as the kernels see it: factorsCount = kPad when padded (schedules, kernel choice, slab sizes)
   float *padded[2] = {nullptr, nullptr};  // [rows x kPad] copies the kernels of that case work on
   bool autoChunk = false;  // options.chunkRatings was 0: sized per upload (auto_chunk)
   std::vector<Part> parts[2];      // the side's local row shard, cut into pipelined pieces (usually one)
@@ -1425,10 +1426,16 @@ int ycnr_als_create(const ycnr_als_options *o, ycnr_als **out) {
       e = hipMemsetAsync(h->factors[s], 0, (size_t)h->rows(s) * o->factorsCount * h->ts(), h->ownStream);
     }
   }
-  if (o->dtype == YCNR_F32 && o->factorsCount > kMaxFactors && o->factorsCount % 4 != 0) {
+  // float32 with factorsCount % 4 != 0: the kernels run on copies of the matrices padded to a multiple of 4 columns (zero columns:
+  // lambda n on their diagonal, x = 0 there, the other columns' arithmetic unchanged) -- rows are then 16-byte aligned and every
+  // such size takes the bf16x6 / LDS-DMA / dual-form kernels of its padded size instead of the plain float32-MFMA ones
+  // (round 3: k > 128 only; round 4: every k).  Costs a pad of the fixed side and an unpad of the solved rows per half-step.
+  if (o->dtype == YCNR_F32 && o->factorsCount % 4 != 0 && (o->factorsCount > kMaxFactors || !getenv("YCNR_NO_KPAD_SMALL"))) {  // (the variable: A/B runs)
     h->kPad = (o->factorsCount + 3) & ~3;
     for (int s = 0; s < 2 && e == hipSuccess; ++s) e = hipMalloc(&h->padded[s], (size_t)h->rows(s) * h->kPad * sizeof(float));
   }
+  h->copt = h->opt;
+  if (h->kPad) h->copt.factorsCount = h->kPad;
   if (e == hipSuccess) e = hipMalloc(&h->dErr, kErrBytes);  // ErrInfo + room for in-kernel stamps of diagnostic builds
   if (e == hipSuccess) e = hipMemsetAsync(h->dErr, 0, kErrBytes, h->ownStream);
   if (e == hipSuccess) e = hipHostMalloc((void **)&h->hErr, sizeof(ErrInfo), hipHostMallocDefault);
@@ -1547,19 +1554,19 @@ static int build_part(ycnr_als *h, int side, const int64_t *rowPtr, const int32_
   std::vector<Unit> units;
   std::vector<SplitRow> split;
   int64_t nSlabs = 0, solved = 0;
-  const bool gen = is_gen(h->opt.dtype, h->opt.factorsCount);  // any-k path: every primal row through slabs, in row order
-  const bool big = !gen && h->opt.factorsCount > kMaxFactors;
+  const bool gen = is_gen(h->copt.dtype, h->copt.factorsCount);  // any-k path: every primal row through slabs, in row order
+  const bool big = !gen && h->copt.factorsCount > kMaxFactors;
   // k > 128: a unit is a whole workgroup's work, so chunks are long (a slab is 140 KB at k = 256)
   // (an explicit options.chunkRatings is honoured there too: tests cut short rows into chunks with it)
   // The automatic chunk length follows the split rows of the WHOLE side (sideNnz: their ratings), not of this piece: where a
   // split row is cut decides the order its partial sums are added in, so a length that depended on the piece would make the
   // factors depend on how the rows are cut into shards and pieces (and a feedback re-cut would change them: round-3 review).
-  const int chunkRatings = h->autoChunk ? (gen ? kGenChunk : big ? kWgChunk : auto_chunk(sideNnz, sideSplitNnz)) : h->opt.chunkRatings;
+  const int chunkRatings = h->autoChunk ? (gen ? kGenChunk : big ? kWgChunk : auto_chunk(sideNnz, sideSplitNnz)) : h->copt.chunkRatings;
   if (gen)
-    build_schedule(hp.data(), rowBegin, rowEnd - rowBegin, chunkRatings, units, split, nSlabs, solved, dual_max_ratings(h->opt), 0);
+    build_schedule(hp.data(), rowBegin, rowEnd - rowBegin, chunkRatings, units, split, nSlabs, solved, dual_max_ratings(h->copt), 0);
   else
     build_schedule(hp.data(), rowBegin, rowEnd - rowBegin, chunkRatings, units, split, nSlabs, solved, -1,
-                   big && h->autoChunk ? kWgFusedMax : std::min(chunkRatings, h->opt.chunkRatings), big ? kMaxSlabsPerRowBig : kMaxSlabsPerRow);
+                   big && h->autoChunk ? kWgFusedMax : std::min(chunkRatings, h->copt.chunkRatings), big ? kMaxSlabsPerRowBig : kMaxSlabsPerRow);
   int64_t arenaSlabs = nSlabs;
   // Band-major chunks (unless YCNR_FLAG_NO_BANDS): when the fixed matrix is far larger than the
   // last-level cache, cut every split row at the same column-id boundaries ("bands" of
@@ -1569,10 +1576,10 @@ static int build_part(ycnr_als *h, int side, const int64_t *rowPtr, const int32_
   // column id (they are when they come from a CSR transpose); unsorted rows only lose locality.
   {
     const int64_t fixedRows = h->rows(1 - side);
-    const int64_t rowBytes = (int64_t)h->opt.factorsCount * (int64_t)h->ts();
+    const int64_t rowBytes = (int64_t)h->copt.factorsCount * (int64_t)h->ts();
     int64_t bandBytes = kBandBytes;
     if (const char *e = getenv("YCNR_BAND_MB")) bandBytes = (int64_t)atoi(e) << 20;  // per upload, not per half-step: read live (tests set it)
-    if (!big && !gen && nSlabs > 1 && !(h->opt.flags & YCNR_FLAG_NO_BANDS) && bandBytes > 0 && fixedRows * rowBytes > 2 * bandBytes) {
+    if (!big && !gen && nSlabs > 1 && !(h->copt.flags & YCNR_FLAG_NO_BANDS) && bandBytes > 0 && fixedRows * rowBytes > 2 * bandBytes) {
       // at most kMaxSlabsPerRow / 2 bands, so that a row present in every band still has chunks to
       // spare (very large fixed matrices get wider bands instead of a failed upload)
       const int64_t W = std::max<int64_t>(std::max<int64_t>(1, bandBytes / rowBytes), (fixedRows + kMaxSlabsPerRow / 2 - 1) / (kMaxSlabsPerRow / 2));
@@ -1651,7 +1658,7 @@ static int build_part(ycnr_als *h, int side, const int64_t *rowPtr, const int32_
   for (size_t i = (size_t)nSlabs; i < units.size(); ++i) S.fusedRatings += units[i].end - units[i].beg;
   // whole rows are sorted by descending length: rows short enough for the dual form are the
   // tail of the list, grouped by their number of 16-rating blocks
-  const int dualMax = dual_max_ratings(h->opt);
+  const int dualMax = dual_max_ratings(h->copt);
   S.nPrimal = 0;
   for (size_t i = (size_t)nSlabs; i < units.size(); ++i) {
     const int64_t n = units[i].end - units[i].beg;
@@ -1667,7 +1674,7 @@ static int build_part(ycnr_als *h, int side, const int64_t *rowPtr, const int32_
     const double nd = (double)n, kd = (double)h->opt.factorsCount;
     S.dualFlops += nd * (nd + 1) * kd + nd * nd * nd / 3.0 + 2.0 * nd * nd + 2.0 * nd * kd;
   }
-  if (big && slab_nb(h->kPad ? h->kPad : h->opt.factorsCount) == kPairNB && S.nPrimal > 0 && !env_flags().noPair) {
+  if (big && slab_nb(h->copt.factorsCount) == kPairNB && S.nPrimal > 0 && !env_flags().noPair) {
     int64_t batchRows = kPairBatchRows;
     if (const char *e = getenv("YCNR_PAIR_BATCH_ROWS")) batchRows = std::max(256, atoi(e));  // read per upload
     S.rowSlabRows = std::min<int64_t>(S.nPrimal, batchRows);
@@ -1684,8 +1691,8 @@ static int build_part(ycnr_als *h, int side, const int64_t *rowPtr, const int32_
       std::stable_sort(split.begin(), split.end(), [](const SplitRow &x, const SplitRow &y) { return x.nslabs > y.nslabs; });
     HIP_TRY(hipMalloc(&S.dSplit, sizeof(SplitRow) * split.size()));
     HIP_TRY(hipMemcpy(S.dSplit, split.data(), sizeof(SplitRow) * split.size(), hipMemcpyHostToDevice));
-    const size_t slabElems = gen ? (size_t)gen_slab_elems(slab_nb(h->opt.factorsCount))
-                                 : big ? (size_t)wg_slab_floats(slab_nb(h->opt.factorsCount)) : (size_t)slab_regs(h->opt, side) * 64;
+    const size_t slabElems = gen ? (size_t)gen_slab_elems(slab_nb(h->copt.factorsCount))
+                                 : big ? (size_t)wg_slab_floats(slab_nb(h->copt.factorsCount)) : (size_t)slab_regs(h->copt, side) * 64;
     if (gen) {
       // rows are solved in batches whose slabs fit the arena (a k = 512 float32 image is 541 KB)
       int64_t arenaBytes = kGenArenaBytes;
@@ -1882,29 +1889,29 @@ static int launch_part(ycnr_als *h, int side, Part &part, hipStream_t stream, bo
   const Ratings &R = part.R;
   const Schedule &S = part.S;
   hipEvent_t *ev = branches ? nullptr : part.ev;
-  const double lambda = side == YCNR_BY_USER ? h->opt.userFactReg : h->opt.itemFactReg;
-  if (h->opt.dtype == YCNR_F32) {
-    const int kk = h->kPad ? h->kPad : h->opt.factorsCount;
+  const double lambda = side == YCNR_BY_USER ? h->copt.userFactReg : h->copt.itemFactReg;
+  if (h->copt.dtype == YCNR_F32) {
+    const int kk = h->copt.factorsCount;  // (= kPad when the matrices are padded)
     const float *fixedM = h->kPad ? h->padded[1 - side] : (const float *)h->factors[1 - side];
     float *solvedM = h->kPad ? h->padded[side] : (float *)h->factors[side];
     StepArgs<float> a{S.dUnits, S.dSplit, R.dIndx, (const float *)R.dVals, fixedM,
                       (const float *)h->dZeros, solvedM, (float *)S.dSlabs, h->dErr, lambda, kk, 0, 0,
-                      use_slab_x6(h->opt, side) ? (uint32_t)(h->rows(1 - side) * h->opt.factorsCount * 4) : 0u};
+                      use_slab_x6(h->copt, side) ? (uint32_t)(h->rows(1 - side) * h->copt.factorsCount * 4) : 0u};
     if (h->kPad) a.kReal = h->opt.factorsCount;
-    if (h->planes[1 - side] && h->planesValid[1 - side] && use_planes(h->opt, side)) {
+    if (h->planes[1 - side] && h->planesValid[1 - side] && use_planes(h->copt, side)) {
       a.planes = h->planes[1 - side];
-      a.planesBytes = (uint32_t)(h->rows(1 - side) * planes_row_bytes(slab_nb(h->opt.factorsCount), planes_pack(h->opt.factorsCount)));
+      a.planesBytes = (uint32_t)(h->rows(1 - side) * planes_row_bytes(slab_nb(h->copt.factorsCount), planes_pack(h->copt.factorsCount)));
     }
     DualPlan dp;
-    dp.noX6 = (h->opt.flags & YCNR_FLAG_NO_BF16X6) != 0;
+    dp.noX6 = (h->copt.flags & YCNR_FLAG_NO_BF16X6) != 0;
     dp.fewSlabs = S.maxRowSlabs <= kFewSlabs;
-    if (dual_max_ratings(h->opt) > 0) {
+    if (dual_max_ratings(h->copt) > 0) {
       dp.nPrimal = S.nPrimal;
       dp.first = S.dualFirst;
       dp.count = S.dualCount;
       // (the fork and join cost nine more runtime calls per half-step: with a few hundred rows,
       // where the half-step is bound by the launches themselves, they made it slower)
-      if ((S.dualRows >= kMinOverlapDualRows || (branches && S.dualRows > 0)) && !inOrder && !(h->opt.flags & YCNR_FLAG_NO_OVERLAP) && !env_flags().noOverlap) {
+      if ((S.dualRows >= kMinOverlapDualRows || (branches && S.dualRows > 0)) && !inOrder && !(h->copt.flags & YCNR_FLAG_NO_OVERLAP) && !env_flags().noOverlap) {
         // (a captured small half-step keeps two branches for its dual classes: every branch is a join, 30 - 60 us each)
         dp.nSide = branches ? std::min(2, side_streams()) : side_streams();
         for (int i = 0; i < dp.nSide; ++i) {
@@ -1919,32 +1926,33 @@ static int launch_part(ycnr_als *h, int side, Part &part, hipStream_t stream, bo
       dp.slabStream = h->pieceStream[0];
       dp.slabJoin = part.slabJoin;
     }
-    if (h->opt.factorsCount > kMaxFactors) {
-      int rc = is_gen(YCNR_F32, h->opt.factorsCount) ? launch_step_gen<float>(a, S.genBatches, stream, ev, dp)
-                                                     : launch_step_big(a, S.nUnits, S.nSlabs, S.nSplit, stream, ev, dp, S.dRowSlabs, S.rowSlabRows);
-      if (rc || !h->kPad) return rc;
-      // the piece's solved rows back into the caller's matrix (before its exchange)
-      const int64_t nr = R.rowEnd - R.rowBegin, n = nr * h->opt.factorsCount;
-      if (n > 0) {
-        hipLaunchKernelGGL(unpad_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const float *)h->padded[side],
-                           (float *)h->factors[side], R.rowBegin, nr, h->opt.factorsCount, h->kPad);
-        HIP_TRY(hipGetLastError());
-      }
-      return YCNR_OK;
+    int rc;
+    if (h->copt.factorsCount > kMaxFactors)
+      rc = is_gen(YCNR_F32, h->copt.factorsCount) ? launch_step_gen<float>(a, S.genBatches, stream, ev, dp)
+                                                  : launch_step_big(a, S.nUnits, S.nSlabs, S.nSplit, stream, ev, dp, S.dRowSlabs, S.rowSlabRows);
+    else
+      rc = launch_step<float>(a, S.nUnits, S.nSlabs, S.nSplit, stream, ev, (h->copt.flags & YCNR_FLAG_LDS_SOLVER) != 0, dp,
+                              use_valu_edge(h->copt), use_slab_x6(h->copt, side));
+    if (rc || !h->kPad) return rc;
+    // the piece's solved rows back into the caller's matrix (before its exchange)
+    const int64_t nr = R.rowEnd - R.rowBegin, n = nr * h->opt.factorsCount;
+    if (n > 0) {
+      hipLaunchKernelGGL(unpad_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const float *)h->padded[side],
+                         (float *)h->factors[side], R.rowBegin, nr, h->opt.factorsCount, h->kPad);
+      HIP_TRY(hipGetLastError());
     }
-    return launch_step<float>(a, S.nUnits, S.nSlabs, S.nSplit, stream, ev, (h->opt.flags & YCNR_FLAG_LDS_SOLVER) != 0, dp,
-                              use_valu_edge(h->opt), use_slab_x6(h->opt, side));
+    return YCNR_OK;
   }
   StepArgs<double> a{S.dUnits, S.dSplit, R.dIndx, (const double *)R.dVals, (const double *)h->factors[1 - side],
-                     (const double *)h->dZeros, (double *)h->factors[side], (double *)S.dSlabs, h->dErr, lambda, h->opt.factorsCount, 0, 0, 0u};
-  if (is_gen(YCNR_F64, h->opt.factorsCount)) return launch_step_gen<double>(a, S.genBatches, stream, ev, DualPlan());
+                     (const double *)h->dZeros, (double *)h->factors[side], (double *)S.dSlabs, h->dErr, lambda, h->copt.factorsCount, 0, 0, 0u};
+  if (is_gen(YCNR_F64, h->copt.factorsCount)) return launch_step_gen<double>(a, S.genBatches, stream, ev, DualPlan());
   DualPlan dpd;  // float64 has no dual classes; the chunk branch of the small-upload form applies
   dpd.fork = part.fork;
   if (branches) {
     dpd.slabStream = h->pieceStream[0];
     dpd.slabJoin = part.slabJoin;
   }
-  return launch_step<double>(a, S.nUnits, S.nSlabs, S.nSplit, stream, ev, (h->opt.flags & YCNR_FLAG_LDS_SOLVER) != 0, dpd);
+  return launch_step<double>(a, S.nUnits, S.nSlabs, S.nSplit, stream, ev, (h->copt.flags & YCNR_FLAG_LDS_SOLVER) != 0, dpd);
 }
 
 // row ranges of piece c of every rank (sharded upload)
@@ -2006,21 +2014,21 @@ int ycnr_als_step_async(ycnr_als *h, int side) {
   // (not for uploads below kGraphMinRatings, whose half-step is a handful of launches: one more launch costs what the planes save)
   int64_t sideRatings = 0;
   for (const Part &p : parts) sideRatings += p.R.nnz;
-  const bool planesNow = use_planes(h->opt, side) && sideRatings >= kGraphMinRatings;
+  const bool planesNow = use_planes(h->copt, side) && sideRatings >= kGraphMinRatings;
   if (!planesNow) h->planesValid[1 - side] = false;
   auto split_planes = [&]() -> int {
     if (!planesNow) return YCNR_OK;
     h->planesValid[1 - side] = true;
-    const int s = 1 - side, nb = slab_nb(h->opt.factorsCount);
-    const bool pack = planes_pack(h->opt.factorsCount);
+    const int s = 1 - side, nb = slab_nb(h->copt.factorsCount);
+    const bool pack = planes_pack(h->copt.factorsCount);
     const int64_t n = h->rows(s) * nb * 4;
-    hipLaunchKernelGGL(als_split_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, (const float *)h->factors[s], h->planes[s],
-                       h->rows(s), h->opt.factorsCount, nb, pack ? 1 : 0);
+    hipLaunchKernelGGL(als_split_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->kPad ? (const float *)h->padded[s] : (const float *)h->factors[s], h->planes[s],
+                       h->rows(s), h->copt.factorsCount, nb, pack ? 1 : 0);
     HIP_TRY(hipGetLastError());
     return YCNR_OK;
   };
   if (planesNow && !h->planes[1 - side])
-    HIP_TRY(hipMalloc(&h->planes[1 - side], (size_t)h->rows(1 - side) * (size_t)planes_row_bytes(slab_nb(h->opt.factorsCount), planes_pack(h->opt.factorsCount))));
+    HIP_TRY(hipMalloc(&h->planes[1 - side], (size_t)h->rows(1 - side) * (size_t)planes_row_bytes(slab_nb(h->copt.factorsCount), planes_pack(h->copt.factorsCount))));
   memset(&h->info, 0, sizeof h->info);
   // Small uploads (the ML-100k / ML-1M shapes): ~15 launches, forks and joins of a half-step whose kernels each fill a
   // fraction of the chip.  Captured once in the branch form (launch_part) and replayed: one launch per half-step.
@@ -2094,7 +2102,7 @@ int ycnr_als_step_async(ycnr_als *h, int side) {
   h->info.struct_size = (int32_t)sizeof(ycnr_als_step_info);
   h->info.side = side;
   h->info.parts = (int32_t)parts.size();
-  const bool dual = h->opt.dtype == YCNR_F32 && dual_max_ratings(h->opt) > 0;
+  const bool dual = h->opt.dtype == YCNR_F32 && dual_max_ratings(h->copt) > 0;
   for (const Part &p : parts) {
     const Schedule &S = p.S;
     h->info.rows += S.solvedRows;
@@ -2107,7 +2115,7 @@ int ycnr_als_step_async(ycnr_als *h, int side) {
       h->info.dualRows += S.dualRows;
       h->info.dualRatings += S.dualRatings;
       h->info.dualFlops += S.dualFlops;
-      if (S.dualRows >= kMinOverlapDualRows && !is_gen(YCNR_F32, h->opt.factorsCount) && !(h->opt.flags & YCNR_FLAG_NO_OVERLAP) &&
+      if (S.dualRows >= kMinOverlapDualRows && !is_gen(YCNR_F32, h->copt.factorsCount) && !(h->opt.flags & YCNR_FLAG_NO_OVERLAP) &&
           !env_flags().noOverlap)
         h->info.dualOverlapped = 1;
     }
