@@ -197,7 +197,10 @@ def main():
         # bf16x6 Gramian: the LDS-DMA kernels (k % 4 == 0, k <= 128, fixed matrix < 2 GB) and the
         # workgroup-per-row kernels of k > 128 (als_wg_*, any fixed matrix size)
         fixed_rows = items if side == "byUser" else users
-        return (not args.double) and (128 < k <= 256 or (k % 4 == 0 and k <= 128 and fixed_rows * k * 4 < 2 ** 31))
+        # (float32 of other sizes runs padded to a multiple of 4 columns), and the any-k path's Gramian where a panel of 32 ratings
+        # fits a workgroup's LDS (k % 4 == 0, k <= 576: als_gen_gram_kernel<float, 4, true>)
+        kp = (k + 3) // 4 * 4
+        return (not args.double) and (128 < k <= 256 or (kp <= 128 and fixed_rows * kp * 4 < 2 ** 31) or (k > 256 and k % 4 == 0 and k <= 576))
 
     gen_path = k > (128 if args.double else 256)  # als_gen_kernels.hip.h: float32 / float64 MFMA, matrix in global memory
     for st in lord.stepTimes:
@@ -235,8 +238,10 @@ def main():
             whole_rows = (row_k, dual_k)
         if gen_path:
             # the any-k path reports its Gramian -> slab and slab -> solve kernels (batches of both) as one interval
-            split_k = (("als_gen_gram_kernel+als_gen_solve_kernel", i.gramSlabMs + i.reduceSolveMs, 0.0,
-                        chunk_ratings * gram_rating + i.splitRows * solve_row, chunk_ratings * bytes_rating + i.splitRows * (k * s + 8)),)
+            # (Gramian flops against the bf16 pipe's float32-equivalent peak when it runs there, else with the solve's on the fp32 / fp64 pipe)
+            gx = x6_of(side)
+            split_k = (("als_gen_gram_kernel+als_gen_solve_kernel", i.gramSlabMs + i.reduceSolveMs, chunk_ratings * gram_rating if gx else 0.0,
+                        (0.0 if gx else chunk_ratings * gram_rating) + i.splitRows * solve_row, chunk_ratings * bytes_rating + i.splitRows * (k * s + 8)),)
         elif slab_in_group:
             split_k = (("als_reduce_solve_kernel", i.reduceSolveMs, 0.0, i.splitRows * solve_row, i.splitRows * (k * s + 8)),)
         else:

@@ -107,12 +107,38 @@ template <typename T, int V>
 constexpr int gen_loader_slots() { return V == 1 ? 8 : 4; }
 __host__ __device__ constexpr size_t gen_gram_lds_bytes(int R, int P, size_t ts) { return (size_t)2 * R * ((size_t)P + 1) * ts; }
 
-template <typename T, int V>
+typedef __bf16 gen_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned gen_u32x4 __attribute__((ext_vector_type(4)));
+// eight float32 values -> their three bf16 planes (exact: x = h + m + l, each the top 16 bits of what is left), two values per dword
+__device__ __forceinline__ void gen_split8(const float (&x)[8], gen_u32x4 &o1, gen_u32x4 &o2, gen_u32x4 &o3) {
+  unsigned h[4], m[4], l[4];
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {
+    const float x0 = x[2 * jj], x1 = x[2 * jj + 1];
+    const unsigned u0 = __builtin_bit_cast(unsigned, x0), u1 = __builtin_bit_cast(unsigned, x1);
+    h[jj] = __builtin_amdgcn_perm(u1, u0, 0x07060302);
+    const float s0 = x0 - __builtin_bit_cast(float, u0 & 0xFFFF0000u);
+    const float s1 = x1 - __builtin_bit_cast(float, u1 & 0xFFFF0000u);
+    const unsigned v0 = __builtin_bit_cast(unsigned, s0), v1 = __builtin_bit_cast(unsigned, s1);
+    m[jj] = __builtin_amdgcn_perm(v1, v0, 0x07060302);
+    const float t0 = s0 - __builtin_bit_cast(float, v0 & 0xFFFF0000u);
+    const float t1 = s1 - __builtin_bit_cast(float, v1 & 0xFFFF0000u);
+    l[jj] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, t1), __builtin_bit_cast(unsigned, t0), 0x07060302);
+  }
+  o1 = gen_u32x4{h[0], h[1], h[2], h[3]};
+  o2 = gen_u32x4{m[0], m[1], m[2], m[3]};
+  o3 = gen_u32x4{l[0], l[1], l[2], l[3]};
+}
+
+// X6 (float32 only, R % 32 == 0): the products on the bf16 pipe -- every wave splits the operands it reads from the panel into three
+// bf16 planes and multiplies six of the nine plane pairs (v_mfma_f32_16x16x32_bf16: 32 ratings per instruction; the dropped
+// pairs are below 2^-24 of the product), the arithmetic of the bf16x6 kernels of k <= 256.
+template <typename T, int V, bool X6 = false>
 __global__ __launch_bounds__(64 * kGenGramMaxWaves, YCNR_GEN_GRAM_WAVES_PER_SIMD) void als_gen_gram_kernel(GenArgs<T> ga, int R, int P) {
   using Tr = MfmaTraits<T>;
   using acc_t = typename Tr::acc_t;
   using Vec = GenVec<T, V>;
-  constexpr int MAXI = gen_loader_slots<T, V>();
+  constexpr int MAXI = X6 ? 8 : gen_loader_slots<T, V>();  // (X6: panels of 32 ratings)
   constexpr int SR = gen_rect_rows<T>(), CW = gen_sqw<T>() * kGenSq;  // a wave's rectangle: SR x CW tiles
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const StepArgs<T> &a = ga.a;
@@ -199,46 +225,49 @@ __global__ __launch_bounds__(64 * kGenGramMaxWaves, YCNR_GEN_GRAM_WAVES_PER_SIMD
     T bacc[SR];
 #pragma unroll
     for (int i = 0; i < SR; ++i) bacc[i] = T(0);
-    // panel 0 into buffer 0, panel 1 into registers, the ids of panel 2 in flight
-    int32_t idn[MAXI];
-    Vec vA[MAXI], vB[MAXI];
-    T rA = T(0), rB = T(0);
-#pragma unroll
-    for (int i = 0; i < MAXI; ++i) idn[i] = ld_idx(0, i);
-#pragma unroll
-    for (int i = 0; i < MAXI; ++i) vA[i] = ld_val(idn[i], i);
-    rA = ld_r(0);
-#pragma unroll
-    for (int i = 0; i < MAXI; ++i) idn[i] = ld_idx(1, i);
-    {
-      const unsigned live0 = live_mask(0);
-#pragma unroll
-      for (int i = 0; i < MAXI; ++i) st_val(buf0, vA[i], i, live0);
-      st_r(rb0, rA, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < MAXI; ++i) vB[i] = ld_val(idn[i], i);
-    rB = ld_r(1);
-#pragma unroll
-    for (int i = 0; i < MAXI; ++i) idn[i] = ld_idx(2, i);
-    __syncthreads();
-    // one panel: request panel p + 2 into (vX, rX), multiply panel p, write panel p + 1 from (vY, rY) into the other buffer
-    auto panel = [&](int64_t p, Vec(&vX)[MAXI], T &rX, Vec(&vY)[MAXI], T &rY) {
-      const T *B = (p & 1) ? buf1 : buf0, *rb = (p & 1) ? rb1 : rb0;
-      T *Bn = (p & 1) ? buf0 : buf1, *rbn = (p & 1) ? rb0 : rb1;
-      if (p + 2 < np) {  // workgroup-uniform
-#pragma unroll
-        for (int i = 0; i < MAXI; ++i) vX[i] = ld_val(idn[i], i);
-        rX = ld_r(p + 2);
-#pragma unroll
-        for (int i = 0; i < MAXI; ++i) idn[i] = ld_idx(p + 3, i);
-      }
+    // the products of one panel (B: its values, rb: its ratings)
+    auto multiply = [&](const T *B, const T *rb) {
       // Straight-line code, the same MFMAs per step for every rectangle: tiles beyond the matrix edge are computed from clamped
       // (valid) columns and the lower tiles of a rectangle on the diagonal from their transposes' operands -- none of them
       // is stored.  With a condition per tile every MFMA sat in a basic block of its own behind a scalar branch and a
       // wait; with one loop for whole rectangles and one for cut ones the accumulators were allocated twice.
       if (active) {
-        if constexpr (sizeof(T) == 4) {
+        if constexpr (X6 && sizeof(T) == 4) {
+          // lane (g, c) of an operand: factor column 16 cb + c, ratings 8 g ... 8 g + 7 of the 32-rating step
+          for (int s32 = 0; s32 < R; s32 += 32) {
+            const T *rowp = B + (int64_t)(s32 + 8 * g) * P + c;
+            gen_u32x4 ah[SR], am[SR], al[SR];
+#pragma unroll
+            for (int i = 0; i < SR; ++i) {
+              float v[8];
+#pragma unroll
+              for (int r8 = 0; r8 < 8; ++r8) v[r8] = rowp[(int64_t)r8 * P + ca[i]];
+              float bs = bacc[i];  // b rides with the rectangles on the diagonal (the others do not store it)
+#pragma unroll
+              for (int r8 = 0; r8 < 8; ++r8) bs = fmaf(v[r8], rb[s32 + 8 * g + r8], bs);
+              bacc[i] = bs;
+              gen_split8(v, ah[i], am[i], al[i]);
+            }
+#pragma unroll
+            for (int j = 0; j < CW; ++j) {
+              float v[8];
+#pragma unroll
+              for (int r8 = 0; r8 < 8; ++r8) v[r8] = rowp[(int64_t)r8 * P + cb[j]];
+              gen_u32x4 bh, bm, bl;
+              gen_split8(v, bh, bm, bl);
+              // smallest terms first: m m, h l, l h, h m, m h, h h
+#pragma unroll
+              for (int term = 0; term < 6; ++term) {
+#pragma unroll
+                for (int i = 0; i < SR; ++i) {
+                  const gen_u32x4 &pa = term == 0 ? am[i] : (term == 1 || term == 3 || term == 5) ? ah[i] : (term == 2 ? al[i] : am[i]);
+                  const gen_u32x4 &pb = term == 0 ? bm : term == 1 ? bl : term == 2 ? bh : term == 3 ? bm : bh;
+                  acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(gen_bf16x8, pa), __builtin_bit_cast(gen_bf16x8, pb), acc[i][j], 0, 0, 0);
+                }
+              }
+            }
+          }
+        } else if constexpr (sizeof(T) == 4) {
           // (the operands of step s + 1 are read from LDS before the MFMAs of step s are issued; float64 has no registers for it)
           const T *rowp = B + (int64_t)g * P + c;
           T ya[SR], yb[CW], r;
@@ -286,17 +315,82 @@ __global__ __launch_bounds__(64 * kGenGramMaxWaves, YCNR_GEN_GRAM_WAVES_PER_SIMD
           }
         }
       }
-      if (p + 1 < np) {
-        const unsigned liveN = live_mask(p + 1);
-#pragma unroll
-        for (int i = 0; i < MAXI; ++i) st_val(Bn, vY[i], i, liveN);
-        st_r(rbn, rY, p + 1);
-      }
-      __syncthreads();
     };
-    for (int64_t p = 0; p < np; p += 2) {
-      panel(p, vA, rA, vB, rB);
-      if (p + 1 < np) panel(p + 1, vB, rB, vA, rA);
+    int32_t idn[MAXI];
+    Vec vA[MAXI];
+    T rA = T(0);
+    // panel 0 into buffer 0
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) idn[i] = ld_idx(0, i);
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) vA[i] = ld_val(idn[i], i);
+    rA = ld_r(0);
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) idn[i] = ld_idx(1, i);
+    {
+      const unsigned live0 = live_mask(0);
+#pragma unroll
+      for (int i = 0; i < MAXI; ++i) st_val(buf0, vA[i], i, live0);
+      st_r(rb0, rA, 0);
+    }
+    if constexpr (X6) {
+      // panels of 32 ratings: one panel of values in flight while the one before it is multiplied (twice the MFMA time per panel
+      // of the float32 form, and no registers for a second set)
+      __syncthreads();
+      for (int64_t p = 0; p < np; ++p) {
+        const T *B = (p & 1) ? buf1 : buf0, *rb = (p & 1) ? rb1 : rb0;
+        T *Bn = (p & 1) ? buf0 : buf1, *rbn = (p & 1) ? rb0 : rb1;
+        const bool more = p + 1 < np;  // workgroup-uniform
+        if (more) {
+#pragma unroll
+          for (int i = 0; i < MAXI; ++i) vA[i] = ld_val(idn[i], i);
+          rA = ld_r(p + 1);
+#pragma unroll
+          for (int i = 0; i < MAXI; ++i) idn[i] = ld_idx(p + 2, i);
+        }
+        multiply(B, rb);
+        if (more) {
+          const unsigned liveN = live_mask(p + 1);
+#pragma unroll
+          for (int i = 0; i < MAXI; ++i) st_val(Bn, vA[i], i, liveN);
+          st_r(rbn, rA, p + 1);
+        }
+        __syncthreads();
+      }
+    } else {
+      // panel 1 into registers, the ids of panel 2 in flight
+      Vec vB[MAXI];
+      T rB = T(0);
+#pragma unroll
+      for (int i = 0; i < MAXI; ++i) vB[i] = ld_val(idn[i], i);
+      rB = ld_r(1);
+#pragma unroll
+      for (int i = 0; i < MAXI; ++i) idn[i] = ld_idx(2, i);
+      __syncthreads();
+      // one panel: request panel p + 2 into (vX, rX), multiply panel p, write panel p + 1 from (vY, rY) into the other buffer
+      auto panel = [&](int64_t p, Vec(&vX)[MAXI], T &rX, Vec(&vY)[MAXI], T &rY) {
+        const T *B = (p & 1) ? buf1 : buf0, *rb = (p & 1) ? rb1 : rb0;
+        T *Bn = (p & 1) ? buf0 : buf1, *rbn = (p & 1) ? rb0 : rb1;
+        if (p + 2 < np) {  // workgroup-uniform
+#pragma unroll
+          for (int i = 0; i < MAXI; ++i) vX[i] = ld_val(idn[i], i);
+          rX = ld_r(p + 2);
+#pragma unroll
+          for (int i = 0; i < MAXI; ++i) idn[i] = ld_idx(p + 3, i);
+        }
+        multiply(B, rb);
+        if (p + 1 < np) {
+          const unsigned liveN = live_mask(p + 1);
+#pragma unroll
+          for (int i = 0; i < MAXI; ++i) st_val(Bn, vY[i], i, liveN);
+          st_r(rbn, rY, p + 1);
+        }
+        __syncthreads();
+      };
+      for (int64_t p = 0; p < np; p += 2) {
+        panel(p, vA, rA, vB, rB);
+        if (p + 1 < np) panel(p + 1, vB, rB, vA, rA);
+      }
     }
     if (active) {
 #pragma unroll

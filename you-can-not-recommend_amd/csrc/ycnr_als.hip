@@ -660,21 +660,32 @@ int launch_step_gen(const StepArgs<T> &args, const std::vector<GenBatch> &batche
   const int nSq = gen_items(ga.nb, gen_rect_rows<T>(), gen_sqw<T>() * kGenSq), passes = (nSq + kGenGramMaxWaves - 1) / kGenGramMaxWaves;
   const int waves = std::max(2, (nSq + passes - 1) / passes), nthr = 64 * waves;
   const int P = gen_panel_pitch(ga.nb, sizeof(T));
-  const int slots = vec ? gen_loader_slots<T, V>() : gen_loader_slots<T, 1>();
+  int slots = vec ? gen_loader_slots<T, V>() : gen_loader_slots<T, 1>();
   int R = 32;
-  while (R > 4 && (gen_gram_lds_bytes(R, P, sizeof(T)) > 72 * 1024 || (int64_t)R * (args.k / (vec ? V : 1)) > (int64_t)slots * nthr)) R >>= 1;
+  // float32 with 16-byte rows whose panel of 32 ratings fits one workgroup's LDS (k <= 560): the products on the bf16 pipe (X6)
+  static const bool noGenX6 = getenv("YCNR_NO_GEN_X6") != nullptr;  // (A/B runs)
+  const bool x6 = sizeof(T) == 4 && vec && !noGenX6 && gen_gram_lds_bytes(32, P, sizeof(T)) <= 150 * 1024 &&
+                  (int64_t)32 * (args.k / V) <= (int64_t)8 * nthr;
+  if (x6) slots = 8;
+  else
+    while (R > 4 && (gen_gram_lds_bytes(R, P, sizeof(T)) > 72 * 1024 || (int64_t)R * (args.k / (vec ? V : 1)) > (int64_t)slots * nthr)) R >>= 1;
   const size_t gramLds = gen_gram_lds_bytes(R, P, sizeof(T));
   if (gramLds > 150 * 1024 || (int64_t)R * (args.k / (vec ? V : 1)) > (int64_t)slots * nthr)
     return fail(YCNR_ERR_UNSUPPORTED, "factorsCount %d: a panel of four ratings does not fit a CU's LDS", args.k);
   const void *gramFn = vec ? reinterpret_cast<const void *>(als_gen_gram_kernel<T, V>) : reinterpret_cast<const void *>(als_gen_gram_kernel<T, 1>);
+  if constexpr (sizeof(T) == 4)
+    if (x6) gramFn = reinterpret_cast<const void *>(als_gen_gram_kernel<T, V, true>);
   if (int rc = set_max_lds(gramFn, gramLds)) return rc;
   if (ev) HIP_TRY(hipEventRecord(ev[0], stream));
   for (const GenBatch &b : batches) {
     ga.slabBase = b.slabBase;
     ga.firstUnit = b.slabBase;  // units of split rows are numbered like their slabs
     ga.firstSplit = b.firstSplit;
-    if (vec) hipLaunchKernelGGL((als_gen_gram_kernel<T, V>), dim3((unsigned)b.nSlabs), dim3(nthr), gramLds, stream, ga, R, P);
-    else hipLaunchKernelGGL((als_gen_gram_kernel<T, 1>), dim3((unsigned)b.nSlabs), dim3(nthr), gramLds, stream, ga, R, P);
+    {
+      int Rv = R, Pv = P;
+      void *gargs[] = {(void *)&ga, (void *)&Rv, (void *)&Pv};
+      HIP_TRY(hipLaunchKernel(gramFn, dim3((unsigned)b.nSlabs), dim3(nthr), gargs, gramLds, stream));
+    }
     HIP_TRY(hipGetLastError());
     if (leftFn) {
       void *kargs[] = {(void *)&ga};
