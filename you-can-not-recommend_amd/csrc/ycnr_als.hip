@@ -2046,7 +2046,8 @@ int ycnr_als_step_async(ycnr_als *h, int side) {
   h->graphRun = false;
   {
     ycnr_als::GraphSlot &gs = h->graph[side];
-    const bool graphable = !exchange && parts.size() == 1 && !h->kPad && h->opt.factorsCount <= kMaxFactors &&
+    // (a padded upload -- kPad -- is captured too: the pads above are plain launches in front of the graph, the unpad of the piece's rows is part of it)
+    const bool graphable = !exchange && parts.size() == 1 && h->copt.factorsCount <= kMaxFactors &&
                            parts[0].R.nnz < kGraphMaxRatings && parts[0].R.nnz >= kGraphMinRatings && h->stream == h->ownStream &&
                            !(h->opt.flags & (YCNR_FLAG_NO_OVERLAP | YCNR_FLAG_NO_GRAPH)) && !env_flags().noOverlap && !env_flags().noGraph;
     if (graphable && gs.state == 1) {
