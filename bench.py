@@ -25,6 +25,45 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "you-can-not-recommend_amd", "python"))
 sys.path.insert(0, ROOT)
 
+
+def self_launch():
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N per-GPU processes ourselves, the way
+    the reference's master forks its workers (EmfMaster.createWorkers, lib/emf/EmfMaster.js:44-98; EmfLord.gatherClusterNodes,
+    lib/emf/EmfLord.js:752-828).  The parent never touches the GPU (nothing of torch or libycnr_als is imported before this
+    runs) and never replaces itself: the ranks are a CHILD process -- `python -m torch.distributed.run` with the same
+    arguments --, its stdout (rank 0's JSON line) is this process's stdout, and its exit code is ours."""
+    if os.environ.get("WORLD_SIZE") or os.environ.get("RANK"):
+        return  # already one rank of a launched job
+    gpus = 1
+    argv = sys.argv[1:]
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            gpus = argv[i + 1]
+        elif a.startswith("--gpus="):
+            gpus = a.split("=", 1)[1]
+    try:
+        gpus = int(gpus)
+    except ValueError:
+        return  # argparse reports it
+    if gpus <= 1 or "--emulate-world" in argv or any(a.startswith("--emulate-world=") for a in argv) or "-h" in argv or "--help" in argv:
+        return
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL and the ipc transport need it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    print("bench.py: launching %d ranks: %s" % (gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+if __name__ == "__main__":
+    self_launch()
+
 # (read by the HIP runtime when it starts, i.e. at torch's first device call: see python/ycnr_als/_lib.py)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
@@ -91,6 +130,7 @@ def main():
     ap.add_argument("--rebalance-after", type=int, default=2, help="N > 1: re-cut the shards from measured times after each of the first this-many iterations (0 = never)")
     ap.add_argument("--exchange-chunks", type=int, default=4, help="pieces a large side's shard is solved in (exchange overlaps solve)")
     ap.add_argument("--dump-factors", default="", help="write the final factor matrices of rank 0 to this .npz")
+    ap.add_argument("--dump-step-info", action="store_true", help="add the library's step info of the last half-step of each side to the line (step_info)")
     ap.add_argument("--debug-mod-idx", type=int, default=0,
                     help="timing experiment only: fold all column ids into [0, N) so every gather hits L1/L2")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the baseline sample")
@@ -100,8 +140,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        # (run by hand `python bench.py --gpus N` starts its own ranks: self_launch above; here a launcher's world wins)
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device (no CPU fallback)")
@@ -198,9 +237,10 @@ def main():
         # workgroup-per-row kernels of k > 128 (als_wg_*, any fixed matrix size)
         fixed_rows = items if side == "byUser" else users
         # (float32 of other sizes runs padded to a multiple of 4 columns), and the any-k path's Gramian where a panel of 32 ratings
-        # fits a workgroup's LDS (k % 4 == 0, k <= 576: als_gen_gram_kernel<float, 4, true>)
+        # fits a workgroup's LDS and loader slots (k % 4 == 0, k <= 512: als_gen_gram_kernel<float, 4, true>)
         kp = (k + 3) // 4 * 4
-        return (not args.double) and (128 < k <= 256 or (kp <= 128 and fixed_rows * kp * 4 < 2 ** 31) or (k > 256 and k % 4 == 0 and k <= 576))
+        # (the any-k Gramian: launch_step_gen enables X6 when a 32-rating panel fits the loader's slots, 32 (k / 4) <= 8 * 512 threads: k <= 512)
+        return (not args.double) and (128 < k <= 256 or (kp <= 128 and fixed_rows * kp * 4 < 2 ** 31) or (k > 256 and k % 4 == 0 and k <= 512))
 
     gen_path = k > (128 if args.double else 256)  # als_gen_kernels.hip.h: float32 / float64 MFMA, matrix in global memory
     for st in lord.stepTimes:
@@ -335,6 +375,9 @@ def main():
     # where a multi-GPU iteration goes, per half-step and averaged over the timed steps (this rank;
     # compute_ms of every rank is gathered so that a straggler shows)
     exchange = {"path": getattr(lord, "exchangePath", "none")}
+    if world > 1 and hasattr(lord.backend, "dev"):
+        # what the library's communicator says it is: transport, rank, world, and the ranks RCCL itself counts (ncclCommCount)
+        exchange["comm"] = lord.backend.dev.comm_info()
     for sd in ("byUser", "byItem"):
         c = comm[sd]
         n = max(c["n"], 1)
@@ -361,6 +404,13 @@ def main():
             exchange["ab"] = transport_ab(args, dist, ds, k, max_rating, local_rank, dev, barrier, lord.shards)
 
     rmse = lord.calcRmse("rmseValidate", False)
+    # the RMSE pass BASELINE's metric names beside the solve: device time of its kernel over this rank's users (HIP events inside
+    # libycnr_als.so), max over the ranks
+    rmse_ms = lord.backend.dev.last_rmse_ms() if hasattr(lord.backend, "dev") else None
+    if dist and rmse_ms is not None:
+        t = torch.tensor([rmse_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        rmse_ms = float(t.item())
     if args.dump_factors and rank == 0:
         np.savez(args.dump_factors, U=lord.backend.get_factors(0), V=lord.backend.get_factors(1), rmse=rmse)
 
@@ -369,6 +419,11 @@ def main():
         cpu = cpu_baseline(lord, by_user, by_item, k, args)
         cpu_blas = cpu_baseline_blas(lord, by_user, by_item, k, args)
 
+    step_info = None
+    if args.dump_step_info:
+        step_info = {}
+        for st in lord.stepTimes:
+            step_info[st["stepType"]] = {f: getattr(st["info"], f) for f, _ in type(st["info"])._fields_}
     if rank == 0:
         out = {
             "metric": "ALS ratings/sec per iteration (U+I solve)", "value": value, "unit": "ratings/s",
@@ -378,9 +433,12 @@ def main():
             "config": {"workload": desc, "users": users, "items": items, "nnz": nnz, "factorsCount": k,
                        "lambda": 0.05, "parallelism": f"row-shard x{world} + direct all-gather ({lord.exchangePath})" if world > 1 else "1 GPU"},
             "rmse_in_sample_after_iters": rmse, "iters_run": args.steps + args.warmup,
+            "rmse_ms": rmse_ms, "rmse_ratings": val.nnz, "rmse_ratings_per_s": (val.nnz / (rmse_ms * 1e-3)) if rmse_ms else None,
             "roofline": roofline, "exchange": exchange, "cpu_baseline": cpu, "cpu_baseline_blas": cpu_blas,
             "setup_s": {"generate": round(t_gen, 2), "prepare": round(t_prep, 2)},
         }
+        if step_info is not None:
+            out["step_info"] = step_info
         print(json.dumps(out), flush=True)
     lord.destroy()
     consistent = (not dist) or exchange.get("replicas_consistent", True)

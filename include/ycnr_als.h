@@ -27,14 +27,14 @@
 extern "C" {
 #endif
 
-#define YCNR_ALS_ABI_VERSION 3
+#define YCNR_ALS_ABI_VERSION 4 /* 4: + ycnr_als_comm_info, ycnr_als_last_rmse_ms (nothing changed or removed) */
 
 /* error codes */
 #define YCNR_OK 0
 #define YCNR_ERR_INVALID (-1)     /* bad argument: null pointer, k out of range, index >= rows ... */
 #define YCNR_ERR_HIP (-2)         /* a HIP runtime call failed (message carries hipGetErrorString) */
 #define YCNR_ERR_NOMEM (-3)       /* host or device allocation failed */
-#define YCNR_ERR_UNSUPPORTED (-4) /* valid request this build cannot serve (e.g. factorsCount > 256) */
+#define YCNR_ERR_UNSUPPORTED (-4) /* valid request this build cannot serve (e.g. factorsCount > 4096) */
 #define YCNR_ERR_NUMERIC (-5)     /* a row's normal matrix was not positive definite (NaN/Inf input) */
 #define YCNR_ERR_STATE (-6)       /* call order violated (e.g. step before set_ratings) */
 
@@ -120,8 +120,10 @@ typedef struct ycnr_als_options {
   int32_t struct_size;     /* = sizeof(ycnr_als_options) */
   int32_t device;          /* HIP device ordinal (one process per GPU: LOCAL_RANK) */
   int32_t dtype;           /* YCNR_F32 | YCNR_F64 = options.useDoublePrecision */
-  int32_t factorsCount;    /* options.factorsCount: float32 1..128 and the multiples of 4 up to 256
-                            * (other values in 129..256 through a zero-padded copy), float64 1..128 */
+  int32_t factorsCount;    /* options.factorsCount: 1..4096 in either precision.  Kernel families by size: one wave per
+                            * row up to 128, a workgroup per row up to 256 (float32), the any-k path beyond (float64: beyond
+                            * 128); float32 values that are not multiples of 4 run on copies padded to the next multiple of 4
+                            * (the matrices the host sees keep factorsCount columns) */
   int64_t totalUsersCount; /* stats.totalUsersCount = max user id (EmfLord.js:81) */
   int64_t totalItemsCount; /* stats.totalItemsCount = max item id (EmfLord.js:82) */
   double userFactReg;      /* options.als.userFactReg (EmfBase.js:67) */
@@ -291,6 +293,10 @@ int ycnr_als_step_info_of(ycnr_als *h, int side, ycnr_als_step_info *info);
 int ycnr_comm_unique_id(int transport, void *id128);
 int ycnr_als_comm_init(ycnr_als *h, int transport, const void *id128, int rank, int world);
 int ycnr_als_comm_destroy(ycnr_als *h);
+/* What the handle's communicator is: out = {transport (YCNR_COMM_*), rank, world, ranks RCCL itself counts in its
+ * communicator (ncclCommCount; -1 for the other transports)} -- lets a host or a benchmark line state which path ran and
+ * that RCCL saw every rank (the reference's Lord logs the nodes it gathered, lib/emf/EmfLord.js:752-828). */
+int ycnr_als_comm_info(ycnr_als *h, int32_t out[4]);
 /* Sharded upload of one side for all ranks of the communicator (world = 1 without one):
  *   boundsWorld  the number of ranks `bounds` describes; must equal the communicator's world
  *   bounds   int64[boundsWorld * (nChunks + 1)], ascending; rank r solves rows [bounds[r (nChunks+1)],
@@ -324,6 +330,9 @@ int ycnr_als_comm_selftest(ycnr_als *h, int64_t nFloats);
  * summed in pieces of at most ceil(rows / 4096) rows, one workgroup each, added in row order. */
 int ycnr_als_rmse(ycnr_als *h, int which, double globalAvgShift, int nPortions,
                   const int64_t *portionRowEnd, double *out);
+/* Device time of the last ycnr_als_rmse on this handle (its kernel between two HIP events on the handle's stream): the
+ * counterpart of the per-portion `time` the reference's workers report (lib/emf/EmfWorker.js:266-315). */
+int ycnr_als_last_rmse_ms(ycnr_als *h, double *ms);
 
 /* ---- Preprocessing directly before the path ------------------------------
  *

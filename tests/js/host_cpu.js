@@ -14,7 +14,7 @@ for (const f of ['sAlsCalcPortion', 'dAlsCalcPortion', 'sRmsePortion', 'dRmsePor
   'setRmseRatings', 'setFactors', 'getFactors', 'step', 'rmse', 'deviceCount', 'lastError', 'version',
   'alsUnpinFixedFactors', 'commUniqueId', 'commInit', 'setRatingsSharded', 'allreduceSum', 'broadcastFactors', 'exchange'])
   assert.strictEqual(typeof n[f], 'function', f);
-assert.strictEqual(n.version(), 3);
+assert.strictEqual(n.version(), 4);
 // the communicator id of the shared-memory stand-in needs no GPU: 128 bytes, not all zero, new every time
 const id1 = n.commUniqueId(als.COMM_SHM), id2 = n.commUniqueId(als.COMM_SHM);
 assert.strictEqual(id1.length, 128);
@@ -55,6 +55,18 @@ lord.getStats().then(() => lord.splitToPortions()).then(() => {
     const b = out.shards[w + '_' + k], ms = b.slice(1).map((_, r) => 1.0 + 0.5 * r);
     out.recut[w + '_' + k] = EmfMaster.rebalancedRanges(ds.trainByUser.rowPtr, b, ms, k, false);
   }
+  // the reference packer's end-of-data quirk, opt-in (checked against the Python mirror and the oracle's PackPortion)
+  out.quirk = { byUser: [], byItemRowPtr: null };
+  let begin = 0;
+  for (const end of lord.stats.portionsRowIdTo.byUser) {
+    out.quirk.byUser.push(Array.from(ds.trainByUser.toPortion(begin, end, true).alsRows));
+    begin = end;
+  }
+  const dq = ds.withoutLastRatingPerPortion(lord.stats.portionsRowIdTo);
+  out.quirk.byUserRowPtr = Array.from(dq.trainByUser.rowPtr);
+  out.quirk.byItemRowPtr = Array.from(dq.trainByItem.rowPtr);
+  out.quirk.byItemIndx = Array.from(dq.trainByItem.indx);
+  out.quirk.validateRowPtr = dq.validate ? Array.from(dq.validate.rowPtr) : null;
   let gpu = true;
   try { n.deviceCount(); } catch (e) { gpu = false; out.deviceCountError = e.message; }
   if (gpu) return;

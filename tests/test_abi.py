@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     L = _lib.load()
     for name in declared_functions():
         assert hasattr(L, name), f"{name} is declared in include/ycnr_als.h but not exported"
-    assert L.ycnr_version() == _lib.ABI_VERSION == 3
+    assert L.ycnr_version() == _lib.ABI_VERSION == 4
 
 
 def test_struct_layouts_match_header():

@@ -191,17 +191,19 @@ def test_ranks_of_one_node_on_one_gpu(als, transport, world, pieces, shape):
         assert parts == pieces and xu > 0 and xi > 0
 
 
-@pytest.mark.parametrize("transport,world", [("ipc", 2), ("ipc", 3), ("shm", 2)])
-def test_back_to_back_async_half_steps(als, transport, world):
+@pytest.mark.parametrize("transport,world,shape", [("ipc", 2, "k100"), ("ipc", 3, "k100"), ("shm", 2, "k100"), ("ipc", 3, "k50")])
+def test_back_to_back_async_half_steps(als, transport, world, shape):
     """step_async(byUser); step_async(byItem); sync between real processes sharing cuda:0: on the push transport the
     second half-step would read user rows that its peers are still writing unless the first is completed before it
-    starts (round-3 review; ycnr_als.h documents the rule).  Bit for bit against the single-process result."""
-    k, users, items, bu, bi, U, V = problem(*SHAPES["k100"])
+    starts (round-3 review; ycnr_als.h documents the rule).  Bit for bit against the single-process result.
+    k50: a padded upload (float32, factorsCount % 4 != 0) -- the pad of the fixed matrix is a READ of the matrix the peers push
+    into and must sit behind that completion too (round-4 review: it was enqueued in front of it)."""
+    k, users, items, bu, bi, U, V = problem(*SHAPES[shape])
     U1, V1 = reference_iteration(als, k, users, items, bu, bi, U, V)
     uid = als.AlsDevice.comm_unique_id(transport)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_rank_main, args=(r, world, uid, 3, q, transport, 0, "k100", True)) for r in range(world)]
+    procs = [ctx.Process(target=_rank_main, args=(r, world, uid, 3, q, transport, 0, shape, True)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in procs]

@@ -144,6 +144,33 @@ def test_half_steps_all_k(als, oracle, k, dt):
     dev.destroy()
 
 
+@pytest.mark.parametrize("k", [97, 99, 50, 37, 130])
+def test_padded_sizes_without_regularisation(als, k):
+    """float32 factorsCount % 4 != 0 runs on matrices padded to the next multiple of 4 (kPad): the padded columns take a UNIT
+    diagonal, not lambda n -- with userFactReg = itemFactReg = 0, which ycnr_als_create accepts (the reference's defaults are
+    options, lib/emf/EmfBase.js:65-70), lambda n there left a zero pivot and every primal row failed with YCNR_ERR_NUMERIC
+    (round-4 review).  Rows have more ratings than factors, so the normal matrices are positive definite without lambda.
+    k = 97: three padded columns inside the four edge columns that solve_edge4 eliminates first; k = 130: the workgroup path."""
+    users, items = 340, 420
+    bu, bi, U, V = make_problem(users, items, k, density=0.62, seed=300 + k, min_per_row=k + 30)
+    dev = als.AlsDevice(k, users, items, userFactReg=0.0, itemFactReg=0.0)
+    dev.set_ratings("byUser", bu.rowPtr, bu.indx, bu.vals)
+    dev.set_ratings("byItem", bi.rowPtr, bi.indx, bi.vals)
+    dev.set_factors("byUser", U)
+    dev.set_factors("byItem", V)
+    info = dev.step("byUser")
+    assert info.numericErrors == 0 and info.rows == users
+    U1 = dev.get_factors("byUser")
+    want, conds = numpy_step(0.0, k, bu, V, U)
+    check_rows(U1, want, conds, np.float32)
+    info = dev.step("byItem")
+    assert info.numericErrors == 0
+    V1 = dev.get_factors("byItem")
+    want, conds = numpy_step(0.0, k, bi, U1, V)
+    check_rows(V1, want, conds, np.float32)
+    dev.destroy()
+
+
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
 def test_split_rows_and_chunk_edges(als, dt):
     """Rows longer than a work unit are split over several waves and reduced in slab order;
@@ -734,6 +761,115 @@ def test_full_iterations_ml100k_shape(als, oracle, double):
     assert h1[-1]["rmseValidate"] < h1[0]["rmseValidate"]  # it learns
 
 
+@pytest.mark.parametrize("double", [True, False])
+def test_warm_start_and_extend_on_the_hip_path_against_the_oracle(als, oracle, tmp_path, double):
+    """N4 on the product backend: train one iteration, save, warm-start from the result files with 7 more
+    users and 4 more items (prepareSharedFactors over _loadSharedFactorsForTrain, lib/emf/EmfMaster.js:347-358,
+    EmfManager.js:405-457; new rows drawn by initSharedFactorsRandom(oldUsersCnt, oldItemsCnt), EmfBase.js:457-513), train
+    again -- the same sequence on HipBackend and on the CPU oracle.  Old rows must come back from the files bit for bit, the
+    new rows must be the seeded draw, factors and calc_info.json must agree between the two backends (float64 1e-9;
+    float32 within the conditioning bound of every row's solve, as in test_half_steps_all_k)."""
+    import copy
+    import json
+    from ycnr_als.data import Csr, init_factors
+    from ycnr_als.emf import Dataset, EmfLord
+    from helpers import OracleBackend, make_problem
+    dt = np.float64 if double else np.float32
+    users, items, k = 300, 180, 36
+    bu, bi, U, V = make_problem(users, items, k, density=0.12, seed=21, dtype=dt, min_per_row=2)
+    sel = np.arange(bu.nnz)
+
+    def pick(c, mask):
+        rows_of = np.repeat(np.arange(c.rows), c.counts())
+        rp = np.zeros(c.rows + 1, np.int64)
+        rp[1:] = np.cumsum(np.bincount(rows_of[mask], minlength=c.rows))
+        return Csr(c.rows, c.cols, rp, c.indx[mask].copy(), c.vals[mask].copy())
+    ds = Dataset(bu, bi, pick(bu, sel % 4 == 0), pick(bu, sel % 9 == 1), float(bu.vals.mean()))
+    # the grown data set: 7 more users and 4 more items, the new users with ratings (also of the new items)
+    rng = np.random.default_rng(5)
+    U2n, I2n = users + 7, items + 4
+    extra_cols = [np.sort(rng.choice(I2n, 9, replace=False)).astype(np.int32) for _ in range(7)]
+    rp2 = np.concatenate([bu.rowPtr, bu.rowPtr[-1] + 9 * np.arange(1, 8)]).astype(np.int64)
+    big_u = Csr(U2n, I2n, rp2, np.concatenate([bu.indx] + extra_cols), np.concatenate([bu.vals, rng.integers(1, 6, 63).astype(dt)]))
+    import torch
+    from ycnr_als.data import transpose_csr
+    big_i = transpose_csr(big_u.to("cpu")).numpy()
+    sel2 = np.arange(big_u.nnz)
+    big = Dataset(big_u, big_i, pick(big_u, sel2 % 4 == 0), pick(big_u, sel2 % 9 == 1), float(big_u.vals.mean()))
+    res = {}
+    for name, factory in (("hip", None), ("oracle", lambda o, u, i, d: OracleBackend(o, u, i, d))):
+        d = tmp_path / name
+        opts = {"factorsCount": k, "trainIters": 1, "useDoublePrecision": double, "dataDir": str(d), "dbType": "ml",
+                "ratingsInPortionForRmse": 400}
+        first = EmfLord(options=opts, backend_factory=factory)
+        first.prepareToTrain(ds, U.copy(), V.copy())
+        first.train()
+        U1, V1 = first.backend.get_factors(0), first.backend.get_factors(1)
+        first.destroy()
+        ready = d / "ml_factors_ready"
+        assert np.array_equal(np.fromfile(ready / "user_factors", dt).reshape(-1, k), U1)   # the files ARE the matrices
+        ext = EmfLord(options=dict(opts, warmStart=True), backend_factory=factory)
+        ext.prepareToTrain(big, seed=5)
+        assert (ext.recreated, ext.extended) == (False, True) and ext.calcCnt == 1
+        Ue, Ve = ext.backend.get_factors(0), ext.backend.get_factors(1)
+        assert np.array_equal(Ue[:users], U1) and np.array_equal(Ve[:items], V1)                         # old rows bit-kept
+        assert np.array_equal(Ue[users:], init_factors(U2n, k, 10, dt)[users:]) and np.abs(Ue[users:]).max() > 0  # seeded N(0, 1/k)
+        assert np.array_equal(Ve[items:], init_factors(I2n, k, 11, dt)[items:])
+        hist = ext.train()
+        info = json.loads((ready / "calc_info.json").read_text())
+        res[name] = (U1, V1, ext.backend.get_factors(0), ext.backend.get_factors(1), info, hist)
+        ext.destroy()
+    h, o = res["hip"], res["oracle"]
+    # float64: 1e-9 everywhere.  float32: the first half-step (same fixed matrix on both backends) within the conditioning bound
+    # of every row's solve -- two float32 implementations, each within 8 cond(A) kappa_b eps32 of float64 --, what follows within a
+    # flat 1e-4 (every later half-step starts from matrices that already differ by those bounds)
+    _, conds = numpy_step(0.05, k, bu, V.astype(np.float64), np.zeros((users, k)))
+    for idx, what in enumerate(("U after the first train", "V after the first train", "U after the warm-started train",
+                                "V after the warm-started train")):
+        e = row_rel_err(h[idx], o[idx])
+        if double:
+            assert e.max() <= 1e-9, (what, float(e.max()))
+        elif idx == 0:
+            assert (e <= np.maximum(16 * conds * EPS32, 2e-6)).all(), (what, float(e.max()))
+        else:
+            assert e.max() <= 1e-4, (what, float(e.max()))
+    for key in ("alg", "algOptions", "useDoublePrecision", "factorsCount", "dataSetDistr", "totalUsersCount", "totalItemsCount", "dbType",
+                "calcCnt", "globalBias"):
+        assert h[4][key] == o[4][key], key
+    assert h[4]["calcCnt"] == 2 and h[4]["totalUsersCount"] == U2n and h[4]["totalItemsCount"] == I2n
+    assert list(h[4].keys()) == list(o[4].keys())
+    assert abs(h[4]["globalAvgShift"] - o[4]["globalAvgShift"]) <= (1e-9 if double else 1e-5)
+    for a, b in zip(h[5], o[5]):
+        for key in ("rmseValidate", "rmseTest", "rmseTestShifted"):
+            # (float32, shifted: the shift is totalRatingsAvg - predAvg of the LAST portion, a float32 mean over a few hundred
+            # predictions of matrices that differ by the bounds above after two trains)
+            tol = 1e-9 if double else (5e-6 if key == "rmseTestShifted" else 1e-6)
+            assert abs(a[key] - b[key]) <= tol, (key, a[key], b[key])
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python3 bench.py --gpus 2 ...` exactly as the driver's scaling job calls it -- plain python, no launcher: bench.py must
+    start its ranks itself, as the reference's master forks its workers (lib/emf/EmfMaster.js:44-98), relay rank 0's line
+    and exit 0.  Two ranks share cuda:0 over the device-to-device `ipc` transport (RCCL refuses duplicate devices)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--same-device", "--backend", "gloo",
+                        "--transport", "ipc", "--workload", "ml1m", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2
+    ex = out["exchange"]
+    assert ex["path"] == "libycnr_als:ipc" and ex["replicas_consistent"] is True
+    assert ex["comm"]["world"] == 2 and ex["comm"]["transport"] == "ipc" and ex["comm"]["rccl_ranks"] is None
+    assert out["rmse_ms"] > 0
+
+
 @pytest.mark.parametrize("world,transport", [(2, "shm"), (4, "shm"), (3, "ipc")])
 def test_ranks_on_one_gpu_equal_one_rank(tmp_path, world, transport):
     """The sharded HIP path end to end: 2 / 4 gloo ranks sharing cuda:0 (functional stand-in for
@@ -777,6 +913,27 @@ def test_four_rows_per_wave_kernel_against_the_one_row_kernel(tmp_path):
         d = np.abs(a[name].astype(np.float64) - b[name]).max(axis=1) / np.maximum(np.abs(b[name]).max(axis=1), 1e-30)
         assert d.max() <= 2e-5, (name, float(d.max()))
     assert not np.array_equal(a["U"], b["U"])
+
+
+@pytest.mark.gpu
+def test_launch_order_of_the_rows_does_not_change_a_bit(tmp_path):
+    """Large launches take their primal rows in a fixed pseudo-random order instead of longest-first (build_part: waves that share
+    a SIMD then differ in length and phase); YCNR_ROW_ORDER=0 keeps the sorted order.  Every row is solved by its own wave, so
+    both orders must give every factor bit for bit (200 K x 20 K shape at k = 100: ~100 K primal rows on the user side).
+    The toggle is read once per process: each result is a child process of bench.py."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = [sys.executable, os.path.join(root, "bench.py"), "--workload", "c3", "--factors", "100", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    rnd, srt = str(tmp_path / "rnd.npz"), str(tmp_path / "srt.npz")
+    env = dict(os.environ)
+    env.pop("YCNR_ROW_ORDER", None)
+    subprocess.check_call(common + ["--dump-factors", rnd], timeout=600, env=env, stdout=subprocess.DEVNULL)
+    env["YCNR_ROW_ORDER"] = "0"
+    subprocess.check_call(common + ["--dump-factors", srt], timeout=600, env=env, stdout=subprocess.DEVNULL)
+    a, b = np.load(rnd), np.load(srt)
+    assert np.array_equal(a["U"], b["U"]) and np.array_equal(a["V"], b["V"])
+    assert float(a["rmse"]) == float(b["rmse"])
 
 
 @pytest.mark.gpu

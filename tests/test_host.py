@@ -8,7 +8,7 @@ import pytest
 
 from helpers import OracleBackend, make_problem
 from ycnr_als.data import Csr, csr_to_portion, init_factors
-from ycnr_als.emf import Dataset, EmfLord, deepmerge, default_options, shard_ranges
+from ycnr_als.emf import Dataset, EmfLord, deepmerge, default_options, shard_ranges, split_to_portions
 
 
 def oracle_factory(o, u, i, d):
@@ -140,6 +140,69 @@ def test_warm_start_extends_factors_for_new_users_and_items(tmp_path):
     shrunk.prepareToTrain(ds, seed=5)
     assert (shrunk.recreated, shrunk.extended) == (True, False)
     assert np.array_equal(shrunk.backend.get_factors(0), init_factors(50, 8, 10))
+
+
+def test_reference_packer_quirk_is_an_opt_in_flag(oracle, tmp_path):
+    """N2: csr_to_portion / Dataset reproduce the end-of-data branch of the reference's packer
+    (lib/emf/EmfMaster.js:594-603) when asked to: the row tables equal the oracle's literal restatement (PackPortion, compat),
+    and a train with options.dropLastRatingPerPortion consumes exactly the ratings those tables name."""
+    from ycnr_als.data import Csr, drop_last_rating_per_portion
+    rng = np.random.default_rng(12)
+    for trial in range(60):
+        rows_n, cols_n = int(rng.integers(1, 12)), 9
+        cnt = rng.integers(0, 5, rows_n)
+        if trial % 5 == 0:
+            cnt[-1] = 1                       # a trailing row of one rating: never recorded
+        if trial % 7 == 0:
+            cnt[:] = 0
+            cnt[rng.integers(0, rows_n)] = 1  # a portion of ONE rating: recorded with cols = 0
+        rp = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+        indx = np.concatenate([np.sort(rng.choice(cols_n, c, replace=False)) for c in cnt] + [np.zeros(0, np.int64)]).astype(np.int32)
+        vals = rng.integers(1, 6, len(indx)).astype(np.float32)
+        c = Csr(rows_n, cols_n, rp, indx, vals)
+        r1 = np.repeat(np.arange(rows_n), cnt).astype(np.int32) + 1
+        for compat in (True, False):
+            want_rows, want_indx, want_vals = oracle.pack_portion(r1, indx + 1, vals, compat=compat)
+            rows, gi, gv = csr_to_portion(c, 0, rows_n, dropLastRatingPerPortion=compat)
+            n = int(want_rows[0])
+            assert rows[0] == n and np.array_equal(rows[1:], want_rows[1:1 + 2 * n]), (trial, compat)
+            assert np.array_equal(gi, want_indx[:len(gi)]) and np.array_equal(gv, want_vals[:len(gv)])
+    # whole data set: every portion of a pass without its last rating
+    ds, U, V = small_dataset()
+    tu = ds.train_by_user
+    cu = np.diff(tu.rowPtr)
+    ends, _, _ = split_to_portions(cu, int((cu > 0).sum()), 40, 2)
+    dropped = drop_last_rating_per_portion(tu, ends)
+    b = 0
+    for e in ends:
+        rows, _, _ = csr_to_portion(tu, b, int(e), dropLastRatingPerPortion=True)
+        got = np.diff(dropped.rowPtr)[b:int(e)]
+        want = np.zeros(int(e) - b, np.int64)
+        want[rows[1::2] - b] = rows[2::2]
+        assert np.array_equal(got, want)
+        b = int(e)
+    assert tu.nnz - dropped.nnz == len(ends)
+    # the option: a train on the full data with the flag == a train without it on the data the flag leaves
+    opts = {"factorsCount": 8, "trainIters": 1, "dataDir": str(tmp_path), "dbType": "ml", "ratingsInPortionForRmse": 40,
+            "ratingsInPortionForAls": {"byUser": 40, "byItem": 40}, "numThreadsForTrain": {"als": 2}}
+    a = EmfLord(options=dict(opts, dropLastRatingPerPortion=True), backend_factory=oracle_factory)
+    a.prepareToTrain(ds, U, V)
+    ha = a.train()
+    cut = a.dataset
+    assert cut.train_by_user.nnz < ds.train_by_user.nnz and cut.train_by_item.nnz == ds.train_by_item.nnz - len(
+        split_to_portions(np.diff(ds.train_by_item.rowPtr), int((np.diff(ds.train_by_item.rowPtr) > 0).sum()), 40, 2)[0])
+    b2 = EmfLord(options=opts, backend_factory=oracle_factory)
+    b2.prepareToTrain(cut, U, V)
+    # (portions of the RMSE passes are cut from the stats of the data a Lord is given; keep those of the full data)
+    b2.portionsRowIdTo = a.portionsRowIdTo
+    hb = b2.train()
+    assert np.array_equal(a.backend.get_factors(0), b2.backend.get_factors(0))
+    assert np.array_equal(a.backend.get_factors(1), b2.backend.get_factors(1))
+    assert ha[-1]["rmseValidate"] == hb[-1]["rmseValidate"]
+    plain = EmfLord(options=opts, backend_factory=oracle_factory)
+    plain.prepareToTrain(ds, U, V)
+    plain.train()
+    assert not np.array_equal(plain.backend.get_factors(0), a.backend.get_factors(0))  # the flag is not a no-op
 
 
 def test_first_factor_as_average_rating():

@@ -57,6 +57,21 @@ def test_js_host_on_cpu(tmp_path):
         want = rebalanced_ranges(cnt_u, shard_ranges(cnt_u, w, k), ms, k)
         assert got == want.tolist(), key
         assert got[1] > shard_ranges(cnt_u, w, k)[1]  # the rank that ran shortest takes rows from the others
+    # N2's opt-in flag: the reference packer's row tables and the data set its passes really consume, against the Python mirror
+    from ycnr_als.data import Csr, csr_to_portion, drop_last_rating_per_portion, transpose_csr
+    import torch
+    tu = Csr(bu.rows, bu.cols, np.concatenate([[0], np.cumsum(cnt_u)]).astype(np.int64), bu.indx[train], bu.vals[train])
+    ends_u, _, _ = split_to_portions(cnt_u, int((cnt_u > 0).sum()), 30, 2)
+    b = 0
+    for p, e in enumerate(ends_u):
+        assert out["quirk"]["byUser"][p] == csr_to_portion(tu, b, int(e), dropLastRatingPerPortion=True)[0].tolist(), p
+        b = int(e)
+    assert out["quirk"]["byUserRowPtr"] == drop_last_rating_per_portion(tu, ends_u).rowPtr.tolist()
+    ti = transpose_csr(tu.to("cpu")).numpy()
+    ends_i, _, _ = split_to_portions(cnt_i, int((cnt_i > 0).sum()), 30, 2)
+    di = drop_last_rating_per_portion(ti, ends_i)
+    assert out["quirk"]["byItemRowPtr"] == di.rowPtr.tolist() and out["quirk"]["byItemIndx"] == di.indx.tolist()
+    assert ti.nnz - di.nnz == len(ends_i)
     if "prepareError" in out:  # no GPU here: loud failure, carrying the library's message
         assert "hip" in out["prepareError"].lower()
 

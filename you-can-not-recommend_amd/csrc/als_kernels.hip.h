@@ -318,6 +318,75 @@ struct GramPlain {
 #pragma unroll
     for (int cb = 0; cb < NB; ++cb) bfull[cb] = st.bacc[cb];
   }
+  // The slabs of a row with MANY chunks are added in double and rounded to T once (als_reduce_solve_kernel): a float32 chain over
+  // n slabs in slab order carries an error of eps sqrt(n / 3) of the total -- 37 eps for the 4096 slabs of a 10 M-rating item --,
+  // far above what the chunks' own chains contribute (each 1 / n of the total); in double the sum over the slabs is exact to
+  // float32 precision.  Order still fixed: independent of how the rows are dealt to GPUs.
+  // Registers: 119 double accumulators (k = 100) and the loads of a slab do not fit the 256 vector registers the vector ALU can
+  // address -- the first build (all tiles at once) waited for every 16-byte load before it issued the next: 0.44 -> 1.0 ms for the
+  // MAL item side's reduce.  Hence TP tiles per pass over the row's slabs, four slabs' loads of those tiles in flight.
+  template <int T0, int TP>
+  static __device__ __forceinline__ void sum_tiles_wide(State &st, const T *s0, int nslabs) {
+    double d[TP][4];
+#pragma unroll
+    for (int t = 0; t < TP; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) d[t][r] = 0.0;
+    }
+    const Quad *q = reinterpret_cast<const Quad *>(s0 + 3 * (int)threadIdx.x) + T0 * 64;
+    constexpr int64_t STRIDE = (int64_t)slab_regs() * 16;  // slab stride in quads: slab_regs() * 64 elements
+    // GS slabs' loads of these tiles are issued together, then added in slab order (left to itself hipcc waited for every
+    // 16-byte load before it issued the next one: a row of 64 slabs was a chain of 1800 round trips)
+    constexpr int GS = 4;
+    for (int sl = 0; sl < nslabs; sl += GS) {
+      Quad v[GS][TP];
+#pragma unroll
+      for (int u = 0; u < GS; ++u) {
+        const Quad *qs = q + (int64_t)(sl + u < nslabs ? sl + u : nslabs - 1) * STRIDE;
+#pragma unroll
+        for (int t = 0; t < TP; ++t) v[u][t] = qs[t * 64];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < GS; ++u) {
+        if (sl + u < nslabs) {  // wave-uniform
+#pragma unroll
+          for (int t = 0; t < TP; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d[t][r] += (double)v[u][t].v[r];
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int t = 0; t < TP; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) st.acc[T0 + t][r] = (T)d[t][r];
+    }
+  }
+  template <int T0>
+  static __device__ __forceinline__ void sum_passes_wide(State &st, const T *s0, int nslabs) {
+    constexpr int TP = NT - T0 < 7 ? NT - T0 : 7;
+    if constexpr (TP > 0) {
+      sum_tiles_wide<T0, TP>(st, s0, nslabs);
+      sum_passes_wide<T0 + TP>(st, s0, nslabs);
+    }
+  }
+  // st <- sum over the nslabs slabs at s0 (this lane's element of the first slab: base + lane), every element summed in double
+  static __device__ __forceinline__ void sum_slabs_wide(State &st, const T *s0, int nslabs) {
+    sum_passes_wide<0>(st, s0, nslabs);
+    double b[NB];
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) b[cb] = 0.0;
+#pragma unroll 4
+    for (int sl = 0; sl < nslabs; ++sl) {
+#pragma unroll
+      for (int cb = 0; cb < NB; ++cb) b[cb] += (double)s0[(int64_t)sl * (slab_regs() * 64) + (NT * 4 + cb) * 64];
+    }
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) st.bacc[cb] = (T)b[cb];
+  }
 };
 
 // Gramian for k = 16 (NB-1) + 4 (k = 20, 36, ..., 100, 116), float32: the last 4 columns would
@@ -562,6 +631,76 @@ struct GramEdge {
       st.be[j] += p[(4 + j) * 64];
     }
   }
+  // (see GramPlain::Wide)
+  struct Wide {
+    double acc[NTM][4];
+    double bacc[NBM];
+    double edge[NBM][4];
+    double corner[4];
+    double be[4];
+  };
+  static __device__ __forceinline__ void init_wide(Wide &w) {
+#pragma unroll
+    for (int t = 0; t < NTM; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) w.acc[t][r] = 0.0;
+    }
+#pragma unroll
+    for (int cb = 0; cb < NBM; ++cb) {
+      w.bacc[cb] = 0.0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w.edge[cb][j] = 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w.corner[j] = w.be[j] = 0.0;
+  }
+  static __device__ __forceinline__ void add_slab_wide(Wide &w, const float *s) {
+#pragma unroll
+    for (int t = 0; t < NTM; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) w.acc[t][r] += (double)s[(t * 4 + r) * 64];
+    }
+    const float *p = s + NTM * 4 * 64;
+#pragma unroll
+    for (int cb = 0; cb < NBM; ++cb) w.bacc[cb] += (double)p[cb * 64];
+    p += NBM * 64;
+#pragma unroll
+    for (int cb = 0; cb < NBM; ++cb) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w.edge[cb][j] += (double)p[(cb * 4 + j) * 64];
+    }
+    p += NBM * 4 * 64;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      w.corner[j] += (double)p[j * 64];
+      w.be[j] += (double)p[(4 + j) * 64];
+    }
+  }
+  static __device__ __forceinline__ void narrow(State &st, const Wide &w) {
+#pragma unroll
+    for (int t = 0; t < NTM; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) st.acc[t][r] = (float)w.acc[t][r];
+    }
+#pragma unroll
+    for (int cb = 0; cb < NBM; ++cb) {
+      st.bacc[cb] = (float)w.bacc[cb];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) st.edge[cb][j] = (float)w.edge[cb][j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      st.corner[j] = (float)w.corner[j];
+      st.be[j] = (float)w.be[j];
+    }
+  }
+  // (the entry point of GramPlain; this form -- fixed matrices of 2 GB and more at k = 16 m + 4 -- keeps the one-pass sum)
+  static __device__ __forceinline__ void sum_slabs_wide(State &st, const float *s0, int nslabs) {
+    Wide w;
+    init_wide(w);
+    for (int sl = 0; sl < nslabs; ++sl) add_slab_wide(w, s0 + (int64_t)sl * (slab_regs() * 64));
+    narrow(st, w);
+  }
   // Rebuild the NB-block upper tile set (C/D layout) and the rhs partials from the state.
   // S: at least (16 NBM + 4) * 16 bytes of LDS, free for reuse after the call.
   static __device__ __forceinline__ void to_tiles(State &st, acc_t (&full)[NT], float (&bfull)[NB], float *S, int lane) {
@@ -635,10 +774,13 @@ struct SolveLds {
   static constexpr int LD = KP + 1;
   static constexpr size_t lds_bytes() { return sizeof(T) * (size_t)KP * LD; }
 
+  // kd: the first kd of the k columns are factors, the rest zero padding of a padded upload (StepArgs::kReal): their diagonal
+  // entry is 1, not lambda n (a zero lambda must not leave a zero pivot there); < 0: all k
   static __device__ __forceinline__ void run(const acc_t (&acc)[NT], const T (&bacc)[NB], T *S, int k,
                                              T lam, T *__restrict__ out_row, int row, ErrInfo *err,
-                                             int lane) {
+                                             int lane, int kd = -1) {
     const int g = lane >> 4, c = lane & 15;
+    if (kd < 0) kd = k;
 #pragma unroll
     for (int bi = 0; bi < NB; ++bi) {
 #pragma unroll
@@ -658,7 +800,7 @@ struct SolveLds {
       const int i = cb * 16 + c;
       if (g == 0 && i < k) S[i * LD + k] = v;
     }
-    for (int i = lane; i < k; i += 64) S[i * LD + i] += lam;
+    for (int i = lane; i < k; i += 64) S[i * LD + i] += i < kd ? lam : T(1);
     __syncthreads();
 
     bool bad = false;
@@ -724,13 +866,24 @@ struct SolveLds {
 //      b_bj -= U[J][bj]^T z_J (sums over lane groups); back substitution mirrors it.
 // Only MFMA, VALU, DPP and ~20 LDS instructions per block step; no barrier other than the
 // wave's own LDS ordering.  k need not be a multiple of 16: the padded diagonal is 1.
-template <int NB>
+// WSYNC: the struct runs inside a workgroup of SEVERAL waves that each solve a row of their own (als_row_pair_kernel): its LDS
+// images are wave-private, so its synchronisation points order the wave's own LDS traffic (program order + a compiler barrier)
+// instead of being workgroup barriers, which the other waves would never reach.  With one wave per workgroup the two mean the same.
+template <int NB, bool WSYNC = false>
 struct SolveMfmaF32 {
   using Tr = MfmaTraits<float>;
   using acc_t = typename Tr::acc_t;
   static constexpr int NT = tile_count(NB);
   static constexpr int LDW = 20;  // floats per LDS image row: 80 B keeps b128 accesses aligned
   static constexpr size_t lds_bytes() { return 2 * 16 * LDW * sizeof(float); }
+  static __device__ __forceinline__ void lds_sync() {
+    if constexpr (WSYNC) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      __syncthreads();
+    }
+  }
 
   template <int N>
   static __device__ __forceinline__ float row_ror(float v) {
@@ -859,10 +1012,13 @@ struct SolveMfmaF32 {
   // the v_fma that uses its SGPR).  Faster in the row kernels (8.3 -> 8.1 ms); in the dual-form
   // kernels it was slower while their Gramian ran on the float32 pipe (7.2 -> 7.4 ms) and is
   // faster since it runs on the bf16 pipe (6.78 -> 6.54 ms), so the caller chooses.
+  // kd (< 0: k): columns kd .. k - 1 are the zero padding of a padded upload (StepArgs::kReal) and take a unit diagonal like
+  // the columns past k (with lambda n there, userFactReg = 0 -- which ycnr_als_create accepts -- left a zero pivot: NaN rows)
   template <bool BATCH = false>
   static __device__ __forceinline__ bool solve(acc_t (&acc)[NT], const float (&bacc)[NB], float *S, int k, float lam,
-                                               float (&xcol)[NB], int lane) {
+                                               float (&xcol)[NB], int lane, int kd = -1) {
     const int g = lane >> 4, c = lane & 15;
+    if (kd < 0) kd = k;
     float *Dt = S;             // D image, [row][col], row stride LDW
     float *Wt = S + 16 * LDW;  // W image stored transposed: Wt[col][row] = W[row][col]
     // right-hand side as per-lane-group partials: b[16 cb + c] = sum over the four groups of bpart[cb].
@@ -878,7 +1034,7 @@ struct SolveMfmaF32 {
       const int t0 = c & 3;
 #pragma unroll
       for (int bi = 0; bi < NB; ++bi) {
-        const float add = (bi * 16 + c < k) ? lam : 1.0f;
+        const float add = (bi * 16 + c < kd) ? lam : 1.0f;
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[tile_index(bi, bi, NB)][t] += (mine && t == t0) ? add : 0.0f;
       }
@@ -893,7 +1049,7 @@ struct SolveMfmaF32 {
 #pragma unroll
         for (int t = 0; t < 4; ++t) Dt[(4 * g + t) * LDW + c] = d[t];
       }
-      __syncthreads();
+      lds_sync();
       float R[16];
       {
         const bool xlane = (g & 1) != 0;  // groups 1 and 3 carry the identity, 0 and 2 carry D
@@ -966,7 +1122,7 @@ struct SolveMfmaF32 {
 #pragma unroll
         for (int m4 = 0; m4 < 4; ++m4) dst[m4] = float4{R[4 * m4], R[4 * m4 + 1], R[4 * m4 + 2], R[4 * m4 + 3]};
       }
-      __syncthreads();
+      lds_sync();
       acc_t W;  // W[4g+t][c]
       {
         const float4 v = *reinterpret_cast<const float4 *>(Wt + c * LDW + 4 * g);
@@ -1056,18 +1212,21 @@ struct SolveMfmaF32 {
   // reaches the MFMA operand layout (lane (g, c): V[g][16 bi + c]) through a 256-byte LDS image per block.
   // The (NB - 1)-block system then goes through the ordinary solve.  Cholesky with another elimination
   // order: the same arithmetic class and error bound as the plain form.
+  // kd (< 0: all four real): edge columns 16 (NB - 1) + j >= kd are zero padding (a padded upload, k = 97 .. 99 -> 100): unit diagonal
   static __device__ __forceinline__ bool solve_edge4(acc_t (&acc)[NT], const float (&bacc)[NB], float *S, float lam,
-                                                     float (&xcol)[NB], int lane) {
+                                                     float (&xcol)[NB], int lane, int kd = -1) {
     static_assert(NB >= 2 && (NB - 1) * 64 * sizeof(float) <= lds_bytes(), "edge image must fit the solver's LDS");
-    using Inner = SolveMfmaF32<NB - 1>;
+    using Inner = SolveMfmaF32<NB - 1, WSYNC>;
     constexpr int L = NB - 1;  // the edge block
     const int g = lane >> 4, c = lane & 15;
     // ---- A22 + lam I and b2, wave-uniform
     const acc_t e = acc[tile_index(L, L, NB)];  // element (row 4g + t, col c) in reg t: rows 0..3 <-> lanes 0..15
+    const float lam1 = (kd < 0 || 16 * L + 1 < kd) ? lam : 1.0f, lam2 = (kd < 0 || 16 * L + 2 < kd) ? lam : 1.0f,
+                lam3 = (kd < 0 || 16 * L + 3 < kd) ? lam : 1.0f;  // (column 16 L is always a factor: at most three columns of padding)
     const float a00 = readlane(e[0], 0) + lam;
-    const float a10 = readlane(e[1], 0), a11 = readlane(e[1], 1) + lam;
-    const float a20 = readlane(e[2], 0), a21 = readlane(e[2], 1), a22 = readlane(e[2], 2) + lam;
-    const float a30 = readlane(e[3], 0), a31 = readlane(e[3], 1), a32 = readlane(e[3], 2), a33 = readlane(e[3], 3) + lam;
+    const float a10 = readlane(e[1], 0), a11 = readlane(e[1], 1) + lam1;
+    const float a20 = readlane(e[2], 0), a21 = readlane(e[2], 1), a22 = readlane(e[2], 2) + lam2;
+    const float a30 = readlane(e[3], 0), a31 = readlane(e[3], 1), a32 = readlane(e[3], 2), a33 = readlane(e[3], 3) + lam3;
     const float bs = group_sum(bacc[L]);
     const float b0 = readlane(bs, 0), b1 = readlane(bs, 1), b2 = readlane(bs, 2), b3 = readlane(bs, 3);
     // ---- C = chol(A22) (lower), M = C^-1
@@ -1108,7 +1267,7 @@ struct SolveMfmaF32 {
         for (int q = 0; q < 4; ++q) S[bi * 64 + (4 * g + q) * 4 + c] = t[q];
       }
     }
-    __syncthreads();
+    lds_sync();
     float V[L];
     acc_t in[Inner::NT];
     float bin[L];
@@ -1118,7 +1277,7 @@ struct SolveMfmaF32 {
       V[bi] = fmaf(Mg3, a.w, fmaf(Mg2, a.z, fmaf(Mg1, a.y, Mg0 * a.x)));
       bin[bi] = fmaf(-V[bi], zg, bacc[bi]);  // this group's share of b1 - V^T z2
     }
-    __syncthreads();  // the image is read before the inner solve reuses S
+    lds_sync();  // the image is read before the inner solve reuses S
     // ---- A11 - V^T V: one MFMA (K = 4: the four rows of V) per tile
 #pragma unroll
     for (int bi = 0; bi < L; ++bi) {
@@ -1150,14 +1309,14 @@ struct SolveMfmaF32 {
   // spilled 168 bytes per lane to scratch.
   template <bool E4 = false>
   static __device__ __forceinline__ void run(acc_t (&acc)[NT], const float (&bacc)[NB], float *S, int k, float lam,
-                                             float *__restrict__ out_row, int row, ErrInfo *err, int lane) {
+                                             float *__restrict__ out_row, int row, ErrInfo *err, int lane, int kd = -1) {
     const int g = lane >> 4, c = lane & 15;
     float xcol[NB];
     bool bad;
     if constexpr (E4 && NB >= 2 && YCNR_EDGE4_SOLVE) {
-      bad = solve_edge4(acc, bacc, S, lam, xcol, lane);
+      bad = solve_edge4(acc, bacc, S, lam, xcol, lane, kd);
     } else {
-      bad = solve<true>(acc, bacc, S, k, lam, xcol, lane);
+      bad = solve<true>(acc, bacc, S, k, lam, xcol, lane, kd);
     }
     // lane group g stores blocks g and g + 4: two full 256-byte stores per row for k >= 64
 #pragma unroll
@@ -1204,8 +1363,9 @@ struct SolveMfmaF64 {
   }
 
   static __device__ __forceinline__ bool solve(acc_t (&acc)[NT], const double (&bacc)[NB], double *S, int k, double lam,
-                                               double (&xcol)[NB], int lane) {
+                                               double (&xcol)[NB], int lane, int kd = -1) {
     const int g = lane >> 4, c = lane & 15;
+    if (kd < 0) kd = k;
     double *Dt = S, *Wt = S + 16 * LDW;
     double bcol[NB];
 #pragma unroll
@@ -1216,7 +1376,7 @@ struct SolveMfmaF64 {
       const int t0 = c >> 2;
 #pragma unroll
       for (int bi = 0; bi < NB; ++bi) {
-        const double add = (bi * 16 + c < k) ? lam : 1.0;
+        const double add = (bi * 16 + c < kd) ? lam : 1.0;
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[tile_index(bi, bi, NB)][t] += (mine && t == t0) ? add : 0.0;
       }
@@ -1320,10 +1480,10 @@ struct SolveMfmaF64 {
   }
 
   static __device__ __forceinline__ void run(acc_t (&acc)[NT], const double (&bacc)[NB], double *S, int k, double lam,
-                                             double *__restrict__ out_row, int row, ErrInfo *err, int lane) {
+                                             double *__restrict__ out_row, int row, ErrInfo *err, int lane, int kd = -1) {
     const int g = lane >> 4, c = lane & 15;
     double xcol[NB];
-    const bool bad = solve(acc, bacc, S, k, lam, xcol, lane);
+    const bool bad = solve(acc, bacc, S, k, lam, xcol, lane, kd);
 #pragma unroll
     for (int cb = 0; cb < NB; ++cb) {
       if ((cb & 3) == g && cb * 16 + c < k) out_row[cb * 16 + c] = xcol[cb];
@@ -2121,18 +2281,20 @@ struct GramX6P {
   // PACK: the corner tile (packed operand x packed operand) holds the plane products of live row i in rows i, i + 5, i + 10:
   // fold them (through a 1 KB LDS image: once per row) and clear rows 5..15.  The columns are folded by
   // GramX6D<NB, true, true>::extract_rhs like every tile of the last block column.
+  // (WSYNC: see SolveMfmaF32)
+  template <bool WSYNC = false>
   static __device__ __forceinline__ void fold_corner_rows(acc_t &tl, float *S, int lane) {
     const int g = lane >> 4, c = lane & 15;
 #pragma unroll
     for (int t = 0; t < 4; ++t) S[(4 * g + t) * 16 + c] = tl[t];
-    __syncthreads();
+    SolveMfmaF32<1, WSYNC>::lds_sync();
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int i = 4 * g + t;
       const float v = i <= 4 ? (S[i * 16 + c] + S[(i + 5) * 16 + c]) + S[(i + 10) * 16 + c] : 0.0f;
       tl[t] = i <= 4 ? v : 0.0f;
     }
-    __syncthreads();
+    SolveMfmaF32<1, WSYNC>::lds_sync();
   }
 };
 
@@ -2193,10 +2355,11 @@ __global__ __launch_bounds__(64, sizeof(T) == 8 ? 1 : YCNR_FUSED_WAVES_PER_SIMD)
   }
 #else
   if constexpr (E4 && std::is_same<T, float>::value && !LDS_SOLVER) {
-    SolveMfmaF32<NB>::template run<true>(acc, bacc, reinterpret_cast<float *>(smem), a.k, lam, a.solved + (int64_t)u.row * a.k, u.row, a.err, lane);
+    SolveMfmaF32<NB>::template run<true>(acc, bacc, reinterpret_cast<float *>(smem), a.k, lam, a.solved + (int64_t)u.row * a.k, u.row, a.err, lane,
+                                         a.kReal > 0 ? a.kReal : -1);
   } else {
     SolverFor<T, NB, LDS_SOLVER>::type::run(acc, bacc, reinterpret_cast<T *>(smem), a.k, lam,
-                                          a.solved + (int64_t)u.row * a.k, u.row, a.err, lane);
+                                          a.solved + (int64_t)u.row * a.k, u.row, a.err, lane, a.kReal > 0 ? a.kReal : -1);
   }
 #endif
 }
@@ -2234,10 +2397,11 @@ __global__ __launch_bounds__(64, NB <= 7 ? 2 : 1) void als_gram_solve_x6d_kernel
   }
 #else
   if constexpr (E4 && !LDS_SOLVER) {
-    SolveMfmaF32<NB>::template run<true>(acc, bacc, reinterpret_cast<float *>(smem), a.k, lam, a.solved + (int64_t)u.row * a.k, u.row, a.err, lane);
+    SolveMfmaF32<NB>::template run<true>(acc, bacc, reinterpret_cast<float *>(smem), a.k, lam, a.solved + (int64_t)u.row * a.k, u.row, a.err, lane,
+                                         a.kReal > 0 ? a.kReal : -1);
   } else {
     SolverFor<float, NB, LDS_SOLVER>::type::run(acc, bacc, reinterpret_cast<float *>(smem), a.k, lam,
-                                                a.solved + (int64_t)u.row * a.k, u.row, a.err, lane);
+                                                a.solved + (int64_t)u.row * a.k, u.row, a.err, lane, a.kReal > 0 ? a.kReal : -1);
   }
 #endif
 }
@@ -2260,14 +2424,28 @@ __global__ __launch_bounds__(64, NB <= 7 ? 2 : 1) void als_gram_solve_x6p_kernel
   float bacc[NB];
 #pragma unroll
   for (int cb = 0; cb < NB; ++cb) bacc[cb] = 0.0f;
+#ifdef YCNR_ABLATE_GRAM  // timing experiments only: skip the Gramian (results are wrong)
+  acc[0][0] = (float)u.beg;
+#else
   G::accumulate(acc, ring, a.indx, a.vals, a.planes, a.planesBytes, a.k, u.beg, u.end - u.beg, lane);
   if constexpr (PACK) G::fold_corner_rows(acc[tile_index(NB - 1, NB - 1, NB)], reinterpret_cast<float *>(ring), lane);
   GD::extract_rhs(acc, bacc, a.k, lane);
+#endif
   const float lam = (float)(a.lambda * (double)(u.end - u.beg));
+#ifdef YCNR_ABLATE_SOLVE  // timing experiments only: skip the solve, keep the Gramian live
+  {
+    float sum = lam;
+    for (int t = 0; t < G::NT; ++t) sum += acc[t][0] + acc[t][1] + acc[t][2] + acc[t][3];
+    for (int cb = 0; cb < NB; ++cb) sum += bacc[cb];
+    if (lane < a.k) a.solved[(int64_t)u.row * a.k + lane] = sum;
+    return;
+  }
+#endif
   if constexpr (E4) {
-    SolveMfmaF32<NB>::template run<true>(acc, bacc, reinterpret_cast<float *>(ring), a.k, lam, a.solved + (int64_t)u.row * a.k, u.row, a.err, lane);
+    SolveMfmaF32<NB>::template run<true>(acc, bacc, reinterpret_cast<float *>(ring), a.k, lam, a.solved + (int64_t)u.row * a.k, u.row, a.err, lane,
+                                         a.kReal > 0 ? a.kReal : -1);
   } else {
-    SolveMfmaF32<NB>::run(acc, bacc, reinterpret_cast<float *>(ring), a.k, lam, a.solved + (int64_t)u.row * a.k, u.row, a.err, lane);
+    SolveMfmaF32<NB>::run(acc, bacc, reinterpret_cast<float *>(ring), a.k, lam, a.solved + (int64_t)u.row * a.k, u.row, a.err, lane, a.kReal > 0 ? a.kReal : -1);
   }
 }
 
@@ -2765,16 +2943,27 @@ __global__ __launch_bounds__(64, (reduce_waves<T, NB, LDS_SOLVER, E4, FEW>())) v
   const SplitRow sr = a.split[blockIdx.x];
   typename G::State st;
   G::init(st);
-  for (int sl = 0; sl < sr.nslabs; ++sl) G::add_slab(st, a.slabs + (int64_t)(sr.slab0 + sl) * (G::slab_regs() * 64) + lane);
+  // Rows of more than kFewSlabs slabs (float32): the sum over the slabs in double, rounded once (G::Wide).  Which form a row
+  // takes depends on its own slab count alone -- not on the piece it was uploaded in (FEW) --, so shards and pieces still
+  // cannot change a row's bits.
+  bool wide = false;
+  if constexpr (std::is_same<T, float>::value && !FEW) wide = sr.nslabs > kFewSlabs;  // wave-uniform
+  if (wide) {
+    if constexpr (std::is_same<T, float>::value && !FEW)
+      G::sum_slabs_wide(st, a.slabs + (int64_t)sr.slab0 * (G::slab_regs() * 64) + lane, sr.nslabs);
+  } else {
+    for (int sl = 0; sl < sr.nslabs; ++sl) G::add_slab(st, a.slabs + (int64_t)(sr.slab0 + sl) * (G::slab_regs() * 64) + lane);
+  }
   acc_t acc[G::NT];
   T bacc[NB];
   G::to_tiles(st, acc, bacc, reinterpret_cast<T *>(smem), lane);
   const T lam = (T)(a.lambda * (double)sr.n);
   if constexpr (E4 && std::is_same<T, float>::value && !LDS_SOLVER) {
-    SolveMfmaF32<NB>::template run<true>(acc, bacc, reinterpret_cast<float *>(smem), a.k, lam, a.solved + (int64_t)sr.row * a.k, sr.row, a.err, lane);
+    SolveMfmaF32<NB>::template run<true>(acc, bacc, reinterpret_cast<float *>(smem), a.k, lam, a.solved + (int64_t)sr.row * a.k, sr.row, a.err, lane,
+                                         a.kReal > 0 ? a.kReal : -1);
   } else {
     SolverFor<T, NB, LDS_SOLVER>::type::run(acc, bacc, reinterpret_cast<T *>(smem), a.k, lam,
-                                          a.solved + (int64_t)sr.row * a.k, sr.row, a.err, lane);
+                                          a.solved + (int64_t)sr.row * a.k, sr.row, a.err, lane, a.kReal > 0 ? a.kReal : -1);
   }
 }
 

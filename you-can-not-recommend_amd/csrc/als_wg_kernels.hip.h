@@ -724,16 +724,43 @@ __global__ __launch_bounds__(kWgThreads, 2) void als_wg_reduce_solve_kernel(Step
   for (int32_t si = blockIdx.x; si < count; si += gridDim.x) {
     const SplitRow sr = a.split[si];
     constexpr int NQ = C::NT * 64;  // float4s of the image
+    // rows of more than kFewSlabs slabs: the sum over the slabs in double, rounded once (GramPlain::Wide in als_kernels.hip.h: a
+    // float32 chain over the 4096 slabs of a 10 M-rating item carries 37 eps of the total); the form follows the row's own
+    // slab count, so it is the same however the rows are dealt to GPUs and pieces
+    const bool wide = sr.nslabs > kFewSlabs;  // uniform over the workgroup
     for (int q0 = tid; q0 < NQ; q0 += 4 * kWgThreads) {
       wg_f32x4 v[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = wg_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-      for (int sl = 0; sl < sr.nslabs; ++sl) {
-        const wg_f32x4 *src = reinterpret_cast<const wg_f32x4 *>(a.slabs + (int64_t)(sr.slab0 + sl) * C::SLAB_FLOATS);
+      if (wide) {
+        double d[4][4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const int q = q0 + u * kWgThreads;
-          if (q < NQ) v[u] += src[q];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) d[u][e] = 0.0;
+        }
+        for (int sl = 0; sl < sr.nslabs; ++sl) {
+          const wg_f32x4 *src = reinterpret_cast<const wg_f32x4 *>(a.slabs + (int64_t)(sr.slab0 + sl) * C::SLAB_FLOATS);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int q = q0 + u * kWgThreads;
+            if (q < NQ) {
+              const wg_f32x4 x = src[q];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) d[u][e] += (double)x[e];
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = wg_f32x4{(float)d[u][0], (float)d[u][1], (float)d[u][2], (float)d[u][3]};
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = wg_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int sl = 0; sl < sr.nslabs; ++sl) {
+          const wg_f32x4 *src = reinterpret_cast<const wg_f32x4 *>(a.slabs + (int64_t)(sr.slab0 + sl) * C::SLAB_FLOATS);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int q = q0 + u * kWgThreads;
+            if (q < NQ) v[u] += src[q];
+          }
         }
       }
 #pragma unroll
@@ -743,9 +770,15 @@ __global__ __launch_bounds__(kWgThreads, 2) void als_wg_reduce_solve_kernel(Step
       }
     }
     if (tid < NB * 16) {
-      float t = 0.0f;
-      for (int sl = 0; sl < sr.nslabs; ++sl) t += a.slabs[(int64_t)(sr.slab0 + sl) * C::SLAB_FLOATS + (int64_t)C::NT * 256 + tid];
-      bvec[tid] = t;
+      if (wide) {
+        double t = 0.0;
+        for (int sl = 0; sl < sr.nslabs; ++sl) t += (double)a.slabs[(int64_t)(sr.slab0 + sl) * C::SLAB_FLOATS + (int64_t)C::NT * 256 + tid];
+        bvec[tid] = (float)t;
+      } else {
+        float t = 0.0f;
+        for (int sl = 0; sl < sr.nslabs; ++sl) t += a.slabs[(int64_t)(sr.slab0 + sl) * C::SLAB_FLOATS + (int64_t)C::NT * 256 + tid];
+        bvec[tid] = t;
+      }
     }
     __syncthreads();
     WgSolve<NB>::run(a, sr.row, sr.n, smem);

@@ -55,6 +55,7 @@ struct RcclApi {
   ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;  // optional: ycnr_als_comm_info reports what RCCL itself counts
 };
 
 // process-wide, loaded once
@@ -88,6 +89,7 @@ int rccl_api(const RcclApi **out) {
     YCNR_SYM(Broadcast, "ncclBroadcast")
     YCNR_SYM(GetErrorString, "ncclGetErrorString")
 #undef YCNR_SYM
+    a.CommCount = reinterpret_cast<decltype(a.CommCount)>(dlsym(dl, "ncclCommCount"));
     api = a;
   }
   *out = &api;

@@ -294,6 +294,8 @@ def lint_dpp(path, wanted):
                 reads |= regs_of(ops[0])
             for w in writers(i, 1):
                 wop = w.split()[0]
+                if wop == "v_writelane_b32":  # the compiler's own SGPR spill / reload pairs (no inline asm writes lanes): its hazard recogniser's business
+                    continue
                 hit = _dest_regs(w) & reads
                 if hit and (lane_read or wop.startswith(TRANS)) and not parts[0].startswith(TRANS):
                     issues += 1

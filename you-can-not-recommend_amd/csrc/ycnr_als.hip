@@ -247,21 +247,27 @@ constexpr int kSideStreams = 6;  // most side streams a handle can have; side_st
 // Side streams in use (YCNR_SIDE_STREAMS, read once; experiments).  The runtime maps a process's streams onto
 // GPU_MAX_HW_QUEUES hardware queues (4 unless that variable says otherwise, read when the runtime starts): kernels on two
 // streams that share a hardware queue run one after the other.
+// The runtime reads GPU_MAX_HW_QUEUES once, when it starts.  The library does not touch the environment (a setenv from a dlopen
+// constructor races with getenv in the host's other threads, and it cannot know whether the runtime has started already): the
+// HOSTS set GPU_MAX_HW_QUEUES=8 before their first HIP call (bench.py, python/ycnr_als/_lib.py -- only while torch has not
+// initialised HIP --, lib/ycnr_als.js).  What the variable said when this library was LOADED is what counts
+// here: a value that appears later cannot have reached the runtime through one of those hosts.
+int g_hw_queues_at_load = 0;
+__attribute__((constructor)) void ycnr_note_hw_queues() {
+  const char *q = getenv("GPU_MAX_HW_QUEUES");
+  g_hw_queues_at_load = q ? atoi(q) : 0;
+}
 int side_streams() {
   static const int n = [] {
     const char *e = getenv("YCNR_SIDE_STREAMS");
     if (e) return std::max(1, std::min(kSideStreams, atoi(e)));
     // one stream per dual class when every stream gets a hardware queue of its own (the row kernel's stream + five), else two:
     // MAL scale, user half-step, same box: 13.20 ms with 4 queues / 2 side streams, 13.14 with 8 / 2, 12.84 with 8 / 5
-    const char *q = getenv("GPU_MAX_HW_QUEUES");
-    return q && atoi(q) >= 8 ? 5 : 2;
+    // (five streams on four queues -- streams sharing a queue wait behind each other's event waits -- is the one to avoid)
+    return g_hw_queues_at_load >= 8 ? 5 : 2;
   }();
   return n;
 }
-// The runtime reads GPU_MAX_HW_QUEUES when it starts: a process that loads this library before its first HIP call gets 8
-// hardware queues unless its environment says otherwise (hosts that initialise HIP first set it themselves: bench.py,
-// python/ycnr_als/_lib.py, lib/ycnr_als.js).
-__attribute__((constructor)) void ycnr_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 constexpr int64_t kGraphMaxRatings = 2 * 1024 * 1024;  // uploads below this replay their half-step as a captured hipGraph ...
 constexpr int64_t kGraphMinRatings = 256 * 1024;       // ... unless they are so small that the graph launch itself costs more than four
                                                         // kernel launches (ML-100k shape: 0.124 ms per iteration launch by launch, 0.174 as graphs)
@@ -662,7 +668,8 @@ int launch_step_gen(const StepArgs<T> &args, const std::vector<GenBatch> &batche
   const int P = gen_panel_pitch(ga.nb, sizeof(T));
   int slots = vec ? gen_loader_slots<T, V>() : gen_loader_slots<T, 1>();
   int R = 32;
-  // float32 with 16-byte rows whose panel of 32 ratings fits one workgroup's LDS (k <= 560): the products on the bf16 pipe (X6)
+  // float32 with 16-byte rows whose panel of 32 ratings fits one workgroup's LDS AND its loader slots (8 per thread of at most
+  // eight waves: 32 (k / 4) <= 8 * 512, i.e. k <= 512): the products on the bf16 pipe (X6); 516 <= k keeps float32 MFMAs
   static const bool noGenX6 = getenv("YCNR_NO_GEN_X6") != nullptr;  // (A/B runs)
   const bool x6 = sizeof(T) == 4 && vec && !noGenX6 && gen_gram_lds_bytes(32, P, sizeof(T)) <= 150 * 1024 &&
                   (int64_t)32 * (args.k / V) <= (int64_t)8 * nthr;
@@ -957,6 +964,7 @@ struct ycnr_als {
   hipEvent_t evComputeEnd = nullptr;
   bool exchangedInStep = false;
   Ratings rmse[2];
+  double lastRmseMs = -1.0;  // device time of the last ycnr_als_rmse (its kernel, HIP events on the handle's stream)
   ErrInfo *dErr = nullptr;
   // The error record is never reset on the device: its count only grows, the host remembers what it has seen
   // (errSeen) and gets the record through an 8-byte copy into page-locked memory at the end of every half-step
@@ -1685,6 +1693,26 @@ static int build_part(ycnr_als *h, int side, const int64_t *rowPtr, const int32_
     const double nd = (double)n, kd = (double)h->opt.factorsCount;
     S.dualFlops += nd * (nd + 1) * kd + nd * nd * nd / 3.0 + 2.0 * nd * nd + 2.0 * nd * kd;
   }
+  // Launch order of the whole rows in primal form (k <= 128: one wave per row).  Sorted by descending length, the waves that
+  // share a SIMD at any moment work on rows of the same length that started together and go through their Gramian phase (matrix
+  // pipe) and their solve phase (vector ALU) side by side.  A large launch therefore takes its rows in a fixed pseudo-random
+  // order -- neighbours in launch order differ in length and drift apart -- with the shortest rows kept, sorted, for the tail:
+  // MAL-scale user half-step 12.18 -> 11.95 ms (interleaved A/B, two runs each; profiles/r05_ab.sh).  Every row is solved by
+  // its own wave: the order cannot change a result.  YCNR_ROW_ORDER=0: sorted (A/B).  Riffles of the sorted list (position q i + j
+  // takes row i + j N / q) were measured much SLOWER for q = 2 ... 32 (12.5 ... 19.4 ms): the dispatcher deals workgroups to
+  // the XCDs round-robin, so part j of the list -- and all the long rows -- landed on XCD j mod 8.
+  constexpr int64_t kShuffleMinRows = 16384;
+  if (!big && !gen && S.nPrimal >= kShuffleMinRows) {
+    static const int order = getenv("YCNR_ROW_ORDER") ? atoi(getenv("YCNR_ROW_ORDER")) : -1;
+    if (order < 0) {
+      const int64_t tail = std::min<int64_t>(S.nPrimal / 8, 8192);  // the shortest rows stay where they are
+      uint64_t x = 0x9E3779B97F4A7C15ull;
+      for (int64_t i = S.nPrimal - tail - 1; i > 0; --i) {
+        x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+        std::swap(units[(size_t)(nSlabs + i)], units[(size_t)(nSlabs + (int64_t)(x % (uint64_t)(i + 1)))]);
+      }
+    }
+  }
   if (big && slab_nb(h->copt.factorsCount) == kPairNB && S.nPrimal > 0 && !env_flags().noPair) {
     int64_t batchRows = kPairBatchRows;
     if (const char *e = getenv("YCNR_PAIR_BATCH_ROWS")) batchRows = std::max(256, atoi(e));  // read per upload
@@ -1986,22 +2014,6 @@ int ycnr_als_step_async(ycnr_als *h, int side) {
   // With a communicator and a sharded upload the half-step includes its exchange: the rows of piece
   // c travel (on the communicator's stream) while piece c + 1 is being solved, and the step's
   // stream waits for the last piece to land -- the next half-step reads the whole matrix.
-  if (h->kPad) {
-    // the FIXED side in full; of the solved side only this rank's rows (launch_part copies them back piece by
-    // piece, the rows without ratings among them unchanged)
-    const int s = 1 - side;
-    const int64_t n = h->rows(s) * h->kPad;
-    hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, (const float *)h->factors[s],
-                       h->padded[s], (int64_t)0, h->rows(s), h->opt.factorsCount, h->kPad);
-    HIP_TRY(hipGetLastError());
-    for (const Part &p : parts) {
-      const int64_t nr = p.R.rowEnd - p.R.rowBegin, m = nr * h->kPad;
-      if (m <= 0) continue;
-      hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, h->stream, (const float *)h->factors[side],
-                         h->padded[side], p.R.rowBegin, nr, h->opt.factorsCount, h->kPad);
-      HIP_TRY(hipGetLastError());
-    }
-  }
   const bool exchange = h->comm.active() && !h->bounds[side].empty();
   if (exchange && h->bounds[side].size() != (size_t)h->comm.world * (parts.size() + 1))
     return fail(YCNR_ERR_STATE, "step: the sharded upload of this side was made for another communicator (bounds of %zu values, world %d x %zu pieces)",
@@ -2018,6 +2030,24 @@ int ycnr_als_step_async(ycnr_als *h, int side) {
       if (int rcf = ipc_finish(h->comm)) return rcf;
     }
     if (int rcb = ipc_enter(h->comm)) return rcb;  // push transport: no peer is still preparing its replica
+  }
+  // (behind the completion of a pending IPC half-step, like the planes below: the pad reads the matrix the peers were pushing
+  // into -- in front of that guard, back-to-back half-steps of a padded upload could pad rows that were still on their way)
+  if (h->kPad) {
+    // the FIXED side in full; of the solved side only this rank's rows (launch_part copies them back piece by
+    // piece, the rows without ratings among them unchanged)
+    const int s = 1 - side;
+    const int64_t n = h->rows(s) * h->kPad;
+    hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, (const float *)h->factors[s],
+                       h->padded[s], (int64_t)0, h->rows(s), h->opt.factorsCount, h->kPad);
+    HIP_TRY(hipGetLastError());
+    for (const Part &p : parts) {
+      const int64_t nr = p.R.rowEnd - p.R.rowBegin, m = nr * h->kPad;
+      if (m <= 0) continue;
+      hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, h->stream, (const float *)h->factors[side],
+                         h->padded[side], p.R.rowBegin, nr, h->opt.factorsCount, h->kPad);
+      HIP_TRY(hipGetLastError());
+    }
   }
   // (behind the completion of a pending IPC half-step above: the planes are read from the matrix the peers were pushing into)
   // the fixed matrix of this half-step as bf16 planes, once for all its waves (12.7 K x 100 floats at MAL scale: microseconds);
@@ -2296,6 +2326,9 @@ int ycnr_als_rmse(ycnr_als *h, int which, double shift, int nPortions, const int
   HIP_TRY(hipMalloc(&dEnds, sizeof(int64_t) * np));
   hipError_t e = hipMalloc(&dOut, sizeof(double) * 3 * np);
   if (e == hipSuccess) e = hipMemcpyAsync(dEnds, pieceEnds.data(), sizeof(int64_t) * np, hipMemcpyHostToDevice, h->stream);
+  EvPair evp;  // the kernel alone (ycnr_als_last_rmse_ms)
+  if (e == hipSuccess) e = evp.create();
+  if (e == hipSuccess) e = hipEventRecord(evp.a, h->stream);
   if (e == hipSuccess) {
     if (h->opt.dtype == YCNR_F32) {
       RmseArgs<float> a{R.dRowPtr, R.dIndx, (const float *)R.dVals, (const float *)h->factors[0],
@@ -2308,8 +2341,13 @@ int ycnr_als_rmse(ycnr_als *h, int which, double shift, int nPortions, const int
     }
     e = hipGetLastError();
   }
+  if (e == hipSuccess) e = hipEventRecord(evp.b, h->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(part.data(), dOut, sizeof(double) * 3 * np, hipMemcpyDeviceToHost, h->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (e == hipSuccess) {
+    float ms = 0;
+    h->lastRmseMs = hipEventElapsedTime(&ms, evp.a, evp.b) == hipSuccess ? (double)ms : -1.0;
+  }
   if (e == hipSuccess) {
     for (int i = 0; i < 3 * nPort; ++i) out[i] = 0.0;
     for (int j = 0; j < np; ++j)
@@ -2318,6 +2356,13 @@ int ycnr_als_rmse(ycnr_als *h, int which, double shift, int nPortions, const int
   if (dEnds) (void)hipFree(dEnds);
   if (dOut) (void)hipFree(dOut);
   if (e != hipSuccess) return fail(YCNR_ERR_HIP, "rmse: %s", hipGetErrorString(e));
+  return YCNR_OK;
+}
+
+int ycnr_als_last_rmse_ms(ycnr_als *h, double *ms) {
+  if (!h || !ms) return fail(YCNR_ERR_INVALID, "null argument");
+  if (h->lastRmseMs < 0) return fail(YCNR_ERR_STATE, "last_rmse_ms: no RMSE pass has run on this handle");
+  *ms = h->lastRmseMs;
   return YCNR_OK;
 }
 
@@ -2358,6 +2403,20 @@ int ycnr_als_comm_init(ycnr_als *h, int transport, const void *id, int rank, int
   if (!rc && transport == YCNR_COMM_IPC) rc = ipc_publish(h->comm, h->factors);
   if (rc) comm_release(h->comm);
   return rc;
+}
+
+int ycnr_als_comm_info(ycnr_als *h, int32_t out[4]) {
+  if (!h || !out) return fail(YCNR_ERR_INVALID, "null argument");
+  out[0] = h->comm.transport;
+  out[1] = h->comm.rank;
+  out[2] = h->comm.world;
+  out[3] = -1;
+  if (h->comm.transport == YCNR_COMM_RCCL && h->comm.nccl && h->comm.api && h->comm.api->CommCount) {
+    int n = -1;
+    NCCL_TRY(h->comm.api, h->comm.api->CommCount(h->comm.nccl, &n));
+    out[3] = n;
+  }
+  return YCNR_OK;
 }
 
 int ycnr_als_comm_destroy(ycnr_als *h) {

@@ -15,6 +15,53 @@ class Csr {
   }
   get nnz() { return this.rowPtr[this.rows]; }
   count(r) { return this.rowPtr[r + 1] - this.rowPtr[r]; }
+
+  /**
+   * The ratings a pass of the REFERENCE really consumes when this matrix is fed to it in the portions that end at the
+   * 1-based inclusive row ids `portionsRowIdTo` (lib/emf/EmfLord.js:571-592): its packer records the row that is open when a
+   * portion's last rating arrives BEFORE counting that rating (lib/emf/EmfMaster.js:594-603), so every portion loses its last
+   * rating.  Returns a new Csr; a row left without ratings is not solved.  Opt-in (options.dropLastRatingPerPortion).
+   */
+  withoutLastRatingPerPortion(portionsRowIdTo) {
+    const drop = new Set();
+    let begin = 0;
+    for (const end of portionsRowIdTo) {
+      if (!(end > 0) || end > this.rows) continue;
+      if (this.rowPtr[end] > this.rowPtr[begin]) drop.add(this.rowPtr[end] - 1);
+      begin = end;
+    }
+    const n = this.nnz - drop.size;
+    const rowPtr = new Float64Array(this.rows + 1), indx = new Int32Array(n), vals = new this.vals.constructor(n);
+    let m = 0;
+    for (let r = 0; r < this.rows; r++) {
+      for (let p = this.rowPtr[r]; p < this.rowPtr[r + 1]; p++) {
+        if (drop.has(p)) continue;
+        indx[m] = this.indx[p]; vals[m] = this.vals[p]; m++;
+      }
+      rowPtr[r + 1] = m;
+    }
+    return new Csr(this.rows, this.cols, rowPtr, indx, vals);
+  }
+
+  /**
+   * Rows [rowBegin, rowEnd) in the reference's portion-buffer format (alsRows / alsIndx / alsVals, lib/emf/EmfMaster.js:589-609),
+   * rows without ratings omitted.  dropLast: the row table the reference's packer writes for these ratings, bug for bug (the
+   * last row one rating short; a last row of one rating not recorded, or recorded with cols = 0 when it is the portion's only
+   * rating); alsIndx / alsVals hold every rating either way.
+   */
+  toPortion(rowBegin, rowEnd, dropLast) {
+    const b = this.rowPtr[rowBegin], e = this.rowPtr[rowEnd];
+    const ids = [], cols = [];
+    for (let r = rowBegin; r < rowEnd; r++) if (this.count(r) > 0) { ids.push(r); cols.push(this.count(r)); }
+    if (dropLast && ids.length) {
+      if (cols[cols.length - 1] > 1 || e - b == 1) cols[cols.length - 1]--;
+      else { ids.pop(); cols.pop(); }
+    }
+    const alsRows = new Int32Array(1 + 2 * ids.length);
+    alsRows[0] = ids.length;
+    ids.forEach((id, i) => { alsRows[1 + 2 * i] = id; alsRows[2 + 2 * i] = cols[i]; });
+    return { alsRows, alsIndx: this.indx.slice(b, e), alsVals: this.vals.slice(b, e) };
+  }
 }
 
 /** Counting sort of (r, c, v) triplets into CSR; triplets must be unique per (r, c). */
@@ -83,6 +130,18 @@ class Dataset {
     let s = 0;
     for (let i = 0; i < n; i++) s += triplets.rating[i];
     this.totalRatingsAvg = n ? s / n : 0;
+  }
+
+  /** options.dropLastRatingPerPortion: every pass cut into its portions (EmfLord.splitToPortions), each without its last rating */
+  withoutLastRatingPerPortion(portionsRowIdTo) {
+    const out = Object.create(Dataset.prototype);
+    Object.assign(out, this);
+    out.trainByUser = this.trainByUser.withoutLastRatingPerPortion(portionsRowIdTo.byUser || []);
+    out.trainByItem = this.trainByItem.withoutLastRatingPerPortion(portionsRowIdTo.byItem || []);
+    if (this.validate) out.validate = this.validate.withoutLastRatingPerPortion((portionsRowIdTo.rmseValidate || []).map((e, i, a) => (i == a.length - 1 ? this.totalUsersCount : e)));
+    if (this.test) out.test = this.test.withoutLastRatingPerPortion((portionsRowIdTo.rmseTest || []).map((e, i, a) => (i == a.length - 1 ? this.totalUsersCount : e)));
+    out.portionQuirkApplied = true;
+    return out;
   }
 
   /**

@@ -56,6 +56,9 @@ class EmfBase extends EventEmitter {
       numThreadsForTrain: { als: numCPUs, sgd: 1 },
       numThreadsForRmse: numCPUs,
       useDoublePrecision: false,
+      // not in the reference (opt-in): consume the ratings as the reference's portion packer hands them to its workers -- the
+      // last rating of every portion dropped (lib/emf/EmfMaster.js:594-603) -- for bug-for-bug replays of a reference run
+      dropLastRatingPerPortion: false,
       // not in the reference: HIP device ordinal, where the factor directories live
       // (reference: <repo>/data), GPU work-unit size (0 = library default), seed of the
       // initial factors (reference: unseeded)

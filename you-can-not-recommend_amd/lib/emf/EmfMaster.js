@@ -37,9 +37,10 @@ class EmfMaster extends EmfManager {
    */
   static rowCost(n, k, double) {
     if (n <= 0) return 0;
+    if (!double) k = Math.ceil(k / 4) * 4;  // float32 sizes that are not multiples of 4 run padded to the next one (the library's kPad)
     const nb = Math.ceil(k / 16);
     const tiles = nb * (nb + 1) / 2.0;
-    const dualMax = (double || k % 4) ? 0 : 16 * Math.min(k > 128 ? 12 : 5, nb - 1);
+    const dualMax = double ? 0 : 16 * Math.min(k > 128 ? 12 : 5, nb - 1);
     if (n <= dualMax) return 2700.0 * Math.pow(Math.ceil(n / 16), 1.36) * (k / 100);
     const edge4 = !double && k <= 128 && nb >= 2 && k % 16 == 4;
     const nbs = edge4 ? nb - 1 : nb;
@@ -152,7 +153,13 @@ class EmfMaster extends EmfManager {
 
   /** Upload the ratings once: replaces createWorkPortionBuffers + per-portion fetches (EmfMaster.js:156-234,501-614) */
   prepareWorkersToTrain() {
-    const ds = this.dataset, n = als.native, o = this.options;
+    const n = als.native, o = this.options;
+    if (o.dropLastRatingPerPortion && !this.dataset.portionQuirkApplied) {
+      // opt-in (SURVEY.md 8f N2): the ratings the REFERENCE's packer hands to its workers -- every portion of every pass without
+      // its last rating (lib/emf/EmfMaster.js:594-603); the stats stay those of the full data, as the reference's come from the db
+      this.dataset = this.dataset.withoutLastRatingPerPortion(this.portionsRowIdTo);
+    }
+    const ds = this.dataset;
     this.shardUsers = [0, this.totalUsersCount];
     if (o.world > 1) {
       // one process per GPU: this rank's place in the exchange, then the sharded upload of both sides

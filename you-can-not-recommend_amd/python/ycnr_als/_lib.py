@@ -7,9 +7,21 @@ import ctypes as C
 import os
 
 # The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default) and reads the variable when
-# it starts: with 8, the row kernel and every dual class of a half-step get a queue of their own (libycnr_als.so sets the
-# same default when it is loaded before the first HIP call; here for hosts that import this package first).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# it starts: with 8, the row kernel and every dual class of a half-step get a queue of their own.  libycnr_als.so looks at the
+# variable when it is LOADED (it never sets it) and uses one side stream per dual class only if it says >= 8 then -- so it is
+# set here, before the library is loaded, unless torch has initialised HIP already (the runtime then runs with what it read at
+# its start, and five side streams on four queues would be the slow configuration).
+def _hip_started():
+    import sys
+    t = sys.modules.get("torch")
+    try:
+        return bool(t is not None and t.cuda.is_initialized())
+    except Exception:  # noqa: BLE001
+        return False
+
+
+if not _hip_started():
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.normpath(os.path.join(_HERE, "..", "..", "csrc"))
@@ -39,10 +51,11 @@ EXPORTS = [
     "ycnr_recommend_items",
     "ycnr_comm_unique_id", "ycnr_als_comm_init", "ycnr_als_comm_destroy", "ycnr_als_set_ratings_sharded",
     "ycnr_als_exchange", "ycnr_als_broadcast_factors", "ycnr_als_allreduce_sum", "ycnr_als_comm_selftest",
+    "ycnr_als_comm_info", "ycnr_als_last_rmse_ms",
 ]
 COMM_NONE, COMM_RCCL, COMM_SHM, COMM_IPC, COMM_STUB = 0, 1, 2, 3, 4
 COMM_ID_BYTES = 128
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class YcnrError(RuntimeError):
@@ -166,6 +179,10 @@ def load():
     L.ycnr_als_allreduce_sum.argtypes = [vp, vp, i64]
     L.ycnr_als_comm_selftest.restype = i32
     L.ycnr_als_comm_selftest.argtypes = [vp, i64]
+    L.ycnr_als_comm_info.restype = i32
+    L.ycnr_als_comm_info.argtypes = [vp, vp]
+    L.ycnr_als_last_rmse_ms.restype = i32
+    L.ycnr_als_last_rmse_ms.argtypes = [vp, C.POINTER(dbl)]
     _lib = L
     return L
 

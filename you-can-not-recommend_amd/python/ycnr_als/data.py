@@ -162,15 +162,56 @@ def init_factors(rows, k, seed, dtype=np.float32):
     return (rng.standard_normal((int(rows), int(k))) / k).astype(dtype)
 
 
-def csr_to_portion(csr, row_begin, row_end):
+def csr_to_portion(csr, row_begin, row_end, dropLastRatingPerPortion=False):
     """Rows [row_begin, row_end) of a numpy Csr in the reference's portion-buffer format
-    (alsRows / alsIndx / alsVals, lib/emf/EmfMaster.js:589-609), rows without ratings omitted."""
+    (alsRows / alsIndx / alsVals, lib/emf/EmfMaster.js:589-609), rows without ratings omitted.
+
+    dropLastRatingPerPortion (opt-in): the row table the REFERENCE's packer writes for these
+    ratings, bug for bug (its end-of-data branch, lib/emf/EmfMaster.js:594-603, records the row that is open when
+    the last rating arrives BEFORE counting that rating): the last row's count is one short; a last row of a
+    single rating is not recorded at all -- unless it is the portion's only rating, then it is recorded with
+    cols = 0 (which libycnr_als skips, include/ycnr_als.h).  alsIndx / alsVals hold every rating either way, as
+    the reference's buffers do."""
     c = csr
     b, e = int(c.rowPtr[row_begin]), int(c.rowPtr[row_end])
     cnt = (c.rowPtr[row_begin + 1:row_end + 1] - c.rowPtr[row_begin:row_end]).astype(np.int64)
     ids = np.nonzero(cnt)[0]
+    cols = cnt[ids]
+    if dropLastRatingPerPortion and len(ids):
+        if cols[-1] > 1 or e - b == 1:
+            cols = cols.copy()
+            cols[-1] -= 1
+        else:
+            ids, cols = ids[:-1], cols[:-1]
     rows = np.empty(1 + 2 * len(ids), np.int32)
     rows[0] = len(ids)
     rows[1::2] = ids + row_begin
-    rows[2::2] = cnt[ids]
+    rows[2::2] = cols
     return rows, np.ascontiguousarray(c.indx[b:e]), np.ascontiguousarray(c.vals[b:e])
+
+
+def drop_last_rating_per_portion(csr, portion_row_ends):
+    """The ratings a pass of the REFERENCE really consumes when `csr` is fed to it in the portions that end at the
+    0-based exclusive row ids `portion_row_ends` (= its 1-based inclusive portionsRowIdTo, lib/emf/EmfLord.js:571-592):
+    every portion loses its last rating (csr_to_portion(..., dropLastRatingPerPortion=True); the packer of
+    lib/emf/EmfMaster.js:594-603).  Returns a Csr of the same shape (numpy or torch, like the input); a row left
+    without ratings is not solved, as the rows the reference never records or records with cols = 0.
+    Opt-in compatibility for bug-for-bug replays: the resident trainer consumes every rating by default."""
+    is_np = isinstance(csr.rowPtr, np.ndarray)
+    rp = csr.rowPtr if is_np else csr.rowPtr.cpu().numpy()
+    ends = np.asarray(portion_row_ends, np.int64)
+    ends = ends[(ends > 0) & (ends <= csr.rows)]
+    last = rp[ends] - 1                                   # position of the last rating of every portion ...
+    begin = rp[np.concatenate([[0], ends[:-1]])]
+    last = np.unique(last[rp[ends] > begin])              # ... that holds a rating at all
+    keep = np.ones(int(rp[-1]), bool)
+    keep[last] = False
+    cnt = np.diff(rp).copy()
+    if len(last):
+        cnt[np.searchsorted(rp, last, side="right") - 1] -= 1
+    new_rp = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+    if is_np:
+        return Csr(csr.rows, csr.cols, new_rp, np.ascontiguousarray(csr.indx[keep]), np.ascontiguousarray(csr.vals[keep]))
+    dev = csr.indx.device
+    k = torch.from_numpy(keep).to(dev)
+    return Csr(csr.rows, csr.cols, torch.from_numpy(new_rp).to(dev), csr.indx[k].contiguous(), csr.vals[k].contiguous())

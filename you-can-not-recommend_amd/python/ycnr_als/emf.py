@@ -38,6 +38,10 @@ def default_options():
         "numThreadsForTrain": {"als": os.cpu_count() or 1, "sgd": 1},
         "numThreadsForRmse": os.cpu_count() or 1,
         "useDoublePrecision": False,
+        # not in the reference (opt-in): consume the ratings the REFERENCE's portion packer really hands to
+        # its workers -- the last rating of every portion dropped (lib/emf/EmfMaster.js:594-603) -- for bug-for-bug replays
+        # of a reference run; portions as splitToPortions cuts them for each pass (lib/emf/EmfLord.js:510-612)
+        "dropLastRatingPerPortion": False,
         # not in the reference: where the factor directories live (reference: <repo>/data)
         "dataDir": "data",
         # ratings per wave-level work unit on the GPU (0 = library default)
@@ -130,9 +134,11 @@ def row_cost(counts, k, double=False):
       * float64 and the any-k path (no dual classes): coarse multiples of the above.
     The feedback re-cut (rebalanced_ranges) corrects what the model gets wrong on a given box."""
     n = np.asarray(counts, np.float64)
+    if not double:
+        k = (k + 3) // 4 * 4  # float32 sizes that are not multiples of 4 run on matrices padded to the next one (kPad): its classes, its edge
     nb = (k + 15) // 16
     tiles = nb * (nb + 1) / 2.0
-    dual_max = 0 if (double or k % 4) else 16 * min(12 if k > 128 else 5, nb - 1)
+    dual_max = 0 if double else 16 * min(12 if k > 128 else 5, nb - 1)
     edge4 = (not double) and k <= 128 and nb >= 2 and k % 16 == 4
     nbs = nb - 1 if edge4 else nb
     mfmas = 4.0 * (nbs * (nbs - 1) / 2.0 + (nbs - 1) * nbs * (nbs + 1) / 6.0) + (nbs * (nbs + 1) / 2.0 if edge4 else 0.0)
@@ -357,6 +363,8 @@ class EmfLord:
         cu = _to_np(ds.train_by_user.counts())
         ci = _to_np(ds.train_by_item.counts())
         self.ratingsCntPerUser, self.ratingsCntPerItem = cu, ci
+        if self.options.get("dropLastRatingPerPortion", False):
+            ds = self.dataset = self._with_reference_portion_quirk(ds, cu, ci)
         k, dbl = self.factorsCount, self.options["useDoublePrecision"]
         # shards: {side: int64[world + 1]} overrides the cost-model cut (bench.py --emulate-world replays measured cuts)
         self.shards = shards or {0: shard_ranges(cu, self.world, k, dbl), 1: shard_ranges(ci, self.world, k, dbl)}
@@ -455,6 +463,26 @@ class EmfLord:
         self.backend.set_factors(0, userFactors)
         self.backend.set_factors(1, itemFactors)
         self._status = "ready"
+
+    def _with_reference_portion_quirk(self, ds, cu, ci):
+        """options.dropLastRatingPerPortion: the data set as the reference's workers see it -- every pass cut into the portions
+        of splitToPortions (stats of the full data, as the reference's come from the db), each portion without its last rating."""
+        from .data import drop_last_rating_per_portion
+        o = self.options
+        nthreads, distr = o["numThreadsForTrain"]["als"], o["dataSetDistr"]
+        per = o["ratingsInPortionForAls"]
+        eu, _, _ = split_to_portions(cu, int((cu > 0).sum()), per["byUser"], nthreads)
+        ei, _, _ = split_to_portions(ci, int((ci > 0).sum()), per["byItem"], nthreads)
+        out = Dataset(drop_last_rating_per_portion(ds.train_by_user, eu), drop_last_rating_per_portion(ds.train_by_item, ei),
+                      ds.validate, ds.test, ds.totalRatingsAvg)
+        for name, pct in (("validate", distr[1] + 1), ("test", distr[2] + 1)):
+            csr = getattr(ds, name)
+            if csr is not None:
+                ends, _, _ = split_to_portions(cu, int((cu > 0).sum()), o["ratingsInPortionForRmse"], nthreads, pct)
+                if len(ends):
+                    ends[-1] = ds.totalUsersCount
+                setattr(out, name, drop_last_rating_per_portion(csr, ends))
+        return out
 
     def _upload_shards(self, sides):
         """(Re)upload the train ratings of `sides` for the current self.shards: this rank's rows, in pieces when

@@ -258,6 +258,19 @@ class AlsDevice:
     def comm_selftest(self, nFloats=1 << 20):
         check(self._L.ycnr_als_comm_selftest(self._h, int(nFloats)))
 
+    def comm_info(self):
+        """{transport, rank, world, rccl_ranks}: rccl_ranks is what RCCL itself counts (ncclCommCount), None off RCCL."""
+        out = np.zeros(4, np.int32)
+        check(self._L.ycnr_als_comm_info(self._h, out.ctypes.data))
+        names = {v: k for k, v in TRANSPORTS.items() if isinstance(k, str)}
+        return {"transport": names.get(int(out[0]), "none"), "rank": int(out[1]), "world": int(out[2]),
+                "rccl_ranks": int(out[3]) if out[3] >= 0 else None}
+
+    def last_rmse_ms(self):
+        ms = C.c_double(0.0)
+        check(self._L.ycnr_als_last_rmse_ms(self._h, C.byref(ms)))
+        return ms.value
+
     def set_rmse_ratings(self, which, rowPtr, indx, vals, rowBegin=0, rowEnd=None):
         self._upload(self._L.ycnr_als_set_rmse_ratings, RMSE_SETS[which], rowPtr, indx, vals, rowBegin, rowEnd)
 
