@@ -129,6 +129,10 @@ def main():
                          "reports the compute time per rank, before and after the feedback re-cut of the shards")
     ap.add_argument("--rebalance-after", type=int, default=2, help="N > 1: re-cut the shards from measured times after each of the first this-many iterations (0 = never)")
     ap.add_argument("--exchange-chunks", type=int, default=4, help="pieces a large side's shard is solved in (exchange overlaps solve)")
+    ap.add_argument("--item-sharding", default="rows", choices=["rows", "bands"],
+                    help="N > 1: how the item half-step is sharded -- 'rows': items over the ranks, the user matrix all-gathered after every "
+                         "user half-step; 'bands': the users in 8 fixed bands, Gramians of all items per band, reduce-scatter of the band sums "
+                         "(EmfLord option itemStepSharding; also at N = 1, where it only fixes the order of the sums)")
     ap.add_argument("--dump-factors", default="", help="write the final factor matrices of rank 0 to this .npz")
     ap.add_argument("--dump-step-info", action="store_true", help="add the library's step info of the last half-step of each side to the line (step_info)")
     ap.add_argument("--debug-mod-idx", type=int, default=0,
@@ -184,7 +188,7 @@ def main():
     lord = EmfLord(options={"factorsCount": k, "trainIters": args.steps, "useDoublePrecision": args.double,
                             "dbType": "mal" if max_rating == 10 else "ml", "chunkRatings": args.chunk,
                             "dataSetDistr": [90, 10, 0], "exchangeChunks": args.exchange_chunks, "rebalanceAfterIters": args.rebalance_after,
-                            "commTransport": requested_transport, "strictTransport": not args.allow_fallback},
+                            "commTransport": requested_transport, "strictTransport": not args.allow_fallback, "itemStepSharding": args.item_sharding},
                     dist=dist)
     lord.prepareToTrain(ds, seed=20260004, device=local_rank)
     if world > 1 and not args.allow_fallback and lord.exchangePath != "libycnr_als:" + requested_transport:
@@ -384,6 +388,7 @@ def main():
         exchange[sd] = {"compute_ms": round(c["compute_ms"] / n, 4), "exchange_ms": round(c["exchange_ms"] / n, 4),
                         "exposed_exchange_ms": round(c["exposed_exchange_ms"] / n, 4), "wall_ms": round(c["wall_ms"] / n, 4),
                         "bytes": int(c["bytes"] // n), "pieces": c["pieces"]}
+    lord.finishExchange()  # (itemStepSharding = 'bands': the user matrix is brought up to date everywhere only now)
     if dist:
         # every replica must hold the same bytes after the last exchange: a checksum of both matrices per rank
         sums = []
@@ -431,7 +436,9 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64" if args.double else "f32", "data": "synthetic",
             "config": {"workload": desc, "users": users, "items": items, "nnz": nnz, "factorsCount": k,
-                       "lambda": 0.05, "parallelism": f"row-shard x{world} + direct all-gather ({lord.exchangePath})" if world > 1 else "1 GPU"},
+                       "lambda": 0.05, "parallelism": (f"row-shard x{world} + direct all-gather ({lord.exchangePath})" if args.item_sharding == "rows" else
+                                                       f"users in 8 bands over {world} rank(s): items' Gramians reduce-scattered, item rows all-gathered ({lord.exchangePath})")
+                       if world > 1 else "1 GPU", "itemStepSharding": args.item_sharding},
             "rmse_in_sample_after_iters": rmse, "iters_run": args.steps + args.warmup,
             "rmse_ms": rmse_ms, "rmse_ratings": val.nnz, "rmse_ratings_per_s": (val.nnz / (rmse_ms * 1e-3)) if rmse_ms else None,
             "roofline": roofline, "exchange": exchange, "cpu_baseline": cpu, "cpu_baseline_blas": cpu_blas,
@@ -552,7 +559,8 @@ def emulate_world(args, local_rank):
         for r in range(W):
             lord = EmfLord(options={"factorsCount": k, "trainIters": args.steps, "useDoublePrecision": args.double,
                                     "dbType": "mal" if max_rating == 10 else "ml", "chunkRatings": args.chunk, "dataSetDistr": [100, 0, 0],
-                                    "exchangeChunks": args.exchange_chunks, "commTransport": "stub", "rebalanceAfterIters": 0},
+                                    "exchangeChunks": args.exchange_chunks, "commTransport": "stub", "rebalanceAfterIters": 0,
+                                    "itemStepSharding": args.item_sharding},
                             dist=EmulatedDist(r, W))
             t_rank = time.time()
             lord.prepareToTrain(ds, seed=20260004, device=local_rank, shards=shards)
@@ -586,6 +594,16 @@ def emulate_world(args, local_rank):
         return per, used
 
     first, shards0 = run(None)
+    if args.item_sharding == "bands":  # (the bands are the shards: nothing to re-cut)
+        out = {"emulated_world": W, "workload": desc, "factorsCount": k, "dtype": "f64" if args.double else "f32", "steps": args.steps,
+               "itemStepSharding": "bands",
+               "note": "one GPU solves every rank's share in turn (transport 'stub', exchange left out): byUser = the rank's user band, "
+                       "no exchange; byItem = Gramians of ALL items over the band's ratings + reduce and solve of the rank's items (the other "
+                       "ranks' band sums are not there: an eighth of the reduce's reads); exchange_bytes = band sums sent + received + "
+                       "item rows, per rank and iteration",
+               "bands_cut": first, "shards": {"bands": shards0}}
+        print(json.dumps(out), flush=True)
+        return
     new = {s: rebalanced_ranges(cnt[s], shards0[s], first[names[s]]["compute_ms"], k, args.double) for s in (0, 1)}
     second, shards1 = run(new)
     out = {"emulated_world": W, "workload": desc, "factorsCount": k, "dtype": "f64" if args.double else "f32", "steps": args.steps,

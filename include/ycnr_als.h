@@ -309,6 +309,28 @@ int ycnr_als_comm_info(ycnr_als *h, int32_t out[4]);
  * meaning of 'stepComplete' in the reference's cluster (EmfLord.alsTrainStep, EmfLord.js:963-984). */
 int ycnr_als_set_ratings_sharded(ycnr_als *h, int side, const int64_t *rowPtr, const int32_t *indx, const void *vals,
                                  int memKind, int nChunks, int boundsWorld, const int64_t *bounds);
+/* A side whose half-step is sharded by BANDS OF COLUMNS instead of by rows (meant for the item side, whose fixed
+ * matrix -- the users' -- is the large one): the columns are cut into nBands bands (nBands <= 8, the same cut for every world
+ * size), rank r holds the bands [rankBands[r], rankBands[r + 1]) and accumulates, for EVERY row of the side, the Gramian over the
+ * ratings whose column lies in its bands -- so the fixed matrix never has to be current outside its own band: with the user side
+ * uploaded as a plain shard (ycnr_als_set_ratings: no exchange) the user matrix is never all-gathered.  Every (row, band) sum
+ * travels to the rank that owns the row (rows [ownerBounds[r], ownerBounds[r + 1])), which adds a row's bands in band order,
+ * solves, and the solved rows are exchanged as after a sharded upload.  The order of every sum is fixed by the bands, not by the
+ * ranks: 1, 2, 4 or 8 ranks give the same bits.  This replaces, for that side, the reference's per-portion row broadcast
+ * (EmfMaster.wm_completedPortion, lib/emf/EmfMaster.js:711-723) by a reduce-scatter of Gramians + the broadcast of the (small) solved side.
+ *   rowPtr / indx / vals   CSR of the side with ALL its rows, holding only the ratings whose column id lies in this rank's bands
+ *                          (the host filters; ascending column ids per row)
+ *   bandBounds             int64[nBands + 1] column ids, ascending from 0 to the column count
+ *   rankBands              int64[world + 1] band indices, ascending from 0 to nBands
+ *   ownerBounds            int64[world + 1] row ids, ascending from 0 to the row count
+ * Collective (every rank of the communicator; world = 1 without one).  factorsCount <= 128 (float32: multiples of 4);
+ * transports rccl, ipc and stub.  A later ycnr_als_set_ratings[_sharded] of the side returns it to row shards. */
+int ycnr_als_set_ratings_banded(ycnr_als *h, int side, const int64_t *rowPtr, const int32_t *indx, const void *vals, int memKind,
+                                int nBands, const int64_t *bandBounds, const int64_t *rankBands, const int64_t *ownerBounds);
+/* deferred != 0: the half-steps of this (sharded) side no longer exchange their solved rows -- every rank's replica is current in
+ * its own rows only -- until ycnr_als_exchange brings all replicas up to date.  For a side whose matrix nobody reads outside its
+ * own shard between two exchanges: the user side when the item side is sharded by user bands (ycnr_als_set_ratings_banded). */
+int ycnr_als_defer_exchange(ycnr_als *h, int side, int deferred);
 /* The exchange alone, whole shards, synchronous (e.g. after ycnr_als_set_factors of local rows). */
 int ycnr_als_exchange(ycnr_als *h, int side);
 /* root's whole matrix to every rank. */

@@ -17,7 +17,7 @@ import socket
 import numpy as np
 import pytest
 
-from helpers import make_problem
+from helpers import EPS32, make_problem, numpy_step, row_rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -45,7 +45,8 @@ def problem(k=36, users=900, items=400, seed=3, density=0.08):
 # k = 256 with rows of ~190 ratings either side of the primal / dual crossover (Gramian -> slab -> four-wave solve in
 # batches, dual classes on the side streams) and items of ~330 ratings
 # k = 50 (float32, factorsCount % 4 != 0: the kernels work on copies padded to 52 columns, every piece unpads its rows before its exchange)
-SHAPES = {"k36": (36, 900, 400, 3, 0.08), "k100": (100, 1200, 500, 4, 0.15), "k256": (256, 700, 400, 5, 0.47), "k50": (50, 1000, 450, 6, 0.12)}
+SHAPES = {"k36": (36, 900, 400, 3, 0.08), "k100": (100, 1200, 500, 4, 0.15), "k256": (256, 700, 400, 5, 0.47), "k50": (50, 1000, 450, 6, 0.12),
+          "k64f": (64, 700, 300, 9, 0.3)}  # k % 16 == 0: the Gramian kernels without a padded right-hand-side column
 
 
 def reference_iteration(als, k, users, items, bu, bi, U, V):
@@ -214,6 +215,90 @@ def test_back_to_back_async_half_steps(als, transport, world, shape):
         assert np.array_equal(Ug, U1) and np.array_equal(Vg, V1), f"rank {rank}: replicas differ from the single-process run"
 
 
+def _band_setup(k, users, items, bu, bi, world):
+    """8 cost-balanced user bands (whatever the world size), rank r holding 8 / world of them; items cut evenly"""
+    from ycnr_als.emf import shard_ranges
+    bands = shard_ranges(np.diff(bu.rowPtr), 8, k)
+    rank_bands = np.arange(world + 1, dtype=np.int64) * (8 // world)
+    owners = np.linspace(0, items, world + 1).astype(np.int64)
+    return bands, rank_bands, owners
+
+
+def _banded_iteration(dev, rank, world, k, users, items, bu, bi, U, V, chunk_check=False):
+    from ycnr_als.emf import _columns_between
+    bands, rank_bands, owners = _band_setup(k, users, items, bu, bi, world)
+    ub = bands[rank_bands]
+    if world > 1:
+        dev.set_ratings_sharded("byUser", bu.rowPtr, bu.indx, bu.vals, np.stack([ub[r:r + 2] for r in range(world)]))
+        dev.defer_exchange("byUser", True)
+    else:
+        dev.set_ratings("byUser", bu.rowPtr, bu.indx, bu.vals)
+    sub = _columns_between(bi, int(ub[rank]), int(ub[rank + 1]))
+    dev.set_ratings_banded("byItem", sub.rowPtr, sub.indx, sub.vals, bands, rank_bands, owners)
+    dev.set_factors("byUser", U)
+    dev.set_factors("byItem", V)
+    iu = dev.step("byUser")
+    ii = dev.step("byItem")
+    # a second iteration: the item half-step above must have left every replica of V current, the user half-step reads it
+    dev.step("byUser")
+    dev.step("byItem")
+    if world > 1:
+        dev.exchange("byUser")
+    return dev.get_factors("byUser"), dev.get_factors("byItem"), iu, ii
+
+
+def _band_rank_main(rank, world, uid, out, shape, chunk, transport="ipc", device=0):
+    import ycnr_als as als
+    k, users, items, bu, bi, U, V = problem(*SHAPES[shape])
+    dev = als.AlsDevice(k, users, items, chunkRatings=chunk, device=device)
+    dev.comm_init(uid, rank, world, transport)
+    Ug, Vg, iu, ii = _banded_iteration(dev, rank, world, k, users, items, bu, bi, U, V)
+    dev.destroy()
+    out.put((rank, Ug, Vg, int(ii.exchangeBytes), int(iu.exchangeBytes)))
+
+
+@pytest.mark.parametrize("shape,chunk", [("k36", 0), ("k100", 32), ("k64f", 0)])
+def test_item_half_step_sharded_by_user_bands(als, shape, chunk):
+    """ycnr_als_set_ratings_banded: the item half-step as Gramians of ALL items over every rank's own users' ratings, one slab per
+    (item, band of users), the owner adds an item's bands in band order and solves.  One rank with all 8 bands must solve every
+    item within the conditioning bound of its float64 solve (another order of the sums than the row-sharded half-step, not
+    another result); 2 and 4 ranks sharing cuda:0 over `ipc` -- band sums pushed into the owners' buffers, the solved item rows
+    pushed into every replica, the user matrix exchanged only at the very end -- must reproduce the one-rank run bit for bit
+    after two iterations.  chunk = 32: (item, band) segments cut into several chunks (the sum kernel)."""
+    k, users, items, bu, bi, U, V = problem(*SHAPES[shape])
+    dev = als.AlsDevice(k, users, items, chunkRatings=chunk)
+    U1, V1, iu, ii = _banded_iteration(dev, 0, 1, k, users, items, bu, bi, U, V)
+    dev.destroy()
+    # against float64, one iteration at a time: redo the two iterations on the host
+    Uh, Vh = U.astype(np.float64), V.astype(np.float64)
+    for _ in range(2):
+        Uh, _c = numpy_step(0.05, k, bu, Vh, Uh)
+        Vh, ci = numpy_step(0.05, k, bi, Uh, Vh)
+    e = row_rel_err(V1, Vh)
+    assert (e <= np.maximum(64 * ci * EPS32, 1e-5)).all(), float((e / np.maximum(64 * ci * EPS32, 1e-5)).max())
+    for world in (2, 4):
+        uid = als.AlsDevice.comm_unique_id("ipc")
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_band_rank_main, args=(r, world, uid, q, shape, chunk)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = []
+        while len(res) < world:
+            try:
+                res.append(q.get(timeout=5))
+            except Exception:  # noqa: BLE001 -- queue.Empty: is everybody still alive?
+                dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+                assert not dead, f"a rank process died (exit codes {dead})"
+        for p in procs:
+            p.join(60)
+            assert p.exitcode == 0
+        for rank, Ug, Vg, xi, xu in res:
+            assert np.array_equal(Vg, V1), f"world {world}, rank {rank}: item factors differ from the one-rank run"
+            assert np.array_equal(Ug, U1), f"world {world}, rank {rank}: user factors differ from the one-rank run"
+            assert xi > 0 and xu == 0   # band sums + item rows travelled; the user half-step exchanged nothing
+
+
 @pytest.mark.parametrize("transport", ["rccl", "ipc"])
 def test_two_ranks_on_two_gpus(als, transport):
     """The product transports between two DEVICES (skipped on the one-GPU boxes; the scaling job's node has
@@ -237,6 +322,31 @@ def test_two_ranks_on_two_gpus(als, transport):
     for rank, (Ug, Vg), s, parts, xu, xi in res:
         assert np.array_equal(Ug, U1) and np.array_equal(Vg, V1), f"rank {rank}: replicas differ from the single-process run"
         assert parts == 3 and xu > 0 and xi > 0
+
+
+@pytest.mark.parametrize("transport", ["rccl", "ipc"])
+def test_user_bands_on_two_gpus(als, transport):
+    """The banded item half-step between two DEVICES (skipped on the one-GPU boxes): the band sums travel by grouped ncclSend /
+    ncclRecv (rccl, stream-ordered) or by pushes into the owner's mapped buffer (ipc), bit for bit the one-rank result."""
+    L = als._lib.load()
+    if L.ycnr_device_count() < 2:
+        pytest.skip("needs two visible devices")
+    k, users, items, bu, bi, U, V = problem(*SHAPES["k100"])
+    dev = als.AlsDevice(k, users, items, chunkRatings=32)
+    U1, V1, _, _ = _banded_iteration(dev, 0, 1, k, users, items, bu, bi, U, V)
+    dev.destroy()
+    uid = als.AlsDevice.comm_unique_id(transport)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_band_rank_main, args=(r, 2, uid, q, "k100", 32, transport, r)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, Ug, Vg, xi, xu in res:
+        assert np.array_equal(Vg, V1) and np.array_equal(Ug, U1), f"rank {rank}: factors differ from the one-rank run"
 
 
 def test_emulated_world_reports_every_rank(tmp_path):

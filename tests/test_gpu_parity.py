@@ -870,8 +870,8 @@ def test_bench_starts_its_own_ranks(tmp_path):
     assert out["rmse_ms"] > 0
 
 
-@pytest.mark.parametrize("world,transport", [(2, "shm"), (4, "shm"), (3, "ipc")])
-def test_ranks_on_one_gpu_equal_one_rank(tmp_path, world, transport):
+@pytest.mark.parametrize("world,transport,sharding", [(2, "shm", "rows"), (4, "shm", "rows"), (3, "ipc", "rows"), (2, "ipc", "bands"), (4, "ipc", "bands")])
+def test_ranks_on_one_gpu_equal_one_rank(tmp_path, world, transport, sharding):
     """The sharded HIP path end to end: 2 / 4 gloo ranks sharing cuda:0 (functional stand-in for
     that many GPUs over RCCL; the GPU boxes allow at most 6 processes on the card, this one included) must reproduce the single-process factors bit for bit -- shard
     ranges, per-shard CSR upload, the chunked pipelined exchange, the padded all-gather and
@@ -879,7 +879,9 @@ def test_ranks_on_one_gpu_equal_one_rank(tmp_path, world, transport):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    common = ["--workload", "ml100k", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    # (sharding = 'bands': EmfLord's itemStepSharding -- users in 8 bands, the items' Gramians reduce-scattered; one rank runs the
+    # same bands, so the order of every sum is the same)
+    common = ["--workload", "ml100k", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--item-sharding", sharding]
     one = str(tmp_path / "one.npz")
     two = str(tmp_path / "two.npz")
     subprocess.check_call([sys.executable, os.path.join(root, "bench.py")] + common + ["--dump-factors", one], timeout=600)

@@ -2968,6 +2968,63 @@ __global__ __launch_bounds__(64, (reduce_waves<T, NB, LDS_SOLVER, E4, FEW>())) v
 }
 
 // ---------------------------------------------------------------------------------------
+// The item half-step sharded by USER BANDS (ycnr_als_set_ratings_banded).  Every rank accumulates, for EVERY row of
+// the side, the Gramian over the ratings of its own bands of columns -- one slab per (row, band): the chunk kernels above, and
+// als_slab_sum_kernel where a (row, band) segment was cut into several chunks --, the slabs travel to the row's owner, and the
+// owner adds a row's band slabs in band order and solves: the same arithmetic whatever the number of ranks.
+
+// dst slab <- sum of n consecutive source slabs, in order (element offsets into one arena); in double beyond kFewSlabs, as the
+// reduce kernels sum the slabs of a row
+struct SlabSum {
+  int64_t dst, src0;
+  int32_t n, pad;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void als_slab_sum_kernel(T *arena, const SlabSum *list, int64_t elems) {
+  const SlabSum e = list[blockIdx.x];
+  for (int64_t i = threadIdx.x; i < elems; i += 256) {
+    const T *src = arena + e.src0 + i;
+    if (std::is_same<T, float>::value && e.n > kFewSlabs) {
+      double v = 0.0;
+      for (int s = 0; s < e.n; ++s) v += (double)src[(int64_t)s * elems];
+      arena[e.dst + i] = (T)v;
+    } else {
+      T v = T(0);
+      for (int s = 0; s < e.n; ++s) v += src[(int64_t)s * elems];
+      arena[e.dst + i] = v;
+    }
+  }
+}
+
+// One wave per owned row: its band slabs (bandSlab[sr.slab0 + b], null where the row has no rating in band b: local ones in this
+// rank's arena, the others where the peers delivered them) added in band order, then the solve of als_reduce_solve_kernel.
+template <typename T, int NB, bool LDS_SOLVER, bool EDGE, bool E4 = false>
+__global__ __launch_bounds__(64, 1) void als_band_reduce_solve_kernel(StepArgs<T> a, const T *const *bandSlab, int32_t nBands) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using G = typename GramSel<T, NB, EDGE>::type;
+  using acc_t = typename G::acc_t;
+  const int lane = threadIdx.x;
+  const SplitRow sr = a.split[blockIdx.x];
+  typename G::State st;
+  G::init(st);
+  for (int b = 0; b < nBands; ++b) {
+    const T *p = bandSlab[(int64_t)sr.slab0 + b];
+    if (p) G::add_slab(st, p + lane);  // wave-uniform
+  }
+  acc_t acc[G::NT];
+  T bacc[NB];
+  G::to_tiles(st, acc, bacc, reinterpret_cast<T *>(smem), lane);
+  const T lam = (T)(a.lambda * (double)sr.n);
+  if constexpr (E4 && std::is_same<T, float>::value && !LDS_SOLVER) {
+    SolveMfmaF32<NB>::template run<true>(acc, bacc, reinterpret_cast<float *>(smem), a.k, lam, a.solved + (int64_t)sr.row * a.k, sr.row, a.err, lane,
+                                         a.kReal > 0 ? a.kReal : -1);
+  } else {
+    SolverFor<T, NB, LDS_SOLVER>::type::run(acc, bacc, reinterpret_cast<T *>(smem), a.k, lam,
+                                          a.solved + (int64_t)sr.row * a.k, sr.row, a.err, lane, a.kReal > 0 ? a.kReal : -1);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // RMSE partial sums (EmfWorker.mw_calcRmsePortion, lib/emf/EmfWorker.js:266-315).
 // One 256-thread workgroup per portion; a 16-lane group walks one user row at a time,
 // its lanes striding the k factors of U[u] and I[i]; (r - pred)^2, pred and the count are

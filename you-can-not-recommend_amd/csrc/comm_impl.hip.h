@@ -130,6 +130,13 @@ struct Comm {
     char *fac[2] = {nullptr, nullptr};   // the peer's matrix of each side
   };
   std::vector<IpcPeer> peers;
+  // IPC: one more buffer per side of every peer, mapped on demand (ipc_publish_extra): where the owner of a row receives the row's
+  // band slabs (the item half-step sharded by user bands)
+  struct IpcExtra {
+    void *base = nullptr;
+    char *ptr = nullptr;
+  };
+  std::vector<IpcExtra> extra[2];
   const void *mapped[2] = {nullptr, nullptr};  // this rank's matrices as the peers know them (re-published when rebound)
   bool pendingFinish = false;                 // pushes enqueued since the last end-of-step barrier
 
@@ -154,6 +161,14 @@ int shm_barrier(Comm &c) {
   return YCNR_OK;
 }
 
+void ipc_close_extra(Comm &c, int side) {
+  for (Comm::IpcExtra &e : c.extra[side]) {
+    if (e.base) (void)hipIpcCloseMemHandle(e.base);
+    e.base = nullptr;
+    e.ptr = nullptr;
+  }
+}
+
 void ipc_close_peers(Comm &c) {
   for (Comm::IpcPeer &p : c.peers)
     for (int s = 0; s < 2; ++s) {
@@ -166,6 +181,10 @@ void ipc_close_peers(Comm &c) {
 
 void comm_release(Comm &c) {
   if (c.stream) (void)hipStreamSynchronize(c.stream);
+  ipc_close_extra(c, 0);
+  ipc_close_extra(c, 1);
+  c.extra[0].clear();
+  c.extra[1].clear();
   ipc_close_peers(c);
   c.peers.clear();
   c.pendingFinish = false;
@@ -326,6 +345,68 @@ int ipc_publish(Comm &c, void *const fac[2], bool localFailed = false) {
   }
   c.mapped[0] = fac[0];
   c.mapped[1] = fac[1];
+  return YCNR_OK;
+}
+
+// IPC: every rank publishes one more device buffer of `side` (null: none) and maps its peers'.  Collective, same protocol as
+// ipc_publish (a rank that failed locally still takes part and says so in its slot).
+int ipc_publish_extra(Comm &c, int side, void *buf, bool localFailed = false) {
+  if (c.transport != YCNR_COMM_IPC || c.world < 2) return YCNR_OK;
+  if ((size_t)c.world * sizeof(IpcSlot) > c.dataBytes) return fail(YCNR_ERR_STATE, "ipc: control segment too small for %d ranks", c.world);
+  ipc_close_extra(c, side);
+  c.extra[side].assign((size_t)c.world, Comm::IpcExtra());
+  IpcSlot mine;
+  memset(&mine, 0, sizeof mine);
+  mine.status = localFailed ? -1 : 1;
+  std::string why;
+  if (mine.status > 0 && buf) {
+    hipDeviceptr_t base = nullptr;
+    size_t size = 0;
+    hipError_t e = hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)buf);
+    if (e == hipSuccess) e = hipIpcGetMemHandle(&mine.handle[0], (void *)base);
+    if (e != hipSuccess) {
+      why = std::string("publishing the band-slab buffer: ") + hipGetErrorString(e);
+      mine.status = -1;
+      (void)hipGetLastError();
+    } else {
+      mine.offset[0] = (uint64_t)((const char *)buf - (const char *)base);
+      mine.offset[1] = 1;  // a buffer is there
+    }
+  }
+  IpcSlot *slots = (IpcSlot *)c.data;
+  memcpy(&slots[c.rank], &mine, sizeof mine);
+  int rc = shm_barrier(c);
+  if (rc) return rc;
+  int failedRank = -1;
+  std::string openErr;
+  for (int p = 0; p < c.world; ++p) {
+    IpcSlot theirs;
+    memcpy(&theirs, &slots[p], sizeof theirs);
+    if (theirs.status <= 0 && failedRank < 0) failedRank = p;
+  }
+  for (int p = 0; p < c.world && failedRank < 0 && openErr.empty(); ++p) {
+    if (p == c.rank) continue;
+    IpcSlot theirs;
+    memcpy(&theirs, &slots[p], sizeof theirs);
+    if (!theirs.offset[1]) continue;
+    void *base = nullptr;
+    hipError_t e = hipIpcOpenMemHandle(&base, theirs.handle[0], hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      openErr = std::string("hipIpcOpenMemHandle of a peer's band-slab buffer failed: ") + hipGetErrorString(e);
+      break;
+    }
+    c.extra[side][(size_t)p].base = base;
+    c.extra[side][(size_t)p].ptr = (char *)base + theirs.offset[0];
+  }
+  rc = shm_barrier(c);
+  if (rc) return rc;
+  if (failedRank >= 0 || !openErr.empty()) {
+    ipc_close_extra(c, side);
+    if (failedRank == c.rank && !why.empty()) return fail(YCNR_ERR_HIP, "ipc: %s", why.c_str());
+    if (failedRank >= 0) return fail(YCNR_ERR_STATE, "ipc: rank %d could not publish its band-slab buffer (this call failed on that rank)", failedRank);
+    return fail(YCNR_ERR_HIP, "ipc: %s", openErr.c_str());
+  }
   return YCNR_OK;
 }
 

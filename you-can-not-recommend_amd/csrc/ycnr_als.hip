@@ -293,6 +293,12 @@ struct DualPlan {
   // replayed (ycnr_als_step_async), so the forks and joins cost nothing per half-step.
   hipStream_t slabStream = nullptr;
   hipEvent_t slabJoin = nullptr;
+  // The item half-step sharded by user bands (step_banded) borrows the kernel choice of launch_nbe: 1 = the chunk kernel alone
+  // over units [0, nSplitUnits) of args.units; 2 = als_band_reduce_solve_kernel alone over nSplit rows of args.split, whose band
+  // slabs are found through this pointer table
+  int only = 0;
+  const void *const *bandSlab = nullptr;
+  int nBands = 0;
 };
 
 template <int M>
@@ -418,6 +424,24 @@ int launch_nbe(StepArgs<T> args, int64_t nUnits, int64_t nSplitUnits, int64_t nS
   const size_t pad = env_flags().k1LdsPad;  // experiments: limits blocks per CU
   if (int rcl = set_max_lds(reinterpret_cast<const void *>(k1), ldsRow + pad)) return rcl;
   if (int rcl = set_max_lds(reinterpret_cast<const void *>(k2), lds)) return rcl;
+  if (dp.only == 1) {
+    if (nSplitUnits > 0) {
+      hipLaunchKernelGGL(k0, dim3((unsigned)nSplitUnits), dim3(64), 0, stream, args);
+      HIP_TRY(hipGetLastError());
+    }
+    return YCNR_OK;
+  }
+  if (dp.only == 2) {
+    void (*kb)(StepArgs<T>, const T *const *, int32_t) = als_band_reduce_solve_kernel<T, NB, LDS_SOLVER, EDGE && !SLABX6, false>;
+    if constexpr (std::is_same<T, float>::value && NB >= 2 && !LDS_SOLVER)
+      if (edge4_k<NB, LDS_SOLVER>(args.k)) kb = als_band_reduce_solve_kernel<T, NB, LDS_SOLVER, EDGE && !SLABX6, true>;
+    if (int rcl = set_max_lds(reinterpret_cast<const void *>(kb), lds)) return rcl;
+    if (nSplit > 0) {
+      hipLaunchKernelGGL(kb, dim3((unsigned)nSplit), dim3(64), lds, stream, args, reinterpret_cast<const T *const *>(dp.bandSlab), (int32_t)dp.nBands);
+      HIP_TRY(hipGetLastError());
+    }
+    return YCNR_OK;
+  }
   args.firstFused = (int32_t)nSplitUnits;
   if (ev) HIP_TRY(hipEventRecord(ev[0], stream));
   const bool branch = dp.slabStream != nullptr && nSplitUnits > 0;  // chunks -> reduce on their own branch
@@ -919,6 +943,39 @@ struct Part {
   }
 };
 
+// A side whose half-step is sharded by BANDS OF COLUMNS (ycnr_als_set_ratings_banded): what the upload leaves besides the
+// side's single Part (local ratings, chunk units, the arena of band + temporary slabs, the owned rows as SplitRow list)
+struct BandedSide {
+  bool on = false;
+  int nBands = 0, world = 1, rank = 0;
+  std::vector<int64_t> rankBands, ownerBounds;    // world + 1 band indices / row ids
+  std::vector<int64_t> groupUnit0, groupUnits;     // per owner group: its chunk units [unit0, +n) of the Part's unit list
+  std::vector<int64_t> groupSum0, groupSums;       // ... and its multi-chunk (row, band) segments [sum0, +n) of dSums
+  std::vector<int64_t> groupSlab0;                 // first band slab of group g in the arena (rows of g x local bands)
+  std::vector<int64_t> recvSlab0;                  // first slab of source rank r in dRecv (owned rows x bands of r; own rank: unused)
+  SlabSum *dSums = nullptr;
+  void *dRecv = nullptr;
+  const void **dTable = nullptr;                   // owned rows x nBands slab pointers (null: no rating of the row in that band)
+  int64_t bandSlabs = 0, tmpSlabs = 0, recvSlabs = 0, ownedSolved = 0, nSums = 0;
+  int64_t slabElems = 0;
+  hipEvent_t evRecv = nullptr, evStage[kFewSlabs] = {};  // stage s: the group computed in it is complete (on its piece stream)
+  void release() {
+    if (dSums) (void)hipFree(dSums);
+    if (dRecv) (void)hipFree(dRecv);
+    if (dTable) (void)hipFree(dTable);
+    if (evRecv) (void)hipEventDestroy(evRecv);
+    for (hipEvent_t &e : evStage) {
+      if (e) (void)hipEventDestroy(e);
+      e = nullptr;
+    }
+    dSums = nullptr;
+    dRecv = nullptr;
+    dTable = nullptr;
+    evRecv = nullptr;
+    on = false;
+  }
+};
+
 }  // namespace
 
 struct ycnr_als {
@@ -959,6 +1016,8 @@ struct ycnr_als {
   float *padded[2] = {nullptr, nullptr};  // [rows x kPad] copies the kernels of that case work on
   bool autoChunk = false;  // options.chunkRatings was 0: sized per upload (auto_chunk)
   std::vector<Part> parts[2];      // the side's local row shard, cut into pipelined pieces (usually one)
+  BandedSide banded[2];            // ycnr_als_set_ratings_banded: the side's half-step is sharded by bands of columns
+  bool deferExchange[2] = {false, false};  // ycnr_als_defer_exchange: the side's half-steps leave the solved rows where they are
   std::vector<int64_t> bounds[2];   // sharded upload: row bounds of every rank's pieces, world x (nParts + 1)
   Comm comm;                        // exchange step of the multi-GPU path (comm_impl.hip.h)
   hipEvent_t evComputeEnd = nullptr;
@@ -1482,6 +1541,7 @@ int ycnr_als_destroy(ycnr_als *h) {
   for (int s = 0; s < 2; ++s) {
     for (Part &p : h->parts[s]) p.release();
     h->parts[s].clear();
+    h->banded[s].release();
     h->rmse[s].release();
     if (h->ownFactors[s] && h->factors[s]) (void)hipFree(h->factors[s]);
     if (h->padded[s]) (void)hipFree(h->padded[s]);
@@ -1790,6 +1850,7 @@ static int set_ratings_parts(ycnr_als *h, int side, const int64_t *rowPtr, const
   }
   HIP_TRY(hipStreamSynchronize(h->stream));  // nothing in flight still reads the previous upload
   for (Part &p : h->parts[side]) p.release();
+  h->banded[side].release();
   h->drop_graphs();
   h->parts[side].swap(pend.parts);
   pend.parts.clear();
@@ -1846,6 +1907,268 @@ int ycnr_als_set_ratings_sharded(ycnr_als *h, int side, const int64_t *rowPtr, c
     else rc = rcp;
   }
   return rc;
+}
+
+// min / max of the column ids against a half-open range (banded uploads: only this rank's bands may appear)
+static int check_index_bounds(const int32_t *dIndx, int64_t n, int64_t lo, int64_t hi, hipStream_t stream, const char *what) {
+  if (n == 0) return YCNR_OK;
+  int32_t *dmm = nullptr;
+  HIP_TRY(hipMalloc(&dmm, 2 * sizeof(int32_t)));
+  int32_t init[2] = {INT32_MIN, INT32_MAX};
+  hipError_t e = hipMemcpyAsync(dmm, init, sizeof init, hipMemcpyHostToDevice, stream);
+  if (e == hipSuccess) {
+    const int blocks = (int)std::min<int64_t>(2048, (n + 255) / 256);
+    hipLaunchKernelGGL(max_i32_kernel, dim3(blocks), dim3(256), 0, stream, dIndx, n, dmm, dmm + 1);
+    e = hipGetLastError();
+  }
+  int32_t got[2] = {0, 0};
+  if (e == hipSuccess) e = hipMemcpyAsync(got, dmm, sizeof got, hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  (void)hipFree(dmm);
+  if (e != hipSuccess) return fail(YCNR_ERR_HIP, "index range check failed: %s", hipGetErrorString(e));
+  if ((int64_t)got[1] < lo || (int64_t)got[0] >= hi)
+    return fail(YCNR_ERR_INVALID, "%s: column id outside this rank's bands (min %d, max %d, bands cover [%lld, %lld))", what, got[1], got[0],
+                (long long)lo, (long long)hi);
+  return YCNR_OK;
+}
+
+int ycnr_als_set_ratings_banded(ycnr_als *h, int side, const int64_t *rowPtr, const int32_t *indx, const void *vals, int memKind,
+                                int nBands, const int64_t *bandBounds, const int64_t *rankBands, const int64_t *ownerBounds) {
+  if (!h || !bandBounds || !rankBands || !ownerBounds) return fail(YCNR_ERR_INVALID, "null argument");
+  if (side != YCNR_BY_USER && side != YCNR_BY_ITEM) return fail(YCNR_ERR_INVALID, "bad side %d", side);
+  if (nBands < 1 || nBands > kFewSlabs)
+    return fail(YCNR_ERR_INVALID, "set_ratings_banded: nBands %d outside [1, %d] (a row's band slabs are added as one short float32 chain)", nBands, kFewSlabs);
+  if (h->copt.factorsCount > kMaxFactors || h->kPad)
+    return fail(YCNR_ERR_UNSUPPORTED, "set_ratings_banded: factorsCount %d (the banded half-step is built for the one-wave kernels: k <= %d, float32 k %% 4 == 0)",
+                h->opt.factorsCount, kMaxFactors);
+  const int world = h->comm.active() ? h->comm.world : 1, rank = h->comm.active() ? h->comm.rank : 0;
+  if (world > kFewSlabs) return fail(YCNR_ERR_UNSUPPORTED, "set_ratings_banded: at most %d ranks", kFewSlabs);
+  if (world > 1 && h->comm.transport == YCNR_COMM_SHM)
+    return fail(YCNR_ERR_UNSUPPORTED, "set_ratings_banded: the host-staged shm stand-in does not carry band slabs (use ipc or rccl)");
+  const int64_t rows = h->rows(side), cols = h->rows(1 - side);
+  for (int b = 0; b <= nBands; ++b)
+    if (bandBounds[b] < 0 || bandBounds[b] > cols || (b > 0 && bandBounds[b] < bandBounds[b - 1]))
+      return fail(YCNR_ERR_INVALID, "set_ratings_banded: bandBounds must ascend within [0, %lld]", (long long)cols);
+  if (bandBounds[0] != 0 || bandBounds[nBands] != cols) return fail(YCNR_ERR_INVALID, "set_ratings_banded: the bands must tile the columns [0, %lld)", (long long)cols);
+  if (rankBands[0] != 0 || rankBands[world] != nBands || ownerBounds[0] != 0 || ownerBounds[world] != rows)
+    return fail(YCNR_ERR_INVALID, "set_ratings_banded: rankBands must tile the %d bands and ownerBounds the %lld rows over the %d rank(s)", nBands, (long long)rows, world);
+  for (int r = 0; r < world; ++r)
+    if (rankBands[r + 1] < rankBands[r] || ownerBounds[r + 1] < ownerBounds[r]) return fail(YCNR_ERR_INVALID, "set_ratings_banded: rankBands / ownerBounds must ascend");
+  HIP_TRY(hipSetDevice(h->opt.device));
+  struct Pending {
+    Part part;
+    BandedSide B;
+    bool keep = false;
+    ~Pending() {
+      if (!keep) {
+        part.release();
+        B.release();
+      }
+    }
+  } pend;
+  Part &part = pend.part;
+  BandedSide &B = pend.B;
+  int rc = YCNR_OK;
+  const size_t ts = h->ts();
+  const int bl = (int)rankBands[rank], bh = (int)rankBands[rank + 1], bpr = bh - bl;
+  std::vector<int64_t> hp;
+  std::vector<double> counts((size_t)rows * (size_t)nBands, 0.0);
+  auto build = [&]() -> int {
+    hipError_t e = part.create_events();
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&B.evRecv, hipEventDisableTiming);
+    for (int i = 0; i < kFewSlabs && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&B.evStage[i], hipEventDisableTiming);
+    if (e != hipSuccess) return fail(YCNR_ERR_HIP, "set_ratings_banded: hipEventCreate: %s", hipGetErrorString(e));
+    int r1 = upload_ratings(h, part.R, rows, cols, rowPtr, indx, vals, 0, rows, memKind, hp, "set_ratings_banded");
+    if (r1) return r1;
+    if (bpr <= 0 && part.R.nnz > 0) return fail(YCNR_ERR_INVALID, "set_ratings_banded: rank %d has no band but %lld ratings", rank, (long long)part.R.nnz);
+    if (bpr > 0)
+      if (int r2 = check_index_bounds(part.R.dIndx, part.R.nnz, bandBounds[bl], bandBounds[bh], h->stream, "set_ratings_banded")) return r2;
+    // where every row's ratings cross this rank's inner band boundaries (rows are sorted by column id)
+    const int64_t base = hp[0];
+    std::vector<int64_t> qBeg, qEnd, cuts;
+    std::vector<int32_t> qKey;
+    std::vector<int64_t> qRow;
+    for (int64_t r = 0; r < rows; ++r) {
+      if (hp[r + 1] == hp[r]) continue;
+      qRow.push_back(r);
+      for (int b = bl + 1; b < bh; ++b) {
+        qBeg.push_back(hp[r] - base);
+        qEnd.push_back(hp[r + 1] - base);
+        qKey.push_back((int32_t)bandBounds[b]);
+      }
+    }
+    if (int r3 = lower_bound_i32(part.R.dIndx, qBeg, qEnd, qKey, cuts, h->stream)) return r3;
+    for (size_t i = 0; i < qRow.size(); ++i) {
+      const int64_t r = qRow[i];
+      int64_t p = hp[r] - base;
+      for (int j = 0; j < bpr; ++j) {
+        const int64_t q = j + 1 < bpr ? cuts[i * (size_t)(bpr - 1) + j] : hp[r + 1] - base;
+        if (q < p) return fail(YCNR_ERR_INVALID, "set_ratings_banded: the column ids of row %lld are not ascending", (long long)r);
+        counts[(size_t)r * nBands + (size_t)(bl + j)] = (double)(q - p);
+        p = q;
+      }
+    }
+    return YCNR_OK;
+  };
+  rc = build();
+  // the ratings of every (row, band) on every rank: the owners skip empty bands, lambda n needs the row's total, and the chunk
+  // length follows the ratings of the WHOLE side -- collective, a rank whose upload failed takes part with what it has
+  if (world > 1) {
+    const std::string why = g_last_error;
+    const int rca = comm_allreduce_sum(h->comm, counts.data(), (int64_t)counts.size());
+    if (rc) g_last_error = why;
+    else rc = rca;
+  }
+  auto finish = [&]() -> int {
+    int64_t sideNnz = 0, sideSplitNnz = 0;
+    std::vector<int64_t> rowTotal((size_t)rows, 0);
+    for (int64_t r = 0; r < rows; ++r) {
+      int64_t t = 0;
+      for (int b = 0; b < nBands; ++b) t += (int64_t)counts[(size_t)r * nBands + b];
+      rowTotal[(size_t)r] = t;
+      sideNnz += t;
+      if (t > kDefaultChunk) sideSplitNnz += t;
+    }
+    if (h->comm.active() && h->comm.transport == YCNR_COMM_STUB) {
+      // (one rank of an emulated world: the counts of the other ranks' bands never arrive; size the chunks for a side `world`
+      // times this rank's share, as the real run would)
+      sideNnz = 0;
+      sideSplitNnz = 0;
+      for (int64_t r = 0; r < rows; ++r) {
+        const int64_t t = rowTotal[(size_t)r] * world;
+        sideNnz += t;
+        if (t > kDefaultChunk) sideSplitNnz += t;
+      }
+    }
+    const int64_t chunk = h->autoChunk ? auto_chunk(sideNnz, sideSplitNnz) : h->copt.chunkRatings;
+    B.nBands = nBands;
+    B.world = world;
+    B.rank = rank;
+    B.rankBands.assign(rankBands, rankBands + world + 1);
+    B.ownerBounds.assign(ownerBounds, ownerBounds + world + 1);
+    B.slabElems = (int64_t)slab_regs(h->copt, side) * 64;
+    B.groupSlab0.assign((size_t)world + 1, 0);
+    for (int g = 0; g < world; ++g) B.groupSlab0[(size_t)g + 1] = B.groupSlab0[(size_t)g] + (ownerBounds[g + 1] - ownerBounds[g]) * bpr;
+    B.bandSlabs = B.groupSlab0[(size_t)world];
+    // units: group by group (the order they are computed and sent in), longest first inside a group
+    const int64_t base = hp[0];
+    std::vector<Unit> units;
+    std::vector<SlabSum> sums;
+    B.groupUnit0.assign((size_t)world, 0);
+    B.groupUnits.assign((size_t)world, 0);
+    B.groupSum0.assign((size_t)world, 0);
+    B.groupSums.assign((size_t)world, 0);
+    int64_t tmp = 0;
+    for (int st = 1; st <= world; ++st) {  // in the order the groups are computed and sent: consecutive stages are contiguous
+      const int g = (rank + st) % world;
+      B.groupUnit0[(size_t)g] = (int64_t)units.size();
+      B.groupSum0[(size_t)g] = (int64_t)sums.size();
+      const size_t u0 = units.size();
+      for (int64_t r = ownerBounds[g]; r < ownerBounds[g + 1]; ++r) {
+        if (hp[r + 1] == hp[r]) continue;
+        int64_t p = hp[r] - base;
+        for (int j = 0; j < bpr; ++j) {
+          const int64_t len = (int64_t)counts[(size_t)r * nBands + (size_t)(bl + j)];
+          if (len <= 0) continue;
+          const int64_t bandSlab = B.groupSlab0[(size_t)g] + (r - ownerBounds[g]) * bpr + j;
+          const int64_t np = (len + chunk - 1) / chunk, pl = (((len + np - 1) / np) + 3) & ~(int64_t)3;
+          if (np == 1) {
+            units.push_back(Unit{p, p + len, (int32_t)r, (int32_t)bandSlab});
+          } else {
+            int64_t made = 0;
+            for (int64_t q = 0; q < np; ++q) {
+              const int64_t ub = p + q * pl, ue = std::min(p + len, ub + pl);
+              if (ue <= ub) break;
+              units.push_back(Unit{ub, ue, (int32_t)r, (int32_t)(B.bandSlabs + tmp + made)});
+              ++made;
+            }
+            sums.push_back(SlabSum{bandSlab * B.slabElems, (B.bandSlabs + tmp) * B.slabElems, (int32_t)made, 0});
+            tmp += made;
+          }
+          p += len;
+        }
+      }
+      std::stable_sort(units.begin() + (ptrdiff_t)u0, units.end(), [](const Unit &x, const Unit &y) { return (x.end - x.beg) > (y.end - y.beg); });
+      B.groupUnits[(size_t)g] = (int64_t)units.size() - B.groupUnit0[(size_t)g];
+      B.groupSums[(size_t)g] = (int64_t)sums.size() - B.groupSum0[(size_t)g];
+    }
+    B.tmpSlabs = tmp;
+    B.nSums = (int64_t)sums.size();
+    if (B.bandSlabs + B.tmpSlabs > 0x7fffffffLL) return fail(YCNR_ERR_UNSUPPORTED, "set_ratings_banded: too many slabs");
+    Schedule &S = part.S;
+    S.nUnits = (int64_t)units.size();
+    S.nSlabs = S.nUnits;
+    if (S.nUnits) {
+      HIP_TRY(hipMalloc(&S.dUnits, sizeof(Unit) * units.size()));
+      HIP_TRY(hipMemcpy(S.dUnits, units.data(), sizeof(Unit) * units.size(), hipMemcpyHostToDevice));
+    }
+    if (B.nSums) {
+      HIP_TRY(hipMalloc(&B.dSums, sizeof(SlabSum) * sums.size()));
+      HIP_TRY(hipMemcpy(B.dSums, sums.data(), sizeof(SlabSum) * sums.size(), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMalloc(&S.dSlabs, std::max<size_t>((size_t)(B.bandSlabs + B.tmpSlabs) * (size_t)B.slabElems * ts, 64)));
+    // what this rank owns: its rows' band slabs from every rank, and the rows to solve
+    const int64_t own0 = ownerBounds[rank], ownN = ownerBounds[rank + 1] - own0;
+    B.recvSlab0.assign((size_t)world + 1, 0);
+    for (int r = 0; r < world; ++r)
+      B.recvSlab0[(size_t)r + 1] = B.recvSlab0[(size_t)r] + (r == rank ? 0 : ownN * (rankBands[r + 1] - rankBands[r]));
+    B.recvSlabs = B.recvSlab0[(size_t)world];
+    HIP_TRY(hipMalloc(&B.dRecv, std::max<size_t>((size_t)B.recvSlabs * (size_t)B.slabElems * ts, 64)));
+    HIP_TRY(hipMemset(B.dRecv, 0, std::max<size_t>((size_t)B.recvSlabs * (size_t)B.slabElems * ts, 64)));
+    std::vector<const void *> table((size_t)ownN * (size_t)nBands, nullptr);
+    std::vector<SplitRow> owned;
+    const size_t slabBytes = (size_t)B.slabElems * ts;
+    for (int64_t i = 0; i < ownN; ++i) {
+      const int64_t r = own0 + i;
+      if (rowTotal[(size_t)r] <= 0) continue;
+      owned.push_back(SplitRow{rowTotal[(size_t)r], (int32_t)r, (int32_t)(i * nBands), (int32_t)nBands, 0});
+      for (int b = 0; b < nBands; ++b) {
+        if (counts[(size_t)r * nBands + b] <= 0) continue;
+        int src = 0;
+        while (src + 1 < world && b >= rankBands[src + 1]) ++src;
+        const char *p = src == rank ? (const char *)S.dSlabs + (size_t)(B.groupSlab0[(size_t)rank] + i * bpr + (b - bl)) * slabBytes
+                                    : (const char *)B.dRecv + (size_t)(B.recvSlab0[(size_t)src] + i * (rankBands[src + 1] - rankBands[src]) + (b - rankBands[src])) * slabBytes;
+        table[(size_t)i * nBands + b] = p;
+      }
+    }
+    if (owned.size() > 0x7fffffffULL / (size_t)std::max(nBands, 1)) return fail(YCNR_ERR_UNSUPPORTED, "set_ratings_banded: too many owned rows");
+    S.nSplit = (int64_t)owned.size();
+    S.solvedRows = S.nSplit;
+    S.maxRowSlabs = nBands;
+    B.ownedSolved = S.nSplit;
+    if (S.nSplit) {
+      HIP_TRY(hipMalloc(&S.dSplit, sizeof(SplitRow) * owned.size()));
+      HIP_TRY(hipMemcpy(S.dSplit, owned.data(), sizeof(SplitRow) * owned.size(), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMalloc((void **)&B.dTable, std::max<size_t>(sizeof(void *) * table.size(), 64)));
+    if (!table.empty()) HIP_TRY(hipMemcpy((void *)B.dTable, table.data(), sizeof(void *) * table.size(), hipMemcpyHostToDevice));
+    B.on = true;
+    return YCNR_OK;
+  };
+  if (!rc) rc = finish();
+  // IPC: the peers push their band slabs into dRecv -- published here, collectively (a rank that failed says so in its slot)
+  if (h->comm.active() && h->comm.transport == YCNR_COMM_IPC) {
+    const std::string why = g_last_error;
+    const int rcp = ipc_publish_extra(h->comm, side, rc ? nullptr : B.dRecv, rc != YCNR_OK);
+    if (rc) g_last_error = why;
+    else rc = rcp;
+  }
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  for (Part &p : h->parts[side]) p.release();
+  h->parts[side].clear();
+  h->banded[side].release();
+  h->drop_graphs();
+  h->parts[side].push_back(part);
+  h->banded[side] = B;
+  pend.keep = true;
+  // the solved rows travel like a sharded side's: one piece per rank (ycnr_als_exchange, the exchange behind the half-step)
+  h->bounds[side].clear();
+  for (int r = 0; r < world; ++r) {
+    h->bounds[side].push_back(ownerBounds[r]);
+    h->bounds[side].push_back(ownerBounds[r + 1]);
+  }
+  return YCNR_OK;
 }
 
 int ycnr_als_set_rmse_ratings(ycnr_als *h, int which, const int64_t *rowPtr, const int32_t *indx,
@@ -2005,16 +2328,213 @@ static void part_ranges(const ycnr_als *h, int side, int c, std::vector<int64_t>
   }
 }
 
+}  // extern "C"
+
+// bookkeeping of a half-step that has just been enqueued: what the step info reports besides the times, and its place among
+// the half-steps ycnr_als_sync will complete
+static void note_enqueued(ycnr_als *h, int side, const std::vector<Part> &parts) {
+  h->info.struct_size = (int32_t)sizeof(ycnr_als_step_info);
+  h->info.side = side;
+  h->info.parts = (int32_t)parts.size();
+  const bool dual = h->opt.dtype == YCNR_F32 && dual_max_ratings(h->copt) > 0;
+  for (const Part &p : parts) {
+    const Schedule &S = p.S;
+    h->info.rows += S.solvedRows;
+    h->info.ratings += p.R.nnz;
+    h->info.units += S.nUnits;
+    h->info.splitRows += S.nSplit;
+    h->info.fusedRows += S.solvedRows - S.nSplit;
+    h->info.fusedRatings += S.fusedRatings;
+    if (dual) {
+      h->info.dualRows += S.dualRows;
+      h->info.dualRatings += S.dualRatings;
+      h->info.dualFlops += S.dualFlops;
+      if (S.dualRows >= kMinOverlapDualRows && !is_gen(YCNR_F32, h->copt.factorsCount) && !(h->opt.flags & YCNR_FLAG_NO_OVERLAP) &&
+          !env_flags().noOverlap)
+        h->info.dualOverlapped = 1;
+    }
+  }
+  h->infoPending = true;
+  h->infoSide = side;
+  // (the same side twice without a sync: its events have been re-recorded, the earlier half-step's times are gone)
+  int np = 0;
+  for (int i = 0; i < h->nPend; ++i)
+    if (h->pendOrder[i] != side) h->pendOrder[np++] = h->pendOrder[i];
+  h->pendOrder[np++] = side;
+  h->nPend = np;
+  h->pend[side].info = h->info;
+  h->pend[side].graphRun = h->graphRun;
+  h->pend[side].exchanged = h->exchangedInStep;
+}
+
+// One half-step of a side sharded by bands of columns (ycnr_als_set_ratings_banded): owner group by owner group the chunk
+// Gramians of this rank's ratings (+ the sums of the segments that were cut into several chunks), every group's band slabs
+// sent to its owner while the next group is computed; then the owned rows' band slabs added in band order + solve, and the
+// solved rows exchanged like a sharded side's.  RCCL: everything stream-ordered.  IPC (the functional path of the one-GPU
+// tests): the pushes are completed with a host barrier before the owners reduce.
+template <typename T>
+static int step_banded_t(ycnr_als *h, int side) {
+  BandedSide &B = h->banded[side];
+  Part &part = h->parts[side][0];
+  Schedule &S = part.S;
+  Comm &c = h->comm;
+  const bool comm = c.active() && B.world > 1;
+  if (comm && (c.world != B.world || c.rank != B.rank)) return fail(YCNR_ERR_STATE, "step: the banded upload of this side was made for another communicator");
+  hipStream_t stream = h->stream;
+  const size_t ts = sizeof(T), slabBytes = (size_t)B.slabElems * ts;
+  const double lambda = side == YCNR_BY_USER ? h->copt.userFactReg : h->copt.itemFactReg;
+  if (comm && c.transport == YCNR_COMM_IPC) {
+    if (c.pendingFinish) {  // (as ycnr_als_step_async: a half-step the peers were still pushing must be complete first)
+      HIP_TRY(hipStreamSynchronize(stream));
+      if (int rcf = ipc_finish(c)) return rcf;
+    }
+    if (int rcb = ipc_enter(c)) return rcb;
+  }
+  StepArgs<T> a{S.dUnits, S.dSplit, part.R.dIndx, (const T *)part.R.dVals, (const T *)h->factors[1 - side], (const T *)h->dZeros, (T *)h->factors[side],
+                (T *)S.dSlabs, h->dErr, lambda, h->copt.factorsCount, 0, 0,
+                use_slab_x6(h->copt, side) ? (uint32_t)(h->rows(1 - side) * h->copt.factorsCount * 4) : 0u};
+  DualPlan dp;
+  dp.noX6 = (h->copt.flags & YCNR_FLAG_NO_BF16X6) != 0;
+  const bool lds = (h->copt.flags & YCNR_FLAG_LDS_SOLVER) != 0, edge = use_valu_edge(h->copt), x6 = use_slab_x6(h->copt, side);
+  HIP_TRY(hipEventRecord(part.ev[0], stream));
+  const int bpr = (int)(B.rankBands[(size_t)B.rank + 1] - B.rankBands[(size_t)B.rank]);
+  // The groups are dealt over up to four streams (the handle's two piece streams and two of its side streams): a group is an
+  // eighth of the rows -- about one round of waves -- and its longest chunk sets its kernel's length, so the kernels of several
+  // groups have to be in flight for the chip to be full (eight launches in stream order: 2.8 ms per rank and item half-step at
+  // MAL scale; over two streams 1.8; one launch over all groups, which could not signal a group's completion: 1.2).
+  int nStreams = 1;
+  hipStream_t gs[kFewSlabs] = {stream, stream, stream, stream, stream, stream, stream, stream};
+  if (B.world > 1 && !(h->opt.flags & YCNR_FLAG_NO_OVERLAP) && !env_flags().noOverlap) {
+    static const int want = getenv("YCNR_BAND_STREAMS") ? std::max(1, std::min(2 + kSideStreams, atoi(getenv("YCNR_BAND_STREAMS")))) : 4;
+    nStreams = std::min(want, B.world);
+    for (int i = 0; i < nStreams; ++i) {
+      if (i < 2) {
+        gs[i] = h->pieceStream[i];
+      } else {
+        if (!h->sideStream[i - 2]) HIP_TRY(hipStreamCreateWithFlags(&h->sideStream[i - 2], hipStreamNonBlocking));
+        gs[i] = h->sideStream[i - 2];
+      }
+    }
+    HIP_TRY(hipEventRecord(h->evStepStart, stream));
+    for (int i = 0; i < nStreams; ++i) HIP_TRY(hipStreamWaitEvent(gs[i], h->evStepStart, 0));
+  }
+  const bool twoStreams = nStreams > 1;
+  // stages per launch: consecutive stages' units (and sums) are contiguous, one launch covers `batch` of them -- enough units to
+  // fill the chip -- and their band slabs leave together when it has finished
+  static const int batchEnv = getenv("YCNR_BAND_BATCH") ? std::max(1, atoi(getenv("YCNR_BAND_BATCH"))) : 0;
+  const int batch = batchEnv ? batchEnv : 1;
+  for (int s = 1; s <= B.world; ++s) {
+    const int g = (B.rank + s) % B.world;  // the own group last: its slabs do not travel
+    const int b0 = ((s - 1) / batch) * batch + 1, b1 = std::min(B.world, b0 + batch - 1);  // the stages launched together with s
+    hipStream_t ps = gs[((s - 1) / batch) % nStreams];
+    if (s == b0) {
+      int64_t nu = 0, ns = 0;
+      const int g0 = (B.rank + b0) % B.world;
+      for (int t = b0; t <= b1; ++t) {
+        nu += B.groupUnits[(size_t)((B.rank + t) % B.world)];
+        ns += B.groupSums[(size_t)((B.rank + t) % B.world)];
+      }
+      if (nu > 0) {
+        StepArgs<T> ag = a;
+        ag.units = S.dUnits + B.groupUnit0[(size_t)g0];
+        dp.only = 1;
+        int rc = launch_step<T>(ag, nu, nu, 0, ps, nullptr, lds, dp, edge, x6);
+        if (rc) return rc;
+      }
+      if (ns > 0) {
+        hipLaunchKernelGGL(als_slab_sum_kernel<T>, dim3((unsigned)ns), dim3(256), 0, ps, (T *)S.dSlabs, (const SlabSum *)B.dSums + B.groupSum0[(size_t)g0], B.slabElems);
+        HIP_TRY(hipGetLastError());
+      }
+    }
+    HIP_TRY(hipEventRecord(B.evStage[s - 1], ps));
+    if (!comm || g == B.rank) continue;
+    const int from = (B.rank - s + B.world) % B.world;  // the rank whose stage-s group this rank is
+    const int64_t sendSlabs = (B.ownerBounds[(size_t)g + 1] - B.ownerBounds[(size_t)g]) * bpr;
+    const int64_t ownN = B.ownerBounds[(size_t)B.rank + 1] - B.ownerBounds[(size_t)B.rank];
+    const int64_t recvSlabs = ownN * (B.rankBands[(size_t)from + 1] - B.rankBands[(size_t)from]);
+    h->info.exchangeBytes += (sendSlabs + recvSlabs) * (int64_t)slabBytes;
+    if (c.transport == YCNR_COMM_STUB) continue;  // (one rank of an emulated world: the bytes are counted, nothing travels)
+    HIP_TRY(hipStreamWaitEvent(c.stream, B.evStage[s - 1], 0));
+    const char *src = (const char *)S.dSlabs + (size_t)B.groupSlab0[(size_t)g] * slabBytes;
+    if (c.transport == YCNR_COMM_RCCL) {
+      const ncclDataType_t dt = ts == 8 ? ncclDouble : ncclFloat;
+      NCCL_TRY(c.api, c.api->GroupStart());
+      if (sendSlabs > 0) NCCL_TRY(c.api, c.api->Send(src, (size_t)sendSlabs * (size_t)B.slabElems, dt, g, c.nccl, c.stream));
+      if (recvSlabs > 0)
+        NCCL_TRY(c.api, c.api->Recv((char *)B.dRecv + (size_t)B.recvSlab0[(size_t)from] * slabBytes, (size_t)recvSlabs * (size_t)B.slabElems, dt, from, c.nccl, c.stream));
+      NCCL_TRY(c.api, c.api->GroupEnd());
+    } else if (c.transport == YCNR_COMM_IPC) {
+      if (c.extra[side].size() != (size_t)c.world || (sendSlabs > 0 && !c.extra[side][(size_t)g].ptr))
+        return fail(YCNR_ERR_STATE, "ipc: the band-slab buffer of rank %d is not mapped", g);
+      // where this rank's slabs start in g's receive buffer: behind those of the ranks before it (g itself sends nothing)
+      int64_t off = 0;
+      const int64_t gRows = B.ownerBounds[(size_t)g + 1] - B.ownerBounds[(size_t)g];
+      for (int r = 0; r < B.rank; ++r)
+        if (r != g) off += gRows * (B.rankBands[(size_t)r + 1] - B.rankBands[(size_t)r]);
+      if (sendSlabs > 0)
+        HIP_TRY(hipMemcpyAsync(c.extra[side][(size_t)g].ptr + (size_t)off * slabBytes, src, (size_t)sendSlabs * slabBytes, hipMemcpyDeviceToDevice, c.stream));
+    } else {
+      return fail(YCNR_ERR_UNSUPPORTED, "step: this transport does not carry band slabs");
+    }
+  }
+  // the step's stream joins the piece streams: the last stage of each (enqueued behind every launch, as in ycnr_als_step_async)
+  if (twoStreams) {
+    const int nb = (B.world + batch - 1) / batch;  // the last launch of every stream in use
+    for (int bi = std::max(0, nb - nStreams); bi < nb; ++bi) HIP_TRY(hipStreamWaitEvent(stream, B.evStage[std::min(B.world, (bi + 1) * batch) - 1], 0));
+  }
+  for (int i = 1; i <= 3; ++i) HIP_TRY(hipEventRecord(part.ev[i], stream));  // (no row kernel, no dual classes)
+  if (comm && c.transport == YCNR_COMM_RCCL) {
+    HIP_TRY(hipEventRecord(B.evRecv, c.stream));
+    HIP_TRY(hipStreamWaitEvent(stream, B.evRecv, 0));
+  } else if (comm && c.transport == YCNR_COMM_IPC) {
+    HIP_TRY(hipStreamSynchronize(c.stream));  // this rank's pushes have landed ...
+    if (int rcb = shm_barrier(c)) return rcb;  // ... and everybody's
+  }
+  if (S.nSplit > 0) {
+    dp.only = 2;
+    dp.bandSlab = B.dTable;
+    dp.nBands = B.nBands;
+    int rc = launch_step<T>(a, 0, 0, S.nSplit, stream, nullptr, lds, dp, edge, x6);
+    if (rc) return rc;
+  }
+  HIP_TRY(hipEventRecord(part.ev[4], stream));
+  h->exchangedInStep = comm;
+  if (comm) {
+    std::vector<int64_t> xb((size_t)B.world), xe((size_t)B.world);
+    for (int r = 0; r < B.world; ++r) {
+      xb[(size_t)r] = B.ownerBounds[(size_t)r];
+      xe[(size_t)r] = B.ownerBounds[(size_t)r + 1];
+    }
+    int rc = comm_exchange(c, h->factors[side], side, h->opt.factorsCount, ts, xb.data(), xe.data(), stream, part.ready, part.x0, part.x1, &h->info.exchangeBytes);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(h->evComputeEnd, stream));
+    if (c.transport != YCNR_COMM_SHM) HIP_TRY(hipStreamWaitEvent(stream, part.x1, 0));
+  }
+  HIP_TRY(hipMemcpyAsync(h->hErr, h->dErr, sizeof(ErrInfo), hipMemcpyDeviceToHost, stream));
+  return YCNR_OK;
+}
+
+extern "C" {
+
 int ycnr_als_step_async(ycnr_als *h, int side) {
   if (!h) return fail(YCNR_ERR_INVALID, "null handle");
   if (side != YCNR_BY_USER && side != YCNR_BY_ITEM) return fail(YCNR_ERR_INVALID, "bad side %d", side);
   std::vector<Part> &parts = h->parts[side];
   if (parts.empty()) return fail(YCNR_ERR_STATE, "step: set_ratings was not called for this side");
   HIP_TRY(hipSetDevice(h->opt.device));
+  if (h->banded[side].on) {
+    memset(&h->info, 0, sizeof h->info);
+    h->graphRun = false;
+    h->planesValid[1 - side] = false;
+    const int rcb = h->opt.dtype == YCNR_F64 ? step_banded_t<double>(h, side) : step_banded_t<float>(h, side);
+    if (rcb) return rcb;
+    note_enqueued(h, side, parts);
+    return YCNR_OK;
+  }
   // With a communicator and a sharded upload the half-step includes its exchange: the rows of piece
   // c travel (on the communicator's stream) while piece c + 1 is being solved, and the step's
   // stream waits for the last piece to land -- the next half-step reads the whole matrix.
-  const bool exchange = h->comm.active() && !h->bounds[side].empty();
+  const bool exchange = h->comm.active() && !h->bounds[side].empty() && !h->deferExchange[side];
   if (exchange && h->bounds[side].size() != (size_t)h->comm.world * (parts.size() + 1))
     return fail(YCNR_ERR_STATE, "step: the sharded upload of this side was made for another communicator (bounds of %zu values, world %d x %zu pieces)",
                 h->bounds[side].size(), h->comm.world, parts.size());
@@ -2141,38 +2661,7 @@ int ycnr_als_step_async(ycnr_als *h, int side) {
     if (h->comm.transport != YCNR_COMM_SHM) HIP_TRY(hipStreamWaitEvent(h->stream, parts.back().x1, 0));  // (SHM is synchronous)
   }
   if (!h->graphRun) HIP_TRY(hipMemcpyAsync(h->hErr, h->dErr, sizeof(ErrInfo), hipMemcpyDeviceToHost, h->stream));
-  h->info.struct_size = (int32_t)sizeof(ycnr_als_step_info);
-  h->info.side = side;
-  h->info.parts = (int32_t)parts.size();
-  const bool dual = h->opt.dtype == YCNR_F32 && dual_max_ratings(h->copt) > 0;
-  for (const Part &p : parts) {
-    const Schedule &S = p.S;
-    h->info.rows += S.solvedRows;
-    h->info.ratings += p.R.nnz;
-    h->info.units += S.nUnits;
-    h->info.splitRows += S.nSplit;
-    h->info.fusedRows += S.solvedRows - S.nSplit;
-    h->info.fusedRatings += S.fusedRatings;
-    if (dual) {
-      h->info.dualRows += S.dualRows;
-      h->info.dualRatings += S.dualRatings;
-      h->info.dualFlops += S.dualFlops;
-      if (S.dualRows >= kMinOverlapDualRows && !is_gen(YCNR_F32, h->copt.factorsCount) && !(h->opt.flags & YCNR_FLAG_NO_OVERLAP) &&
-          !env_flags().noOverlap)
-        h->info.dualOverlapped = 1;
-    }
-  }
-  h->infoPending = true;
-  h->infoSide = side;
-  // (the same side twice without a sync: its events have been re-recorded, the earlier half-step's times are gone)
-  int np = 0;
-  for (int i = 0; i < h->nPend; ++i)
-    if (h->pendOrder[i] != side) h->pendOrder[np++] = h->pendOrder[i];
-  h->pendOrder[np++] = side;
-  h->nPend = np;
-  h->pend[side].info = h->info;
-  h->pend[side].graphRun = h->graphRun;
-  h->pend[side].exchanged = h->exchangedInStep;
+  note_enqueued(h, side, parts);
   return YCNR_OK;
 }
 
@@ -2427,6 +2916,13 @@ int ycnr_als_comm_destroy(ycnr_als *h) {
   // exchange ranges belong to the communicator they were made for: a later ycnr_als_set_ratings[_sharded] renews them
   h->bounds[0].clear();
   h->bounds[1].clear();
+  return YCNR_OK;
+}
+
+int ycnr_als_defer_exchange(ycnr_als *h, int side, int deferred) {
+  if (!h) return fail(YCNR_ERR_INVALID, "null handle");
+  if (side != 0 && side != 1) return fail(YCNR_ERR_INVALID, "bad side %d", side);
+  h->deferExchange[side] = deferred != 0;
   return YCNR_OK;
 }
 

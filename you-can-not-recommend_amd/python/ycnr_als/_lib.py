@@ -51,7 +51,7 @@ EXPORTS = [
     "ycnr_recommend_items",
     "ycnr_comm_unique_id", "ycnr_als_comm_init", "ycnr_als_comm_destroy", "ycnr_als_set_ratings_sharded",
     "ycnr_als_exchange", "ycnr_als_broadcast_factors", "ycnr_als_allreduce_sum", "ycnr_als_comm_selftest",
-    "ycnr_als_comm_info", "ycnr_als_last_rmse_ms",
+    "ycnr_als_comm_info", "ycnr_als_last_rmse_ms", "ycnr_als_set_ratings_banded", "ycnr_als_defer_exchange",
 ]
 COMM_NONE, COMM_RCCL, COMM_SHM, COMM_IPC, COMM_STUB = 0, 1, 2, 3, 4
 COMM_ID_BYTES = 128
@@ -171,6 +171,10 @@ def load():
     L.ycnr_als_comm_destroy.argtypes = [vp]
     L.ycnr_als_set_ratings_sharded.restype = i32
     L.ycnr_als_set_ratings_sharded.argtypes = [vp, i32, vp, vp, vp, i32, i32, i32, vp]
+    L.ycnr_als_set_ratings_banded.restype = i32
+    L.ycnr_als_set_ratings_banded.argtypes = [vp, i32, vp, vp, vp, i32, i32, vp, vp, vp]
+    L.ycnr_als_defer_exchange.restype = i32
+    L.ycnr_als_defer_exchange.argtypes = [vp, i32, i32]
     L.ycnr_als_exchange.restype = i32
     L.ycnr_als_exchange.argtypes = [vp, i32]
     L.ycnr_als_broadcast_factors.restype = i32

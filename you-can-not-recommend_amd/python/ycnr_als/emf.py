@@ -58,6 +58,13 @@ def default_options():
         # model (row_cost), this is the feedback that corrects it -- the role of the reference's work-stealing
         # portion dispenser (EmfLord.m_incrNextPortion, lib/emf/EmfLord.js:996-1006)
         "rebalanceAfterIters": 2,  # a re-cut after each of the first N iterations
+        # multi-GPU only: how the ITEM half-step is sharded.  "rows": every rank solves a range of items against the whole user
+        # matrix, which is therefore all-gathered after every user half-step (700 MB at MAL scale).  "bands": the users are cut
+        # into 8 cost-balanced bands (the same for every world size), a rank holds its bands' users, accumulates the Gramians of
+        # ALL items over its own users' ratings and the per-band sums travel to the items' owners (ycnr_als_set_ratings_banded):
+        # the user matrix is never all-gathered, the order of every sum is fixed by the bands, 1 / 2 / 4 / 8 ranks give the same
+        # bits.  Needs world in {1, 2, 4, 8} and a backend with set_ratings_banded; the shards are not re-cut in this mode.
+        "itemStepSharding": "rows",
     }
 
 
@@ -288,6 +295,20 @@ class HipBackend:
         else:
             self.dev.set_ratings(side, c.rowPtr, c.indx, c.vals, rb, re)
 
+    def set_ratings_banded(self, side, csr, band_bounds, rank_bands, owner_bounds):
+        c = self._vals(csr)
+        self.dev.set_ratings_banded(side, c.rowPtr, c.indx, c.vals, band_bounds, rank_bands, owner_bounds)
+
+    def set_ratings_deferred(self, side, csr, bounds):
+        """sharded upload whose half-steps leave the solved rows where they are until exchange(side)"""
+        c = self._vals(csr)
+        self.dev.set_ratings_sharded(side, c.rowPtr, c.indx, c.vals, bounds)
+        self.dev.defer_exchange(side, True)
+
+    def exchange(self, side):
+        self.torch.cuda.synchronize(self.device)
+        self.dev.exchange(side)
+
     def set_rmse_ratings(self, which, csr, rb, re):
         c = self._vals(csr)
         self.dev.set_rmse_ratings(which, c.rowPtr, c.indx, c.vals, rb, re)
@@ -368,6 +389,15 @@ class EmfLord:
         k, dbl = self.factorsCount, self.options["useDoublePrecision"]
         # shards: {side: int64[world + 1]} overrides the cost-model cut (bench.py --emulate-world replays measured cuts)
         self.shards = shards or {0: shard_ranges(cu, self.world, k, dbl), 1: shard_ranges(ci, self.world, k, dbl)}
+        # the item half-step sharded by user bands: 8 cost-balanced bands of users whatever the world size; rank r holds
+        # 8 / world consecutive bands = its user shard
+        self.bands = None
+        if self.options.get("itemStepSharding", "rows") == "bands":
+            if self.world not in (1, 2, 4, 8):
+                raise ValueError("itemStepSharding='bands' needs 1, 2, 4 or 8 ranks (8 user bands), got %d" % self.world)
+            self.bands = shard_ranges(cu, 8, k, dbl)
+            self.rankBands = np.arange(self.world + 1, dtype=np.int64) * (8 // self.world)
+            self.shards = {0: self.bands[self.rankBands], 1: self.shards[1]}
         self._itersRun, self.rebalanced = 0, None
         self.backend = self._backend_factory(self.options, self.totalUsersCount, self.totalItemsCount, device)
         ub, ue = self.shards[0][self.rank], self.shards[0][self.rank + 1]
@@ -403,6 +433,10 @@ class EmfLord:
                 self.native_exchange = False
         self.exchangePath = ("libycnr_als:" + self.options.get("commTransport", "rccl")) if self.native_exchange else \
             ("torch.distributed" if self.world > 1 else "none")
+        if self.bands is not None and not hasattr(self.backend, "set_ratings_banded"):
+            raise RuntimeError("itemStepSharding='bands' needs a backend with set_ratings_banded (the HIP backend)")
+        if self.bands is not None and self.world > 1 and not self.native_exchange:
+            raise RuntimeError("itemStepSharding='bands' needs the library's own exchange (commTransport rccl or ipc)")
         self._upload_shards((0, 1))
         self.trainRatingsCount = int(cu.sum())
         # portions of the RMSE passes (EmfLord.js:523-598); kept as exclusive 0-based row ends
@@ -491,6 +525,19 @@ class EmfLord:
         cnts = {0: self.ratingsCntPerUser, 1: self.ratingsCntPerItem}
         csrs = {0: ds.train_by_user, 1: ds.train_by_item}
         rows = {0: self.totalUsersCount, 1: self.totalItemsCount}
+        if self.bands is not None:
+            b0 = self.shards[0]
+            if 0 in sides:
+                # the users as plain row shards whose half-steps exchange nothing: nobody reads a user row outside its band
+                # until the training ends (finishExchange)
+                if self.world > 1:
+                    self.backend.set_ratings_deferred(0, csrs[0], np.stack([b0[r:r + 2] for r in range(self.world)]))
+                else:
+                    self.backend.set_ratings(0, csrs[0], 0, rows[0])
+            if 1 in sides:
+                lo, hi = int(b0[self.rank]), int(b0[self.rank + 1])
+                self.backend.set_ratings_banded(1, _columns_between(csrs[1], lo, hi), self.bands, self.rankBands, self.shards[1])
+            return
         if self.native_exchange:
             s = 8 if dbl else 4
             self.pieceBounds = getattr(self, "pieceBounds", {})
@@ -517,9 +564,17 @@ class EmfLord:
         self._dist.all_reduce(t)
         return t.cpu().numpy()
 
+    def finishExchange(self):
+        """itemStepSharding='bands': bring every rank's copy of the USER matrix up to date (the half-steps never all-gather it).
+        Collective; a no-op in the other modes."""
+        if self.bands is not None and self.world > 1:
+            self.backend.exchange(0)
+
     def rebalance(self):
         """Cut both sides' row shards again from the compute time every rank measured in the last iteration
         (rebalanced_ranges) and upload the ratings for the new cuts.  Collective.  Returns {side: new bounds}."""
+        if self.bands is not None:
+            return {}  # (the bands are the shards: fixed for every world size)
         last = {}
         for st in self.stepTimes[::-1]:
             if st["stepType"] not in last:
@@ -573,9 +628,12 @@ class EmfLord:
             self.trainIter += 1
             # the reference's open todo "saveCalcResults every iter!" (lib/YcnrController.js:288): a
             # checkpoint a later prepareToTrain(warmStart) can resume from; calcCnt counts finished trains
-            if self.options.get("saveCalcResultsEveryIter", False) and self.rank == 0 and self.trainIter < self.options["trainIters"]:
-                self.saveCalcResults(self.getCalcInfo())
+            if self.options.get("saveCalcResultsEveryIter", False) and self.trainIter < self.options["trainIters"]:
+                self.finishExchange()
+                if self.rank == 0:
+                    self.saveCalcResults(self.getCalcInfo())
         self.calcCnt += 1
+        self.finishExchange()
         if self.rank == 0:
             self.saveCalcResults(self.getCalcInfo())
         self._status = "ready"
@@ -727,6 +785,18 @@ class EmfLord:
 
 def _to_np(x):
     return x if isinstance(x, np.ndarray) else x.cpu().numpy()
+
+
+def _columns_between(csr, lo, hi):
+    """The ratings of a Csr (numpy or torch) whose column id lies in [lo, hi): same shape, fewer ratings."""
+    if isinstance(csr.indx, np.ndarray):
+        mask = (csr.indx >= lo) & (csr.indx < hi)
+        rows_of = np.repeat(np.arange(csr.rows), np.diff(csr.rowPtr))
+        rp = np.zeros(csr.rows + 1, np.int64)
+        rp[1:] = np.cumsum(np.bincount(rows_of[mask], minlength=csr.rows))
+        return Csr(csr.rows, csr.cols, rp, np.ascontiguousarray(csr.indx[mask]), np.ascontiguousarray(csr.vals[mask]))
+    from .data import select_csr
+    return select_csr(csr, (csr.indx >= lo) & (csr.indx < hi))
 
 
 def _torch():

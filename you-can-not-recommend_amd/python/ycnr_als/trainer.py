@@ -226,6 +226,19 @@ class AlsDevice:
             raise ValueError("rowPtr, indx and vals must live in the same kind of memory")
         check(self._L.ycnr_als_set_ratings_sharded(self._h, SIDES[side], p0, p1, p2, k0, b.shape[1] - 1, b.shape[0], b.ctypes.data))
 
+    def set_ratings_banded(self, side, rowPtr, indx, vals, bandBounds, rankBands, ownerBounds):
+        """The side's half-step sharded by bands of COLUMNS (ycnr_als_set_ratings_banded): rowPtr / indx / vals hold every row of
+        the side with only the ratings whose column lies in this rank's bands."""
+        bb = np.ascontiguousarray(bandBounds, np.int64)
+        rb = np.ascontiguousarray(rankBands, np.int64)
+        ob = np.ascontiguousarray(ownerBounds, np.int64)
+        p0, k0 = _ptr_kind(rowPtr, np.int64)
+        p1, k1 = _ptr_kind(indx, np.int32)
+        p2, k2 = _ptr_kind(vals, self.dtype)
+        if not (k0 == k1 == k2):
+            raise ValueError("rowPtr, indx and vals must live in the same kind of memory")
+        check(self._L.ycnr_als_set_ratings_banded(self._h, SIDES[side], p0, p1, p2, k0, len(bb) - 1, bb.ctypes.data, rb.ctypes.data, ob.ctypes.data))
+
     # -- multi-GPU exchange -----------------------------------------------------------
     @staticmethod
     def comm_unique_id(transport="rccl"):
@@ -245,6 +258,9 @@ class AlsDevice:
 
     def exchange(self, side):
         check(self._L.ycnr_als_exchange(self._h, SIDES[side]))
+
+    def defer_exchange(self, side, deferred=True):
+        check(self._L.ycnr_als_defer_exchange(self._h, SIDES[side], 1 if deferred else 0))
 
     def broadcast_factors(self, side, root=0):
         check(self._L.ycnr_als_broadcast_factors(self._h, SIDES[side], int(root)))
