@@ -11,7 +11,7 @@ const input = JSON.parse(fs.readFileSync(process.argv[2], 'utf8'));
 const lord = Emf.createLord();
 lord.init({}, { factorsCount: input.k, trainIters: input.iters, dataDir: input.dir, dbType: 'ml', useDoublePrecision: input.useDoublePrecision,
   ratingsInPortionForRmse: input.rip, numThreadsForTrain: { als: input.threads }, gpus: input.world, commTransport: input.transport || 'shm',
-  exchangeChunks: 3 });
+  exchangeChunks: 3, itemStepSharding: input.sharding || 'rows' });
 const spec = { inline: { users: input.users, items: input.items, user: input.user, item: input.item, rating: input.rating, type: input.type } };
 const { Dataset } = require(path.join(root, 'lib', 'Dataset'));
 const F = input.useDoublePrecision ? Float64Array : Float32Array;

@@ -151,17 +151,20 @@ def test_js_train_matches_python_host(tmp_path, double):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("double,transport", [(False, "shm"), (True, "shm"), (False, "ipc")])
-def test_js_train_on_per_gpu_processes(tmp_path, double, transport):
+@pytest.mark.parametrize("double,transport,sharding", [(False, "shm", "rows"), (True, "shm", "rows"), (False, "ipc", "rows"), (False, "ipc", "bands"), (True, "ipc", "bands")])
+def test_js_train_on_per_gpu_processes(tmp_path, double, transport, sharding):
     """The NodeJS Lord forks 2 and 3 per-GPU processes (here sharing cuda:0: the host-staged stand-in 'shm' and the
     device-to-device transport 'ipc'): sharded upload, pipelined pieces, exchange, all-reduce and the re-cut of the
-    shards after the first iteration through the addon.  Result files and RMSE history must equal the single-process run's."""
+    shards after the first iteration through the addon.  Result files and RMSE history must equal the single-process run's.
+    sharding = 'bands': options.itemStepSharding -- the users in 8 bands, the items' Gramians reduce-scattered, the user matrix exchanged
+    once at the end (setRatingsBanded / deferExchange of the addon); 1, 2 and 4 processes."""
     dt = np.float64 if double else np.float32
     bu, user, typ, U, V = problem(seed=9, users=120, items=70)
     res = {}
-    for world in (1, 2, 3):
+    worlds = (1, 2, 4) if sharding == "bands" else (1, 2, 3)
+    for world in worlds:
         d = tmp_path / f"w{world}"
-        inp = {"dir": str(d), "k": 12, "iters": 3, "rip": 40, "threads": 2, "useDoublePrecision": double, "world": world, "transport": transport,
+        inp = {"dir": str(d), "k": 12, "iters": 3, "rip": 40, "threads": 2, "useDoublePrecision": double, "world": world, "transport": transport, "sharding": sharding,
                "users": bu.rows, "items": bu.cols, "user": user.tolist(), "item": bu.indx.tolist(),
                "rating": bu.vals.astype(dt).tolist(), "type": typ.tolist()}
         (tmp_path / f"in{world}.json").write_text(json.dumps(inp))
@@ -169,7 +172,7 @@ def test_js_train_on_per_gpu_processes(tmp_path, double, transport):
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         res[world] = json.loads(r.stdout.strip().splitlines()[-1])
-    for world in (2, 3):
+    for world in worlds[1:]:
         for name in ("user_factors", "item_factors"):
             a = np.fromfile(tmp_path / "w1" / "ml_factors_ready" / name, dt)
             b = np.fromfile(tmp_path / f"w{world}" / "ml_factors_ready" / name, dt)

@@ -458,6 +458,45 @@ napi_value SetRatingsSharded(napi_env env, napi_callback_info info) {
   return nullptr;
 }
 
+// setRatingsBanded(handle, side, rowPtr, indx, vals, bandBounds: Float64Array(nBands + 1), rankBands: Float64Array(world + 1),
+//                  ownerBounds: Float64Array(world + 1)): the side's half-step sharded by bands of columns (ycnr_als_set_ratings_banded)
+napi_value SetRatingsBanded(napi_env env, napi_callback_info info) {
+  size_t argc = 8;
+  napi_value a[8];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, a, nullptr, nullptr));
+  if (argc < 8) return throw_msg(env, "setRatingsBanded(handle, side, rowPtr, indx, vals, bandBounds, rankBands, ownerBounds)");
+  Handle *hd = handle_of(env, a[0]);
+  int64_t side;
+  if (!hd || !get_int(env, a[1], &side) || (side != 0 && side != 1)) return throw_msg(env, "bad handle or side");
+  View rp = view_of(env, a[2]), indx = view_of(env, a[3]), vals = view_of(env, a[4]), bb = view_of(env, a[5]), rb = view_of(env, a[6]), ob = view_of(env, a[7]);
+  const napi_typedarray_type ft = hd->dtype == YCNR_F64 ? napi_float64_array : napi_float32_array;
+  if (!rp.ok || !indx.ok || !vals.ok || !bb.ok || !rb.ok || !ob.ok || indx.type != napi_int32_array || vals.type != ft) return throw_msg(env, "invalid type!");
+  std::vector<int64_t> rowPtr, bandBounds, rankBands, ownerBounds;
+  if (!to_i64(rp, rowPtr) || rowPtr.empty() || !to_i64(bb, bandBounds) || !to_i64(rb, rankBands) || !to_i64(ob, ownerBounds)) return throw_msg(env, "invalid type!");
+  if ((int64_t)rowPtr.size() != hd->rows[side] + 1) return throw_msg(env, "rowPtr must have rows + 1 entries");
+  if (bandBounds.size() < 2 || rankBands.size() < 2 || rankBands.size() != ownerBounds.size()) return throw_msg(env, "bandBounds: nBands + 1 ids; rankBands, ownerBounds: world + 1 each");
+  if (rowPtr.back() < 0 || (size_t)rowPtr.back() > indx.length || (size_t)rowPtr.back() > vals.length)
+    return throw_msg(env, "indx / vals shorter than rowPtr says");
+  // (the library checks rankBands / ownerBounds against its communicator's world: it reads world + 1 entries of each)
+  int rc = ycnr_als_set_ratings_banded(hd->h, (int)side, rowPtr.data(), static_cast<const int32_t *>(indx.data), vals.data, YCNR_MEM_HOST,
+                                       (int)bandBounds.size() - 1, bandBounds.data(), rankBands.data(), ownerBounds.data());
+  if (rc) return throw_last(env, "setRatingsBanded", rc);
+  return nullptr;
+}
+
+// deferExchange(handle, side, deferred): ycnr_als_defer_exchange
+napi_value DeferExchange(napi_env env, napi_callback_info info) {
+  size_t argc = 3;
+  napi_value a[3];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, a, nullptr, nullptr));
+  Handle *hd = argc >= 3 ? handle_of(env, a[0]) : nullptr;
+  int64_t side, on;
+  if (!hd || !get_int(env, a[1], &side) || !get_int(env, a[2], &on)) return throw_msg(env, "deferExchange(handle, side, deferred)");
+  int rc = ycnr_als_defer_exchange(hd->h, (int)side, (int)on);
+  if (rc) return throw_last(env, "deferExchange", rc);
+  return nullptr;
+}
+
 // allreduceSum(handle, Float64Array) -> the same array, summed over the ranks in place
 napi_value AllreduceSum(napi_env env, napi_callback_info info) {
   size_t argc = 2;
@@ -678,6 +717,8 @@ napi_value Init(napi_env env, napi_value exports) {
       {"commUniqueId", nullptr, CommUniqueId, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
       {"commInit", nullptr, CommInit, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
       {"setRatingsSharded", nullptr, SetRatingsSharded, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+      {"setRatingsBanded", nullptr, SetRatingsBanded, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+      {"deferExchange", nullptr, DeferExchange, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
       {"allreduceSum", nullptr, AllreduceSum, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
       {"broadcastFactors", nullptr, CommSide<true>, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
       {"exchange", nullptr, CommSide<false>, nullptr, nullptr, nullptr, napi_enumerable, nullptr},

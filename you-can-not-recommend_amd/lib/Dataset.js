@@ -43,6 +43,21 @@ class Csr {
     return new Csr(this.rows, this.cols, rowPtr, indx, vals);
   }
 
+  /** The ratings whose column id lies in [lo, hi): same shape, fewer ratings (the item side of a rank that holds the users [lo, hi)). */
+  columnsBetween(lo, hi) {
+    let n = 0;
+    for (let p = 0; p < this.nnz; p++) if (this.indx[p] >= lo && this.indx[p] < hi) n++;
+    const rowPtr = new Float64Array(this.rows + 1), indx = new Int32Array(n), vals = new this.vals.constructor(n);
+    let m = 0;
+    for (let r = 0; r < this.rows; r++) {
+      for (let p = this.rowPtr[r]; p < this.rowPtr[r + 1]; p++) {
+        if (this.indx[p] >= lo && this.indx[p] < hi) { indx[m] = this.indx[p]; vals[m] = this.vals[p]; m++; }
+      }
+      rowPtr[r + 1] = m;
+    }
+    return new Csr(this.rows, this.cols, rowPtr, indx, vals);
+  }
+
   /**
    * Rows [rowBegin, rowEnd) in the reference's portion-buffer format (alsRows / alsIndx / alsVals, lib/emf/EmfMaster.js:589-609),
    * rows without ratings omitted.  dropLast: the row table the reference's packer writes for these ratings, bug for bug (the

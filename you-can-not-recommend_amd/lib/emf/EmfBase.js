@@ -74,6 +74,11 @@ class EmfBase extends EventEmitter {
       commTransport: 'rccl', // 'rccl' | 'ipc' (mapped peer replicas + copy engines; also several ranks on one GPU) | 'shm' (host-staged stand-in)
       exchangeChunks: 4,
       rebalanceAfterIters: 2,   // multi-GPU: cut the row shards again from the measured compute times after each of the first N iterations (0 = never)
+      // multi-GPU: 'rows' = items over the ranks, the user matrix all-gathered after every user half-step; 'bands' = the users in 8
+      // cost-balanced bands (the same for every world size), every rank accumulates the Gramians of ALL items over its own users'
+      // ratings, the per-band sums travel to the items' owners, the user matrix is never all-gathered (ycnr_als_set_ratings_banded;
+      // world 1, 2, 4 or 8, transports rccl / ipc; the shards are not re-cut in this mode)
+      itemStepSharding: 'rows',
       gpuDevices: 0,            // devices the per-GPU processes are spread over (0 = what the library reports)
       gpuProcessScript: null,   // entry point of a per-GPU process (default lib/emf/EmfGpuProcess.js)
       gpuProcessTimeoutMs: 0,   // trainOnGpus gives up after this long (0 = no limit)

@@ -149,14 +149,17 @@ class EmfLord extends EmfMaster {
             this.trainIter++;
             // the reference's open todo "saveCalcResults every iter!" (lib/YcnrController.js:288): a
             // checkpoint the next train() warm-starts from (_loadSharedFactorsForTrain)
-            if (this.options.saveCalcResultsEveryIter && this.trainIter < this.options.trainIters && this.options.rank == 0)
-              return Promise.resolve(this.saveCalcResults(this.getCalcInfo())).then(loop);
+            if (this.options.saveCalcResultsEveryIter && this.trainIter < this.options.trainIters) {
+              this.finishExchange();  // (itemStepSharding 'bands': the user matrix is brought up to date only where it is read whole)
+              if (this.options.rank == 0) return Promise.resolve(this.saveCalcResults(this.getCalcInfo())).then(loop);
+            }
             return loop();
           });
       };
       return loop();
     }).then(() => {
       this.calcCnt++;
+      this.finishExchange();
       if (this.options.rank != 0) return Promise.resolve();  // one writer of the result files
       return this.saveCalcResults(this.getCalcInfo());
     }).then(() => {

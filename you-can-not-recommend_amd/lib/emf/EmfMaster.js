@@ -128,9 +128,15 @@ class EmfMaster extends EmfManager {
    * Cut both sides' shards again from the compute time every rank measured in its last half-steps and upload
    * the ratings for the new cuts.  Collective (every per-GPU process calls it after the same iteration).
    */
+  /** itemStepSharding 'bands': bring every replica of the USER matrix up to date (the half-steps never all-gather it). Collective. */
+  finishExchange() {
+    if (this.bands && this.options.world > 1) als.native.exchange(this.handle, als.BY_USER);
+  }
+
   rebalance() {
     const n = als.native, o = this.options, ds = this.dataset;
     const out = {};
+    if (this.bands) return out;  // (the bands are the shards: fixed for every world size)
     for (const [name, side, csr, rows] of [['byUser', als.BY_USER, ds.trainByUser, this.totalUsersCount],
       ['byItem', als.BY_ITEM, ds.trainByItem, this.totalItemsCount]]) {
       const info = this.lastStepInfoBySide[name];
@@ -151,6 +157,36 @@ class EmfMaster extends EmfManager {
     return out;
   }
 
+  /**
+   * itemStepSharding 'bands' (any world of 1, 2, 4, 8): the users in 8 cost-balanced bands, rank r holding 8 / world of them; the user
+   * side as row shards whose half-steps exchange nothing, the item side through ycnr_als_set_ratings_banded.
+   */
+  _uploadBanded() {
+    const ds = this.dataset, n = als.native, o = this.options, k = this.factorsCount, dbl = o.useDoublePrecision;
+    if (![1, 2, 4, 8].includes(o.world)) throw new Error("itemStepSharding 'bands' needs 1, 2, 4 or 8 GPUs (8 user bands)");
+    const bands = EmfMaster.shardRanges(ds.trainByUser.rowPtr, 0, this.totalUsersCount, 8, k, dbl);
+    const rankBands = [], su = [];
+    for (let r = 0; r <= o.world; r++) { rankBands.push(r * (8 / o.world)); su.push(bands[r * (8 / o.world)]); }
+    const owners = EmfMaster.shardRanges(ds.trainByItem.rowPtr, 0, this.totalItemsCount, o.world, k, dbl);
+    this.shards = {};
+    this.shards[als.BY_USER] = su;
+    this.shards[als.BY_ITEM] = owners;
+    this.bands = bands;
+    if (o.world > 1) {
+      // nobody reads a user row outside its band until finishExchange()
+      const ub = new Float64Array(o.world * 2);
+      for (let r = 0; r < o.world; r++) { ub[2 * r] = su[r]; ub[2 * r + 1] = su[r + 1]; }
+      n.setRatingsSharded(this.handle, als.BY_USER, ds.trainByUser.rowPtr, ds.trainByUser.indx, ds.trainByUser.vals, 1, ub);
+      n.deferExchange(this.handle, als.BY_USER, 1);
+    } else {
+      n.setRatings(this.handle, als.BY_USER, ds.trainByUser.rowPtr, ds.trainByUser.indx, ds.trainByUser.vals);
+    }
+    // the items: every row, only this rank's users' ratings
+    const sub = o.world > 1 ? ds.trainByItem.columnsBetween(su[o.rank], su[o.rank + 1]) : ds.trainByItem;
+    n.setRatingsBanded(this.handle, als.BY_ITEM, sub.rowPtr, sub.indx, sub.vals, Float64Array.from(bands), Float64Array.from(rankBands), Float64Array.from(owners));
+    this.shardUsers = [su[o.rank], su[o.rank + 1]];
+  }
+
   /** Upload the ratings once: replaces createWorkPortionBuffers + per-portion fetches (EmfMaster.js:156-234,501-614) */
   prepareWorkersToTrain() {
     const n = als.native, o = this.options;
@@ -161,7 +197,10 @@ class EmfMaster extends EmfManager {
     }
     const ds = this.dataset;
     this.shardUsers = [0, this.totalUsersCount];
-    if (o.world > 1) {
+    if (o.itemStepSharding == 'bands') {
+      if (o.world > 1) n.commInit(this.handle, als.commTransport[o.commTransport], Uint8Array.from(Buffer.from(o.commId, 'base64')), o.rank, o.world);
+      this._uploadBanded();
+    } else if (o.world > 1) {
       // one process per GPU: this rank's place in the exchange, then the sharded upload of both sides
       n.commInit(this.handle, als.commTransport[o.commTransport], Uint8Array.from(Buffer.from(o.commId, 'base64')), o.rank, o.world);
       const k = this.factorsCount, dbl = o.useDoublePrecision;
