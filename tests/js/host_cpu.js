@@ -12,7 +12,8 @@ const { Dataset, rng } = require(path.join(root, 'lib', 'Dataset'));
 const n = als.native;
 for (const f of ['sAlsCalcPortion', 'dAlsCalcPortion', 'sRmsePortion', 'dRmsePortion', 'create', 'destroy', 'setRatings',
   'setRmseRatings', 'setFactors', 'getFactors', 'step', 'rmse', 'deviceCount', 'lastError', 'version',
-  'alsUnpinFixedFactors', 'commUniqueId', 'commInit', 'setRatingsSharded', 'allreduceSum', 'broadcastFactors', 'exchange'])
+  'alsUnpinFixedFactors', 'commUniqueId', 'commInit', 'setRatingsSharded', 'allreduceSum', 'broadcastFactors', 'exchange',
+  'setRatingsBanded', 'deferExchange', 'commInfo', 'lastRmseMs'])
   assert.strictEqual(typeof n[f], 'function', f);
 assert.strictEqual(n.version(), 4);
 // the communicator id of the shared-memory stand-in needs no GPU: 128 bytes, not all zero, new every time

@@ -205,6 +205,25 @@ def test_reference_packer_quirk_is_an_opt_in_flag(oracle, tmp_path):
     assert not np.array_equal(plain.backend.get_factors(0), a.backend.get_factors(0))  # the flag is not a no-op
 
 
+def test_item_sharding_by_user_bands_is_refused_where_it_cannot_run():
+    """options.itemStepSharding = 'bands' (DESIGN.md 6): 8 user bands, so 1 / 2 / 4 / 8 ranks only, and only on a backend that has
+    the banded half-step (the HIP library) -- never a silent fall back to row shards."""
+    ds, U, V = small_dataset()
+    lord = EmfLord(options={"factorsCount": 8, "itemStepSharding": "bands"}, backend_factory=oracle_factory)
+    with pytest.raises(RuntimeError, match="set_ratings_banded"):
+        lord.prepareToTrain(ds, U, V)
+
+    class ThreeRanks:
+        def get_rank(self):
+            return 0
+
+        def get_world_size(self):
+            return 3
+    with pytest.raises(ValueError, match="1, 2, 4 or 8"):
+        EmfLord(options={"factorsCount": 8, "itemStepSharding": "bands"}, backend_factory=oracle_factory, dist=ThreeRanks()).prepareToTrain(ds, U, V)
+    assert default_options()["itemStepSharding"] == "rows"
+
+
 def test_first_factor_as_average_rating():
     """als.initFirstFactorAsAvgRating (EmfBase.js:74, :493-511): rows drawn at prepareToTrain get
     their average train rating as first factor; rows without ratings keep the random draw."""

@@ -484,6 +484,38 @@ napi_value SetRatingsBanded(napi_env env, napi_callback_info info) {
   return nullptr;
 }
 
+// commInfo(handle) -> {transport, rank, world, rcclRanks}: ycnr_als_comm_info (rcclRanks: what ncclCommCount says, -1 off RCCL)
+napi_value CommInfo(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value a[1];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, a, nullptr, nullptr));
+  Handle *hd = argc >= 1 ? handle_of(env, a[0]) : nullptr;
+  if (!hd) return throw_msg(env, "commInfo(handle)");
+  int32_t v[4] = {0, 0, 1, -1};
+  int rc = ycnr_als_comm_info(hd->h, v);
+  if (rc) return throw_last(env, "commInfo", rc);
+  napi_value o;
+  NAPI_OK(napi_create_object(env, &o));
+  set_num(env, o, "transport", (double)v[0]);
+  set_num(env, o, "rank", (double)v[1]);
+  set_num(env, o, "world", (double)v[2]);
+  set_num(env, o, "rcclRanks", (double)v[3]);
+  return o;
+}
+
+// lastRmseMs(handle) -> device time of the handle's last rmse() pass (ycnr_als_last_rmse_ms)
+napi_value LastRmseMs(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value a[1];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, a, nullptr, nullptr));
+  Handle *hd = argc >= 1 ? handle_of(env, a[0]) : nullptr;
+  if (!hd) return throw_msg(env, "lastRmseMs(handle)");
+  double ms = 0;
+  int rc = ycnr_als_last_rmse_ms(hd->h, &ms);
+  if (rc) return throw_last(env, "lastRmseMs", rc);
+  return num(env, ms);
+}
+
 // deferExchange(handle, side, deferred): ycnr_als_defer_exchange
 napi_value DeferExchange(napi_env env, napi_callback_info info) {
   size_t argc = 3;
@@ -719,6 +751,8 @@ napi_value Init(napi_env env, napi_value exports) {
       {"setRatingsSharded", nullptr, SetRatingsSharded, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
       {"setRatingsBanded", nullptr, SetRatingsBanded, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
       {"deferExchange", nullptr, DeferExchange, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+      {"commInfo", nullptr, CommInfo, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+      {"lastRmseMs", nullptr, LastRmseMs, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
       {"allreduceSum", nullptr, AllreduceSum, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
       {"broadcastFactors", nullptr, CommSide<true>, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
       {"exchange", nullptr, CommSide<false>, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
