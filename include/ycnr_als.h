@@ -329,7 +329,8 @@ int ycnr_als_set_ratings_banded(ycnr_als *h, int side, const int64_t *rowPtr, co
                                 int nBands, const int64_t *bandBounds, const int64_t *rankBands, const int64_t *ownerBounds);
 /* deferred != 0: the half-steps of this (sharded) side no longer exchange their solved rows -- every rank's replica is current in
  * its own rows only -- until ycnr_als_exchange brings all replicas up to date.  For a side whose matrix nobody reads outside its
- * own shard between two exchanges: the user side when the item side is sharded by user bands (ycnr_als_set_ratings_banded). */
+ * own shard between two exchanges: the user side when the item side is sharded by user bands (ycnr_als_set_ratings_banded).
+ * A new upload of the side (ycnr_als_set_ratings[_sharded]) resets it. */
 int ycnr_als_defer_exchange(ycnr_als *h, int side, int deferred);
 /* The exchange alone, whole shards, synchronous (e.g. after ycnr_als_set_factors of local rows). */
 int ycnr_als_exchange(ycnr_als *h, int side);

@@ -1851,6 +1851,7 @@ static int set_ratings_parts(ycnr_als *h, int side, const int64_t *rowPtr, const
   HIP_TRY(hipStreamSynchronize(h->stream));  // nothing in flight still reads the previous upload
   for (Part &p : h->parts[side]) p.release();
   h->banded[side].release();
+  h->deferExchange[side] = false;  // (a new upload exchanges after every half-step again until the host says otherwise)
   h->drop_graphs();
   h->parts[side].swap(pend.parts);
   pend.parts.clear();
