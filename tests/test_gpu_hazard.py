@@ -159,3 +159,39 @@ def test_every_dual_class_at_full_occupancy(als, k):
     worst = 16 * float(amp.max()) * EPS32
     bad = np.flatnonzero(d > max(worst, 2e-5))
     assert bad.size == 0, f"{bad.size} rows differ between the dual and the primal form, e.g. row {int(bad[0])} ({int(lens[bad[0]])} ratings): {float(d[bad[0]]):.3g}"
+
+
+def test_seven_block_dual_class_alone_on_the_chip(als):
+    """The 7-block dual class (97..112 ratings, k = 256) with nothing but its own 4800 workgroups on the chip, so that the two waves
+    of a SIMD run the same phases a few microseconds apart -- the situation in which the build of rounds 3-4 got 1 - 3 % of the rows
+    wrong (a v_pk_fma_f32 that hipcc's SLP vectoriser had made of two blocks' right-hand-side updates: csrc/devtest/dual7/README.md).
+    Every row against float64, twice.  The class ships at two waves per SIMD since round 5; tests/tools/dual_trace.py is the tool
+    that located the failure."""
+    k, m, per, items = 256, 7, 300, 3000
+    rng = np.random.default_rng(5)
+    lens = np.repeat(np.arange(16 * (m - 1) + 1, 16 * m + 1), per).astype(np.int64)
+    rng.shuffle(lens)
+    users = len(lens)
+    rowPtr = np.zeros(users + 1, np.int64)
+    np.cumsum(lens, out=rowPtr[1:])
+    indx = np.concatenate([np.sort(rng.choice(items, n, replace=False)) for n in lens]).astype(np.int32)
+    vals = (rng.standard_normal(rowPtr[-1]) * 2.0 + 5.0).astype(np.float32)
+    V = (rng.standard_normal((items, k)) / np.sqrt(k)).astype(np.float32)
+    V64 = V.astype(np.float64)
+    want = np.zeros((users, k))
+    for u in range(users):  # dual form in float64: n x n systems
+        Y = V64[indx[rowPtr[u]:rowPtr[u + 1]]]
+        w = np.linalg.solve(Y @ Y.T + 0.05 * len(Y) * np.eye(len(Y)), vals[rowPtr[u]:rowPtr[u + 1]].astype(np.float64))
+        want[u] = Y.T @ w
+    for rep in range(2):
+        dev = als.AlsDevice(k, users, items)
+        dev.set_ratings("byUser", rowPtr, indx, vals)
+        dev.set_factors("byUser", np.zeros((users, k), np.float32))
+        dev.set_factors("byItem", V)
+        info = dev.step("byUser")
+        got = dev.get_factors("byUser").astype(np.float64)
+        dev.destroy()
+        assert info.numericErrors == 0 and info.dualRows == users
+        err = np.linalg.norm(got - want, axis=1) / np.linalg.norm(want, axis=1)
+        bad = np.flatnonzero(err > 2e-6)
+        assert bad.size == 0, f"run {rep}: {bad.size} of {users} rows off against float64 (worst {float(err.max()):.3g}), e.g. row {int(bad[0])} with {int(lens[bad[0]])} ratings"

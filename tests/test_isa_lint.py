@@ -77,18 +77,24 @@ PK_BAD = """
 _ZN4ycnr24als_gram_slab_x6d_kernelILi4ELb0EEEvNS_8StepArgsIfEE: ; @x6d
 	v_pk_fma_f32 v[120:121], v[122:123], v[30:31], v[120:121] op_sel_hi:[1,0,1]
 	s_endpgm
-_ZN4ycnr21als_dual_solve_kernelILi2ELb1EEEvNS_8StepArgsIfEE: ; @other kernels may pack
-	v_pk_fma_f32 v[2:3], v[4:5], v[6:7], v[2:3]
+_ZN4ycnr21als_dual_solve_kernelILi2ELb1EEEvNS_8StepArgsIfEE: ; @no kernel may pack float32 multiplies (round 5)
+	v_pk_mul_f32 v[2:3], v[4:5], v[6:7]
+	s_endpgm
+_ZN4ycnr15als_rmse_kernelIfEEvNS_8RmseArgsIT_EE: ; @packed moves and packed adds pass
+	v_pk_mov_b32 v[2:3], v[4:5], v[6:7]
+	v_pk_add_f32 v[2:3], v[4:5], v[6:7]
+	v_fma_f32 v2, v3, v4, v2
 	s_endpgm
 """
 
 
-def test_packed_fma_lint_names_the_gram_x6d_kernels_only(tmp_path, capsys):
+def test_packed_float32_lint_names_every_kernel_that_packs(tmp_path, capsys):
     lint = load_lint()
     f = tmp_path / "pk.s"
     f.write_text(PK_BAD)
-    assert lint.lint_packed_fma(str(f)) == 1
-    assert "x6d" in capsys.readouterr().out
+    assert lint.lint_packed_fma(str(f)) == 2
+    out = capsys.readouterr().out
+    assert "x6d" in out and "als_dual_solve_kernelILi2" in out and "rmse" not in out.replace("kernels checked", "")
 
 
 SCRATCH = """
@@ -124,14 +130,18 @@ _ZN4ycnr21als_dual_solve_kernelILi11ELb1EEEvNS_8StepArgsIfEE: ; @scratch, but ev
 	scratch_store_dword off, v1, off
 	s_waitcnt vmcnt(0)
 	s_endpgm
+_ZN4ycnr21als_dual_solve_kernelILi7ELb1EEEvNS_8StepArgsIfEE: ; @two waves per SIMD AND a packed multiply-add
+	v_pk_fma_f32 v[150:151], v[68:69], v[146:147], v[148:149] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]
+	s_endpgm
 """
 
 
 def test_scratch_lints_name_counted_waits_and_the_two_wave_dual_class(tmp_path, capsys):
     """(1) A kernel that counts its vector-memory waits by hand (inline-asm vmcnt, LDS-DMA) must have NO scratch: a spill is a
     vector-memory operation its count does not know.  (2) The dual class of 7 blocks built for two waves per SIMD solved rows
-    wrong at C5 scale -- with and without scratch (devtest/dual7/README.md) -- so the classes of 7+ blocks must be built for
-    one wave per SIMD.  Other kernels below the general limit pass, whatever their scratch."""
+    wrong at C5 scale exactly when hipcc had paired two blocks' right-hand-side updates into v_pk_fma_f32
+    (devtest/dual7/README.md): a class of 7+ blocks that fits two waves per SIMD must contain no packed float32 instruction.
+    Other kernels below the general limit pass, whatever their scratch."""
     lint = load_lint()
     f = tmp_path / "scratch.s"
     f.write_text(SCRATCH)
@@ -205,7 +215,7 @@ def test_device_assembly_has_no_premature_lds_uses(tmp_path):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     out = tmp_path / "dev.s"
     subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-ffp-contract=on",
-                    "-I" + os.path.join(ROOT, "include"), "--cuda-device-only", "-S", "-o", str(out),
+                    "-fno-slp-vectorize", "-I" + os.path.join(ROOT, "include"), "--cuda-device-only", "-S", "-o", str(out),
                     os.path.join(CSRC, "ycnr_als.hip")], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     assert lint.lint(str(out), []) == 0
     # vector loads issued from inline asm (GramX6P's ids and ratings): no use or copy before their counted wait, back edges included
@@ -219,6 +229,6 @@ def test_device_assembly_has_no_premature_lds_uses(tmp_path):
     # blocks are built for one wave per SIMD (devtest/dual7/README.md)
     assert lint.lint_counted_waits_have_no_scratch(str(out)) == 0
     assert lint.lint_dual_occupancy(str(out)) == 0
-    # the fence of the stale-b hazard: hipcc must not have packed any multiply-add of a GramX6D kernel into
-    # v_pk_fma_f32 (devtest/pkrepro.hip is the reproducer)
+    # the fence of the stale-b and the dual7 hazard: no packed float32 arithmetic in ANY kernel (devtest/pkfma/README.md;
+    # the library is built with -fno-slp-vectorize)
     assert lint.lint_packed_fma(str(out)) == 0

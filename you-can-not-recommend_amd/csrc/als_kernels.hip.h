@@ -982,7 +982,10 @@ struct SolveMfmaF32 {
     if constexpr (P < N) {
       const float d = readlane(R[P], P);
       dmin = fminf(dmin, d);
-      const float rs = __builtin_amdgcn_rsqf(d);
+      float rs = __builtin_amdgcn_rsqf(d);
+#if defined(YCNR_PIVOT_PROBE) && YCNR_PIVOT_PROBE == 3  // devtest: sixteen wait states between the v_rsq and the first use of its result
+      asm volatile("s_nop 7\n\ts_nop 7" : "+v"(rs));
+#endif
       R[P] *= rs;  // L[i][P] in groups 0 / 2, Linv[P][c] in groups 1 / 3
       float l = R[P], b = R[P];
       // l.row1 <-> b.row0, l.row3 <-> b.row2: l = L[j][P] in lane j of every 16-lane row (b is scratch)
@@ -992,6 +995,9 @@ struct SolveMfmaF32 {
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(l), "+v"(b));
       __builtin_amdgcn_sched_barrier(0);
+#elif defined(YCNR_PIVOT_PROBE) && YCNR_PIVOT_PROBE == 4  // devtest: the same l without v_permlane16_swap (lane j of rows 1 / 3 from rows 0 / 2 through the LDS crossbar)
+      l = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((int)((threadIdx.x & ~16u) << 2), __builtin_bit_cast(int, l)));
+      asm volatile("s_nop 1" : "+v"(l), "+v"(b));
 #else
       asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(l), "+v"(b));
 #endif
@@ -1016,7 +1022,7 @@ struct SolveMfmaF32 {
   // the columns past k (with lambda n there, userFactReg = 0 -- which ycnr_als_create accepts -- left a zero pivot: NaN rows)
   template <bool BATCH = false>
   static __device__ __forceinline__ bool solve(acc_t (&acc)[NT], const float (&bacc)[NB], float *S, int k, float lam,
-                                               float (&xcol)[NB], int lane, int kd = -1) {
+                                               float (&xcol)[NB], int lane, int kd = -1, [[maybe_unused]] unsigned *tr = nullptr) {
     const int g = lane >> 4, c = lane & 15;
     if (kd < 0) kd = k;
     float *Dt = S;             // D image, [row][col], row stride LDW
@@ -1043,6 +1049,9 @@ struct SolveMfmaF32 {
     float zrow[NB][4];  // z in row form: zrow[J][t] = z[16 J + 4 g + t] in every lane of group g
 #pragma unroll
     for (int J = 0; J < NB; ++J) {
+#ifdef YCNR_DUAL_TRACE  // devtest: when block step J began (100 MHz clock)
+      if (tr && lane == 0 && J < 8) tr[8 + J] = (unsigned)__builtin_amdgcn_s_memrealtime();
+#endif
       // ---- 1. diagonal tile -> LDS -> lane-per-row Cholesky + inverse
       {
         const acc_t d = acc[tile_index(J, J, NB)];
@@ -1141,6 +1150,10 @@ struct SolveMfmaF32 {
       // ---- 5a. z_J = W b_J, row form
       {
         const float bcolJ = group_sum(bpart[J]);  // b[16 J + c] after the updates of the block steps before
+#ifdef YCNR_DUAL_TRACE  // devtest: the right-hand side block as step J found it
+        if (tr && g == 0 && J < 7) reinterpret_cast<float *>(tr)[256 + 16 * J + c] = bcolJ;
+        if (tr && g == 1 && J < 7) reinterpret_cast<float *>(tr)[384 + 16 * J + c] = bpart[J];
+#endif
 #pragma unroll
         for (int t = 0; t < 4; ++t) zrow[J][t] = row_sum(W[t] * bcolJ);
       }
@@ -1157,6 +1170,9 @@ struct SolveMfmaF32 {
         s = fmaf(-P[1], zrow[J][1], s);
         s = fmaf(-P[2], zrow[J][2], s);
         s = fmaf(-P[3], zrow[J][3], s);
+#ifdef YCNR_SOLVE_NO_PK_FMA  // devtest (dual7): the updates of two blocks' right-hand sides must not pair into v_pk_fma_f32
+        asm volatile("" : "+v"(s));
+#endif
         bpart[bj] = s;
       }
       // ---- 4. trailing update: T[bi][bj] -= U[J][bi]^T U[J][bj], operands straight from the panel tiles
@@ -1176,6 +1192,15 @@ struct SolveMfmaF32 {
         }
       }
     }
+#ifdef YCNR_DUAL_TRACE  // devtest: z = L^-1 b as the forward elimination left it
+    if (tr && c == 0) {
+#pragma unroll
+      for (int J = 0; J < NB && J < 7; ++J)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) reinterpret_cast<float *>(tr)[16 + 16 * J + 4 * g + t] = zrow[J][t];
+    }
+    if (tr && lane == 0) tr[15] = (unsigned)__builtin_amdgcn_s_memrealtime();
+#endif
     // ---- back substitution: x_J = W_J^T (z_J - sum_{bj > J} U[J][bj] x_bj)
 #pragma unroll
     for (int J = NB - 1; J >= 0; --J) {
@@ -1195,6 +1220,12 @@ struct SolveMfmaF32 {
       }
       xcol[J] = group_sum(s);
     }
+#ifdef YCNR_DUAL_TRACE  // devtest: the solution itself
+    if (tr && g == 0) {
+#pragma unroll
+      for (int J = 0; J < NB && J < 7; ++J) reinterpret_cast<float *>(tr)[128 + 16 * J + c] = xcol[J];
+    }
+#endif
     // NaN / Inf in the input never shows as a small pivot (fminf drops NaNs) but ends up in x
     float chk = 0.0f;
 #pragma unroll
@@ -2462,10 +2493,14 @@ __global__ __launch_bounds__(64, NB <= 7 ? 2 : 1) void als_gram_solve_x6p_kernel
 // runs over the k factors, which are contiguous in a gathered row, so lane (g, c) loads its eight
 // operand values 32 s + 8 g .. + 7 of row 16 ba + c as two float4 and splits them in place; 6 MFMAs
 // of K = 32 per tile replace 8 float32 MFMAs of K = 4 that cost 35 cycles each.
-// (YCNR_DUAL7_WAVES: devtest/dual7 builds the 7-block class at two waves per SIMD -- 24 bytes of scratch per lane --, the form
-// that solved rows wrong at C5 scale in round 3; the library keeps one wave per SIMD and no scratch there)
+// YCNR_DUAL7_WAVES: the 7-block class (97 ... 112 ratings, k > 128) at TWO waves per SIMD (256 registers, no scratch).  Rounds 3-4
+// this build solved 1 - 3 % of its rows wrong at full occupancy and was fenced off; round 5 found the instruction: hipcc's SLP
+// vectoriser had paired the right-hand-side updates of two blocks (b_bj -= U[J][bj]^T z_J in SolveMfmaF32::solve) into v_pk_fma_f32
+// on kept copies of the panel tiles, and one such product came out wrong when the SIMD's other wave was in its bf16 MFMA phase
+// (devtest/dual7/README.md: traced to the block, 0 wrong rows of 2 x 19 200 without the pairing).  The library is built with
+// -fno-slp-vectorize and isa_lint.py refuses any packed float32 multiply; one GPU's eighth of C5: 135.8 -> 134.3 ms.
 #ifndef YCNR_DUAL7_WAVES
-#define YCNR_DUAL7_WAVES 1
+#define YCNR_DUAL7_WAVES 2
 #endif
 // The 5-block class (65 ... 80 ratings, the largest of the MAL shape's dual classes) at THREE waves per SIMD: with the next K-step's raw
 // values double-buffered it takes 224 registers; in the row-by-row form of the classes above 6 blocks (operand planes single-
@@ -2473,6 +2508,12 @@ __global__ __launch_bounds__(64, NB <= 7 ? 2 : 1) void als_gram_solve_x6p_kernel
 // MAL user half-step 12.23 -> 12.13 ms (interleaved A/B, same box); classes 3 / 4 one wave higher (5 / 4) spill 20 bytes.
 #ifndef YCNR_DUAL5_WAVES
 #define YCNR_DUAL5_WAVES 3
+#endif
+#ifndef YCNR_DUAL_AHEAD_MAX  // classes up to this many blocks double-buffer the raw values of a whole K-step in registers
+#define YCNR_DUAL_AHEAD_MAX 6
+#endif
+#ifndef YCNR_DUAL_XDEPTH  // steps of x = Y^T w whose loads are in flight in the classes of 7 blocks and more (1: one step, as measured best)
+#define YCNR_DUAL_XDEPTH 1
 #endif
 template <int NBN, bool X6>
 __global__ __launch_bounds__(64, NBN == 3 ? 4 : NBN == 4 ? 3 : NBN == 5 ? YCNR_DUAL5_WAVES : NBN == 7 ? YCNR_DUAL7_WAVES : 1) void als_dual_solve_kernel(StepArgs<float> a) {
@@ -2486,6 +2527,11 @@ __global__ __launch_bounds__(64, NBN == 3 ? 4 : NBN == 4 ? 3 : NBN == 5 ? YCNR_D
   const int n = (int)(u.end - u.beg);
   const int k = a.k;
   const int ksteps = (k + 15) >> 4;
+#ifdef YCNR_DUAL_TRACE  // devtest (tests/tools/dual_trace.py): where and when every row ran -- HW_ID, XCC_ID and the 100 MHz clock at the phase
+                        // boundaries go to the rows of `solved` from row YCNR_DUAL_TRACE on, which the probe leaves without ratings
+  const unsigned long long tr0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long tr1 = 0, tr2 = 0;
+#endif
   // this lane's rating of each 16-rating block: its factor row and its value
   const float *rowp[NBN];
   float bacc[NBN];
@@ -2571,7 +2617,7 @@ __global__ __launch_bounds__(64, NBN == 3 ? 4 : NBN == 4 ? 3 : NBN == 5 ? YCNR_D
     // split into the same registers while the rows below still multiply, and its raw values are requested one row
     // ahead (the scheme of GramX6D).  Before: every block loaded just before its split, one wave per SIMD, nothing to
     // hide the loads behind.
-    constexpr bool AHEAD = NBN <= 6 && !(NBN == 5 && YCNR_DUAL5_WAVES >= 3);
+    constexpr bool AHEAD = NBN <= YCNR_DUAL_AHEAD_MAX && !(NBN == 5 && YCNR_DUAL5_WAVES >= 3);
     auto split8 = [&](const float4 &z0, const float4 &z1, u32x4 &o1, u32x4 &o2, u32x4 &o3) {
       const float x[8] = {z0.x, z0.y, z0.z, z0.w, z1.x, z1.y, z1.z, z1.w};
       unsigned h[4], m[4], l[4];
@@ -2680,6 +2726,9 @@ __global__ __launch_bounds__(64, NBN == 3 ? 4 : NBN == 4 ? 3 : NBN == 5 ? YCNR_D
     }
 #endif
   }
+#ifdef YCNR_DUAL_TRACE
+  tr1 = __builtin_amdgcn_s_memrealtime();
+#endif
   if constexpr (LATE_RHS) {
 #pragma unroll
     for (int ba = 0; ba < NBN; ++ba) {
@@ -2697,25 +2746,27 @@ __global__ __launch_bounds__(64, NBN == 3 ? 4 : NBN == 4 ? 3 : NBN == 5 ? YCNR_D
     for (int bb = ba; bb < NBN; ++bb) wcol[ba] += acc[tile_index(ba, bb, NBN)][0] + acc[tile_index(ba, bb, NBN)][1] + acc[tile_index(ba, bb, NBN)][2] + acc[tile_index(ba, bb, NBN)][3];
   }
 #else
+#ifdef YCNR_DUAL_TRACE
+  unsigned *const trRec = reinterpret_cast<unsigned *>(a.solved + (int64_t)(YCNR_DUAL_TRACE) * k) + (int64_t)u.row * 512;
+  const bool bad = Sv::template solve<YCNR_DUAL_BATCH>(acc, bacc, reinterpret_cast<float *>(smem), n, lam, wcol, lane, -1, trRec);
+#else
   const bool bad = Sv::template solve<YCNR_DUAL_BATCH>(acc, bacc, reinterpret_cast<float *>(smem), n, lam, wcol, lane);
+#endif
+#endif
+#ifdef YCNR_DUAL_TRACE
+  tr2 = __builtin_amdgcn_s_memrealtime();
 #endif
   // x[f] = sum_a Y[a][f] w[a]: per lane the 4 factors 16 s + 4 g + j of its NBN ratings,
   // summed over the 16 lanes of the group; lane c == 0 of each group stores them
   float *out = a.solved + (int64_t)u.row * k;
-#ifdef YCNR_DUAL_ABLATE_X  // timing experiments only
-  if (lane < NBN) out[lane] = wcol[0];
-  for (int s = 0; s < 0; ++s) {
-#else
-  for (int s = 0; s < ksteps; ++s) {
-#endif
-    load(ya, s);
+  auto xstep = [&](const float4 (&y)[NBN], int s) {
     float4 x = float4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int ba = 0; ba < NBN; ++ba) {
-      x.x = fmaf(ya[ba].x, wcol[ba], x.x);
-      x.y = fmaf(ya[ba].y, wcol[ba], x.y);
-      x.z = fmaf(ya[ba].z, wcol[ba], x.z);
-      x.w = fmaf(ya[ba].w, wcol[ba], x.w);
+      x.x = fmaf(y[ba].x, wcol[ba], x.x);
+      x.y = fmaf(y[ba].y, wcol[ba], x.y);
+      x.z = fmaf(y[ba].z, wcol[ba], x.z);
+      x.w = fmaf(y[ba].w, wcol[ba], x.w);
     }
     x.x = Sv::row_sum(x.x);
     x.y = Sv::row_sum(x.y);
@@ -2723,7 +2774,49 @@ __global__ __launch_bounds__(64, NBN == 3 ? 4 : NBN == 4 ? 3 : NBN == 5 ? YCNR_D
     x.w = Sv::row_sum(x.w);
     const int f = 16 * s + 4 * g;
     if (c == 0 && f < k) *reinterpret_cast<float4 *>(out + f) = x;
+  };
+  // YCNR_DUAL_XDEPTH > 1 (devtest): XD steps' loads in flight in the classes of 7 blocks and more (one wave per SIMD, the accumulators are
+  // dead by now).  Measured at k = 256: no class faster, the 12-block class slower (4.0 -> 4.3 / 4.5 ms at 2 / 4) -- the pass waits for bytes
+  // (it gathers the row's ratings a second time from the last-level cache), not for single loads (NOTES_r05.md).
+  constexpr int XD = NBN >= 7 ? YCNR_DUAL_XDEPTH : 1;
+#ifdef YCNR_DUAL_ABLATE_X  // timing experiments only
+  if (lane < NBN) out[lane] = wcol[0];
+#else
+  if constexpr (XD > 1) {
+    float4 yq[XD][NBN];
+#pragma unroll
+    for (int d = 0; d < XD; ++d)
+      if (d < ksteps) load(yq[d], d);
+    for (int s0 = 0; s0 < ksteps; s0 += XD) {
+#pragma unroll
+      for (int d = 0; d < XD; ++d) {
+        const int s = s0 + d;
+        if (s < ksteps) {
+          xstep(yq[d], s);
+          if (s + XD < ksteps) load(yq[d], s + XD);
+        }
+      }
+    }
+  } else {
+    for (int s = 0; s < ksteps; ++s) {
+      load(ya, s);
+      xstep(ya, s);
+    }
   }
+#endif
+#ifdef YCNR_DUAL_TRACE
+  if (lane == 0) {
+    unsigned *tr = trRec;
+    tr[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID
+    tr[1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
+    tr[2] = (unsigned)tr0;
+    tr[3] = (unsigned)tr1;
+    tr[4] = (unsigned)tr2;
+    tr[5] = (unsigned)__builtin_amdgcn_s_memrealtime();
+    tr[6] = (unsigned)blockIdx.x;
+    tr[7] = 0x7ace7aceu;
+  }
+#endif
   if (bad && lane == 0) {
     atomicAdd(&a.err->count, 1);
     a.err->firstRow = u.row;

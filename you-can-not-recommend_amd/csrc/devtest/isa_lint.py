@@ -362,10 +362,11 @@ def lint_counted_waits_have_no_scratch(path):
 
 
 def lint_dual_occupancy(path):
-    """The dual class of 7 blocks solved rows wrong when it was built for two waves per SIMD (256 VGPRs, no AGPRs) -- with
-    AND without scratch, only with three or more of its workgroups on a CU, only with the bf16x6 Gramian and the inline-asm DPP
-    pivots together (devtest/dual7/README.md: the mechanism is open).  Until it is understood, the dual classes of 7 and more
-    blocks (k > 128) must be compiled for ONE wave per SIMD: more than 256 registers in all."""
+    """Round 3-4: the dual class of 7 blocks solved 1 - 3 % of its rows wrong when it was built for two waves per SIMD.  Round 5
+    (devtest/dual7/README.md): the wrong value is ONE right-hand-side block, and it is wrong exactly when hipcc has paired the updates
+    b_bj -= U[J][bj]^T z_J of two blocks into v_pk_fma_f32 -- the shape of the stale-b hazard.  Without packed float32 instructions
+    the two-wave build solves every row (lint_packed_fma below is the fence now).  What stays checked here: a dual class of 7 and
+    more blocks that fits two waves per SIMD (<= 256 registers) must not contain a single packed float32 multiply."""
     text = open(path).read()
     bad = seen = 0
     for m in re.finditer(r"^\s*\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, re.M | re.S):
@@ -373,36 +374,46 @@ def lint_dual_occupancy(path):
         d = re.search(r"als_dual_solve_kernelILi(\d+)E", name)
         if not d or int(d.group(1)) < 7:
             continue
-        seen += 1
         nv = re.search(r"\.amdhsa_next_free_vgpr (\d+)", body)
-        if nv and int(nv.group(1)) <= 256:
+        if not nv or int(nv.group(1)) > 256:
+            continue
+        seen += 1
+        k = re.search(r"^" + re.escape(name) + r":[^\n]*$", text, re.M)
+        end = text.find("s_endpgm", k.end()) if k else -1
+        n = len(re.findall(r"^\s*v_pk_(?:fma|mul)_f32\b", text[k.end():end], re.M)) if k else 1
+        if n:
             bad += 1
-            print(f"FAIL {name[:90]}: dual class of {d.group(1)} blocks built for more than one wave per SIMD "
-                  f"(next_free_vgpr {nv.group(1)}): devtest/dual7/README.md")
-    print(f"dual classes of 7+ blocks checked for one wave per SIMD: {seen}")
-    return bad
+            print(f"FAIL {name[:90]}: dual class of {d.group(1)} blocks at two waves per SIMD with {n} packed float32 "
+                  f"instructions: devtest/dual7/README.md")
+    print(f"dual classes of 7+ blocks built for two waves per SIMD, checked for packed float32: {seen}")
     return bad
 
 
-def lint_packed_fma(path, kernels=("x6d",)):
-    """The fence of the stale-b hazard: with the right-hand side's multiply-adds of two column
-    blocks SLP-packed into v_pk_fma_f32, the GramX6D kernels computed a wrong b in lanes 48..63 under full
-    occupancy (devtest/pkrepro.hip reproduces it).  The source keeps hipcc from packing with an empty asm
-    per accumulator; a compiler that packs somewhere else would pass every CPU test and fail only on the
-    GPU, so the build itself is checked: NO v_pk_fma_f32 in any kernel built around GramX6D."""
+PACKED_F32 = re.compile(r"^\s*(v_pk_(?:fma|mul)_f32)\b", re.M)
+
+
+def lint_packed_fma(path, kernels=None):
+    """The fence of the stale-b and the dual7 hazard (devtest/pkfma/README.md): with the multiply-adds of two column blocks
+    SLP-packed into v_pk_fma_f32 -- operand pairs assembled from kept copies, one multiplier broadcast by op_sel_hi -- kernels
+    of this library computed wrong values under full occupancy (GramX6D: b in lanes 48..63; the 7-block dual class at two waves
+    per SIMD: one block of the right-hand side), and right ones in every small test.  The library is built with
+    -fno-slp-vectorize; a compiler that packs anyway would pass every CPU test and fail only on the GPU, so the build itself is
+    checked: NO packed float32 multiply (v_pk_fma_f32 / v_pk_mul_f32) in ANY kernel.  (v_pk_add_f32 from source-level float2
+    sums -- the LDS solver's column sums -- stays: the two-wave dual build with its 69 packed adds and without the paired
+    multiply-adds solved every row.)"""
     text = open(path).read()
     bad = seen = 0
     for m in re.finditer(r"^(_Z[\w]+):[^\n]*$", text, re.M):
         name = m.group(1)
-        if "ycnr" not in name or not any(w in name for w in kernels):
+        if "ycnr" not in name or (kernels and not any(w in name for w in kernels)):
             continue
         seen += 1
         end = text.find("s_endpgm", m.end())
-        n = len(re.findall(r"^\s*v_pk_fma_f32\b", text[m.end():end], re.M))
-        if n:
+        found = PACKED_F32.findall(text[m.end():end])
+        if found:
             bad += 1
-            print(f"FAIL {name[:90]}: {n} v_pk_fma_f32 in a GramX6D kernel")
-    print(f"GramX6D kernels checked for packed multiply-adds: {seen}")
+            print(f"FAIL {name[:90]}: {len(found)} packed float32 instructions ({', '.join(sorted(set(found)))})")
+    print(f"kernels checked for packed float32 arithmetic: {seen}")
     return bad
 
 
@@ -412,7 +423,7 @@ if __name__ == "__main__":
     nd = lint_dpp(sys.argv[1], sys.argv[2:])
     print("DPP reads too early:", nd)
     ns = lint_scratch(sys.argv[1]) + lint_counted_waits_have_no_scratch(sys.argv[1]) + lint_dual_occupancy(sys.argv[1])
-    print("kernels spilling to scratch / counted waits with scratch / dual classes at two waves:", ns)
+    print("kernels spilling to scratch / counted waits with scratch / two-wave dual classes with packed float32:", ns)
     npk = lint_packed_fma(sys.argv[1])
-    print("GramX6D kernels with packed multiply-adds:", npk)
+    print("kernels with packed float32 arithmetic:", npk)
     sys.exit(1 if n or nd or ns or npk else 0)
