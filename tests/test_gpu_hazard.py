@@ -161,13 +161,15 @@ def test_every_dual_class_at_full_occupancy(als, k):
     assert bad.size == 0, f"{bad.size} rows differ between the dual and the primal form, e.g. row {int(bad[0])} ({int(lens[bad[0]])} ratings): {float(d[bad[0]]):.3g}"
 
 
-def test_seven_block_dual_class_alone_on_the_chip(als):
+@pytest.mark.parametrize("m", [3, 7, 12])
+def test_seven_block_dual_class_alone_on_the_chip(als, m):
     """The 7-block dual class (97..112 ratings, k = 256) with nothing but its own 4800 workgroups on the chip, so that the two waves
     of a SIMD run the same phases a few microseconds apart -- the situation in which the build of rounds 3-4 got 1 - 3 % of the rows
     wrong (a v_pk_fma_f32 that hipcc's SLP vectoriser had made of two blocks' right-hand-side updates: csrc/devtest/dual7/README.md).
     Every row against float64, twice.  The class ships at two waves per SIMD since round 5; tests/tools/dual_trace.py is the tool
-    that located the failure."""
-    k, m, per, items = 256, 7, 300, 3000
+    that located the failure.  (m = 3 / 12: a class at four waves per SIMD and the largest one, the same way;
+    profiles/r05_dualprobe_all.sh runs all seventeen classes of k = 256 and k = 100.)"""
+    k, per, items = 256, 300, 3000
     rng = np.random.default_rng(5)
     lens = np.repeat(np.arange(16 * (m - 1) + 1, 16 * m + 1), per).astype(np.int64)
     rng.shuffle(lens)
