@@ -3136,7 +3136,15 @@ struct RmseArgs {
   int32_t k;
 };
 
-template <typename T>
+// NCH: chunks of 4 values per lane (rows of at most 64 NCH values whose byte length is a multiple of 16: lane l16 owns the chunks
+// l16, l16 + 16, ... of both factor rows; the user's chunks stay in registers for all of its ratings); 0: any k, value by value.
+// Round 5: RB ratings of the row are in flight at once -- their column ids, values and item rows are requested before the first dot
+// product is formed (before: one rating at a time, two dependent trips to memory each: 2.6 ms for the 12 M validation ratings of the
+// MAL-scale run).  Same products, same sums, same order as before: the partial sums are bit for bit those of rounds 1-4.
+#ifndef YCNR_RMSE_RB
+#define YCNR_RMSE_RB 4  // ratings of a row in flight per 16-lane group (float32, k <= 128; half / a quarter of it for wider rows)
+#endif
+template <typename T, int NCH>
 __global__ __launch_bounds__(256) void als_rmse_kernel(RmseArgs<T> a) {
   __shared__ double red[3][16];
   const int tid = threadIdx.x, grp = tid >> 4, l16 = tid & 15;
@@ -3144,49 +3152,68 @@ __global__ __launch_bounds__(256) void als_rmse_kernel(RmseArgs<T> a) {
   const int64_t r0 = p == 0 ? 0 : a.portionRowEnd[p - 1];
   const int64_t r1 = a.portionRowEnd[p];
   double sd2 = 0, sp = 0, cnt = 0;
-  // 16-byte loads when rows are 16-byte multiples: lane l16 owns the vec4 chunks l16, l16 + 16, ...
-  // of both factor rows; the user's chunks stay in registers for all of its ratings
   typedef T vec4 __attribute__((ext_vector_type(4)));
-  const bool vec = (a.k * sizeof(T)) % 16 == 0 && a.k <= 512;
+  constexpr int NC = NCH > 0 ? NCH : 1;
+  constexpr int RB = NCH == 0 ? 1 : (NCH * (int)sizeof(T) <= 8 ? YCNR_RMSE_RB : (NCH * (int)sizeof(T) <= 16 ? YCNR_RMSE_RB / 2 : YCNR_RMSE_RB / 4));
   const int nchunk = a.k >> 2;
   for (int64_t r = r0 + grp; r < r1; r += 16) {
     const T *uF = a.userFactors + (a.rowBegin + r) * a.k;
-    vec4 u[8];
-    if (vec) {
+    vec4 u[NC];
+    if constexpr (NCH > 0) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < NCH; ++i) {
         const int ch = l16 + 16 * i;
         u[i] = ch < nchunk ? *reinterpret_cast<const vec4 *>(uF + 4 * ch) : vec4{T(0), T(0), T(0), T(0)};
       }
     }
-    for (int64_t q = a.rowPtr[r]; q < a.rowPtr[r + 1]; ++q) {
-      const T *iF = a.itemFactors + (int64_t)a.indx[q] * a.k;
-      T dot = T(0);
-      if (vec) {
+    const int64_t q1 = a.rowPtr[r + 1];
+    for (int64_t q = a.rowPtr[r]; q < q1; q += RB) {
+      int32_t id[RB];
+      T val[RB];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int ch = l16 + 16 * i;
-          if (16 * i < nchunk) {  // uniform
-            const vec4 v = ch < nchunk ? *reinterpret_cast<const vec4 *>(iF + 4 * ch) : vec4{T(0), T(0), T(0), T(0)};
-            dot = fma(u[i][0], v[0], dot);
-            dot = fma(u[i][1], v[1], dot);
-            dot = fma(u[i][2], v[2], dot);
-            dot = fma(u[i][3], v[3], dot);
+      for (int j = 0; j < RB; ++j) {
+        const int64_t qq = q + j < q1 ? q + j : q1 - 1;
+        id[j] = a.indx[qq];
+        val[j] = a.vals[qq];
+      }
+      vec4 v[RB][NC];
+      if constexpr (NCH > 0) {
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+          const T *iF = a.itemFactors + (int64_t)id[j] * a.k;
+#pragma unroll
+          for (int i = 0; i < NCH; ++i) {
+            const int ch = l16 + 16 * i;
+            v[j][i] = ch < nchunk ? *reinterpret_cast<const vec4 *>(iF + 4 * ch) : vec4{T(0), T(0), T(0), T(0)};
           }
         }
-      } else {
-        for (int f = l16; f < a.k; f += 16) dot = fma(uF[f], iF[f], dot);
       }
-      dot += wave_shfl_xor<T>(dot, 8);
-      dot += wave_shfl_xor<T>(dot, 4);
-      dot += wave_shfl_xor<T>(dot, 2);
-      dot += wave_shfl_xor<T>(dot, 1);
-      if (l16 == 0) {
-        const double pred = (double)dot + a.shift;
-        const double d = (double)a.vals[q] - pred;
-        sd2 += d * d;
-        sp += pred;
-        cnt += 1.0;
+#pragma unroll
+      for (int j = 0; j < RB; ++j) {
+        T dot = T(0);
+        if constexpr (NCH > 0) {
+#pragma unroll
+          for (int i = 0; i < NCH; ++i) {
+            dot = fma(u[i][0], v[j][i][0], dot);
+            dot = fma(u[i][1], v[j][i][1], dot);
+            dot = fma(u[i][2], v[j][i][2], dot);
+            dot = fma(u[i][3], v[j][i][3], dot);
+          }
+        } else {
+          const T *iF = a.itemFactors + (int64_t)id[j] * a.k;
+          for (int f = l16; f < a.k; f += 16) dot = fma(uF[f], iF[f], dot);
+        }
+        dot += wave_shfl_xor<T>(dot, 8);
+        dot += wave_shfl_xor<T>(dot, 4);
+        dot += wave_shfl_xor<T>(dot, 2);
+        dot += wave_shfl_xor<T>(dot, 1);
+        if (l16 == 0 && q + j < q1) {
+          const double pred = (double)dot + a.shift;
+          const double d = (double)val[j] - pred;
+          sd2 += d * d;
+          sp += pred;
+          cnt += 1.0;
+        }
       }
     }
   }

@@ -328,6 +328,15 @@ int launch_dual(StepArgs<float> args, const DualPlan &dp, hipStream_t stream) {
   return YCNR_OK;
 }
 
+// the RMSE kernel for this k: chunks of four values per lane of a 16-lane group (als_rmse_kernel)
+template <typename T>
+void launch_rmse(const RmseArgs<T> &a, int nPieces, hipStream_t stream) {
+  const bool vec = ((size_t)a.k * sizeof(T)) % 16 == 0 && a.k <= 512;
+  void (*kr)(RmseArgs<T>) = als_rmse_kernel<T, 0>;
+  if (vec) kr = a.k <= 64 ? als_rmse_kernel<T, 1> : a.k <= 128 ? als_rmse_kernel<T, 2> : a.k <= 256 ? als_rmse_kernel<T, 4> : als_rmse_kernel<T, 8>;
+  hipLaunchKernelGGL(kr, dim3((unsigned)nPieces), dim3(256), 0, stream, a);
+}
+
 template <typename T>
 int launch_duals(const StepArgs<T> &, const DualPlan &, hipStream_t) { return YCNR_OK; }
 template <>
@@ -2823,11 +2832,11 @@ int ycnr_als_rmse(ycnr_als *h, int which, double shift, int nPortions, const int
     if (h->opt.dtype == YCNR_F32) {
       RmseArgs<float> a{R.dRowPtr, R.dIndx, (const float *)R.dVals, (const float *)h->factors[0],
                         (const float *)h->factors[1], dEnds, dOut, shift, R.rowBegin, h->opt.factorsCount};
-      hipLaunchKernelGGL(als_rmse_kernel<float>, dim3(np), dim3(256), 0, h->stream, a);
+      launch_rmse(a, np, h->stream);
     } else {
       RmseArgs<double> a{R.dRowPtr, R.dIndx, (const double *)R.dVals, (const double *)h->factors[0],
                          (const double *)h->factors[1], dEnds, dOut, shift, R.rowBegin, h->opt.factorsCount};
-      hipLaunchKernelGGL(als_rmse_kernel<double>, dim3(np), dim3(256), 0, h->stream, a);
+      launch_rmse(a, np, h->stream);
     }
     e = hipGetLastError();
   }
