@@ -49,6 +49,9 @@ while time.time() - t0 < budget:
         if not (err <= bound).all():
             r = int(np.argmax(err / bound))
             print('FAIL', side, 'k', k, 'f64' if dbl else 'f32', 'users', users, 'items', items, 'flags', flags, 'chunk', chunk, 'row', r, 'n', int(np.diff(csr.rowPtr)[r]), 'err', float(err[r]), 'bound', float(bound[r]))
+            sys.stdout.flush()
             sys.exit(1)
     runs += 1
+    if runs % 10 == 0:  # (a run that prints nothing for minutes is taken for hung on the GPU boxes)
+        print('...', runs, 'problems, %.0f s, worst err / bound so far %.3f' % (time.time() - t0, worst), flush=True)
 print('ok:', runs, 'random problems, worst err / bound = %.3f' % worst)
