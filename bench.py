@@ -121,9 +121,11 @@ def main():
                          "ipc = mapped peer replicas + copy engines, also with several ranks on one GPU)")
     ap.add_argument("--transport-ab", default="", choices=["", "rccl", "ipc", "shm"],
                     help="N > 1: after the timed run, the same iterations once more over THIS transport; reported beside it as exchange.ab")
-    ap.add_argument("--allow-fallback", action="store_true",
-                    help="N > 1: let the host fall back to torch.distributed's all-gather when the requested transport cannot be "
-                         "set up (default: exit non-zero -- a line must not name a path that did not run)")
+    ap.add_argument("--strict-transport", action="store_true",
+                    help="N > 1: exit non-zero when the requested transport cannot be set up on every rank (default: try the other "
+                         "device-to-device transport, then torch.distributed's all-gather; exchange.path names the path that RAN, "
+                         "exchange.requested the one asked for, exchange.fallback why)")
+    ap.add_argument("--allow-fallback", action="store_true", help="(the default since round 5; kept for old command lines)")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="one GPU solves the shard of every rank of a world of this size in turn (exchange left out) and "
                          "reports the compute time per rank, before and after the feedback re-cut of the shards")
@@ -188,10 +190,10 @@ def main():
     lord = EmfLord(options={"factorsCount": k, "trainIters": args.steps, "useDoublePrecision": args.double,
                             "dbType": "mal" if max_rating == 10 else "ml", "chunkRatings": args.chunk,
                             "dataSetDistr": [90, 10, 0], "exchangeChunks": args.exchange_chunks, "rebalanceAfterIters": args.rebalance_after,
-                            "commTransport": requested_transport, "strictTransport": not args.allow_fallback, "itemStepSharding": args.item_sharding},
+                            "commTransport": requested_transport, "strictTransport": args.strict_transport, "itemStepSharding": args.item_sharding},
                     dist=dist)
     lord.prepareToTrain(ds, seed=20260004, device=local_rank)
-    if world > 1 and not args.allow_fallback and lord.exchangePath != "libycnr_als:" + requested_transport:
+    if world > 1 and args.strict_transport and lord.exchangePath != "libycnr_als:" + requested_transport:
         sys.exit(f"bench.py: the exchange runs over '{lord.exchangePath}', not over the requested 'libycnr_als:{requested_transport}'")
     t_prep = time.time() - t0 - t_gen
 
@@ -379,6 +381,8 @@ def main():
     # where a multi-GPU iteration goes, per half-step and averaged over the timed steps (this rank;
     # compute_ms of every rank is gathered so that a straggler shows)
     exchange = {"path": getattr(lord, "exchangePath", "none")}
+    if world > 1 and getattr(lord, "commFallback", None):
+        exchange["fallback"] = lord.commFallback  # (why exchange.path is not libycnr_als:<requested_transport>)
     if world > 1 and hasattr(lord.backend, "dev"):
         # what the library's communicator says it is: transport, rank, world, and the ranks RCCL itself counts (ncclCommCount)
         exchange["comm"] = lord.backend.dev.comm_info()

@@ -870,6 +870,27 @@ def test_bench_starts_its_own_ranks(tmp_path):
     assert out["rmse_ms"] > 0
 
 
+def test_bench_falls_back_to_the_other_transport(tmp_path):
+    """A transport that cannot be set up on every rank must not cost the run: two ranks on ONE device ask for `rccl` (which refuses
+    duplicate devices), the host moves on to `ipc`, the line says over which path it ran and why; with --strict-transport the
+    same command exits non-zero (a measurement that must not run over another path than the one it names)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--same-device", "--backend", "gloo", "--transport", "rccl",
+           "--workload", "ml100k", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    ex = out["exchange"]
+    assert ex["path"] == "libycnr_als:ipc" and ex["requested_transport"] == "rccl" and ex["replicas_consistent"] is True
+    assert ex["fallback"] and ex["fallback"][0].startswith("rccl:")
+    r = subprocess.run(cmd + ["--strict-transport"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode != 0 and "unavailable" in (r.stderr + r.stdout)
+
+
 @pytest.mark.parametrize("world,transport,sharding", [(2, "shm", "rows"), (4, "shm", "rows"), (3, "ipc", "rows"), (2, "ipc", "bands"), (4, "ipc", "bands")])
 def test_ranks_on_one_gpu_equal_one_rank(tmp_path, world, transport, sharding):
     """The sharded HIP path end to end: 2 / 4 gloo ranks sharing cuda:0 (functional stand-in for

@@ -266,6 +266,10 @@ class HipBackend:
         self.dev.comm_init(unique_id, rank, world, transport)
         self.world = world
 
+    def comm_destroy(self):
+        self.dev.comm_destroy()
+        self.world = 1
+
     def allreduce_sum(self, arr):
         return self.dev.allreduce_sum(arr)
 
@@ -409,35 +413,54 @@ class EmfLord:
         ub, ue = self.shards[0][self.rank], self.shards[0][self.rank + 1]
         ib, ie = self.shards[1][self.rank], self.shards[1][self.rank + 1]
         self.native_exchange = self.world > 1 and getattr(self.backend, "native_exchange", False)
+        self.commTransport, self.commFallback = None, []
         if self.native_exchange:
             # the communicator's id travels over the host's control plane (here torch.distributed's
-            # store; in the NodeJS host the Lord's process.send), the rows over the library's transport
-            transport = self.options.get("commTransport", "rccl")
-            ok, why = 1, ""
-            try:
-                box = [self.backend.comm_unique_id(transport) if self.rank == 0 else None]
-            except Exception as e:  # noqa: BLE001 -- reported below, collectively
-                box, ok, why = [None], 0, str(e)
-            self._dist.broadcast_object_list(box, src=0)
-            if box[0] is not None:
+            # store; in the NodeJS host the Lord's process.send), the rows over the library's transport.
+            # Unless strictTransport is set, a device-to-device transport that cannot be set up on EVERY rank is followed by the
+            # other one (rccl -> ipc, ipc -> rccl) before the host falls back to torch.distributed: a run on a node nobody has
+            # seen before should produce a number, and exchangePath / commFallback say over which path and why.
+            wanted = self.options.get("commTransport", "rccl")
+            strict = bool(self.options.get("strictTransport", False))
+            candidates = [wanted] + ([t for t in ("rccl", "ipc") if t != wanted] if (not strict and wanted in ("rccl", "ipc")) else [])
+            for transport in candidates:
+                ok, why = 1, ""
                 try:
-                    self.backend.comm_init(box[0], self.rank, self.world, transport)
-                except Exception as e:  # noqa: BLE001
-                    ok, why = 0, str(e)
-            else:
-                ok = 0
-            # all ranks must agree on the path: one failed rank sends everybody to torch.distributed
-            flags = [None] * self.world
-            self._dist.all_gather_object(flags, (ok, why))
-            if not all(f[0] for f in flags):
+                    box = [self.backend.comm_unique_id(transport) if self.rank == 0 else None]
+                except Exception as e:  # noqa: BLE001 -- reported below, collectively
+                    box, ok, why = [None], 0, str(e)
+                self._dist.broadcast_object_list(box, src=0)
+                inited = False
+                if box[0] is not None:
+                    try:
+                        self.backend.comm_init(box[0], self.rank, self.world, transport)
+                        inited = True
+                    except Exception as e:  # noqa: BLE001
+                        ok, why = 0, str(e)
+                else:
+                    ok = 0
+                # all ranks must agree on the path: one failed rank sends everybody on
+                flags = [None] * self.world
+                self._dist.all_gather_object(flags, (ok, why))
+                if all(f[0] for f in flags):
+                    self.commTransport = transport
+                    break
                 why = "; ".join("rank %d: %s" % (r, f[1]) for r, f in enumerate(flags) if not f[0])
-                if self.options.get("strictTransport", False):
-                    # a measurement must not silently run over another path than the one it names (bench.py)
-                    raise RuntimeError("exchange transport '%s' unavailable (%s)" % (transport, why))
+                self.commFallback.append("%s: %s" % (transport, why))
+                if inited and hasattr(self.backend, "comm_destroy"):
+                    self.backend.comm_destroy()
+            if self.commTransport is None:
+                why = " | ".join(self.commFallback)
+                if strict:
+                    # a measurement must not silently run over another path than the one it names (bench.py --strict-transport)
+                    raise RuntimeError("exchange transport '%s' unavailable (%s)" % (wanted, why))
                 import warnings
                 warnings.warn("native exchange unavailable (%s); using torch.distributed all-gather" % why)
                 self.native_exchange = False
-        self.exchangePath = ("libycnr_als:" + self.options.get("commTransport", "rccl")) if self.native_exchange else \
+            elif self.commFallback:
+                import warnings
+                warnings.warn("exchange over '%s' instead of '%s' (%s)" % (self.commTransport, wanted, " | ".join(self.commFallback)))
+        self.exchangePath = ("libycnr_als:" + self.commTransport) if self.native_exchange else \
             ("torch.distributed" if self.world > 1 else "none")
         if self.bands is not None and not hasattr(self.backend, "set_ratings_banded"):
             raise RuntimeError("itemStepSharding='bands' needs a backend with set_ratings_banded (the HIP backend)")
