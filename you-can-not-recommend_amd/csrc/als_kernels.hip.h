@@ -897,6 +897,44 @@ struct SolveMfmaF32 {
     v += row_ror<1>(v);
     return v;
   }
+  // row_sum of FOUR values at once, one v_add_f32_dpp per value and stage (round 5).  hipcc makes two instructions of `v += row_ror(v)`
+  // (v_mov_b32_dpp + v_add_f32, and now and then a third that clears the mov's `old` operand): 32+ per four sums, 224 per block step of a
+  // solve and 7 x 32 in the dual classes' x = Y^T w -- a tenth of the user half-step's vector instructions at MAL scale.  Same operands,
+  // same adds, same order: bit for bit row_sum.  Hazards hipcc does not pad around inline asm: a DPP operand written by a vector
+  // instruction needs two wait states -- `s_nop 1` in front (the compiler's producer may sit directly before the statement), and
+  // between the stages the other three values' instructions lie (isa_lint.py: lint_dpp walks these too).
+#ifndef YCNR_ROW_SUM4_ASM
+#define YCNR_ROW_SUM4_ASM 1
+#endif
+  static __device__ __forceinline__ void row_sum4(float &a, float &b, float &c, float &d) {
+    // (NB >= 10 -- the dual classes of 145+ ratings at k > 128 -- keeps the compiler's form: with one more asm statement in their
+    // solves hipcc spilled 536 bytes per lane in the 12-block class; see the pivots' note on NB >= 10)
+    if constexpr (YCNR_ROW_SUM4_ASM && NB <= 9) {
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_ror:1 row_mask:0xf bank_mask:0xf"
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    } else {
+      a = row_sum(a);
+      b = row_sum(b);
+      c = row_sum(c);
+      d = row_sum(d);
+    }
+  }
   // sum over the 4 lane groups (same c), result in every group
   static __device__ __forceinline__ float group_sum(float v) {
     v += __shfl_xor(v, 16, 64);
@@ -1155,7 +1193,8 @@ struct SolveMfmaF32 {
         if (tr && g == 1 && J < 7) reinterpret_cast<float *>(tr)[384 + 16 * J + c] = bpart[J];
 #endif
 #pragma unroll
-        for (int t = 0; t < 4; ++t) zrow[J][t] = row_sum(W[t] * bcolJ);
+        for (int t = 0; t < 4; ++t) zrow[J][t] = W[t] * bcolJ;
+        row_sum4(zrow[J][0], zrow[J][1], zrow[J][2], zrow[J][3]);
       }
       // ---- 3. panel tiles and 5b. rhs update
 #pragma unroll
@@ -1213,9 +1252,10 @@ struct SolveMfmaF32 {
       }
       const acc_t W = acc[tile_index(J, J, NB)];
       float s = 0.0f;
+      if (J + 1 < NB) row_sum4(part[0], part[1], part[2], part[3]);
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const float y = (J + 1 < NB) ? zrow[J][t] - row_sum(part[t]) : zrow[J][t];
+        const float y = (J + 1 < NB) ? zrow[J][t] - part[t] : zrow[J][t];
         s = fmaf(W[t], y, s);
       }
       xcol[J] = group_sum(s);
@@ -2768,10 +2808,7 @@ __global__ __launch_bounds__(64, NBN == 3 ? 4 : NBN == 4 ? 3 : NBN == 5 ? YCNR_D
       x.z = fmaf(y[ba].z, wcol[ba], x.z);
       x.w = fmaf(y[ba].w, wcol[ba], x.w);
     }
-    x.x = Sv::row_sum(x.x);
-    x.y = Sv::row_sum(x.y);
-    x.z = Sv::row_sum(x.z);
-    x.w = Sv::row_sum(x.w);
+    Sv::row_sum4(x.x, x.y, x.z, x.w);
     const int f = 16 * s + 4 * g;
     if (c == 0 && f < k) *reinterpret_cast<float4 *>(out + f) = x;
   };

@@ -152,7 +152,8 @@ struct PairSolve {
         const float bcolJ = Sm::group_sum(bpart[J]);
         float zr[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) zr[t] = Sm::row_sum(Wd[t] * bcolJ);
+        for (int t = 0; t < 4; ++t) zr[t] = Wd[t] * bcolJ;
+        Sm::row_sum4(zr[0], zr[1], zr[2], zr[3]);
         if (c == 0) *reinterpret_cast<float4 *>(zJ + 4 * g) = float4{zr[0], zr[1], zr[2], zr[3]};
       }
       // panel U[J][bj] = W T[J][bj]: kept in registers (back substitution), published to LDS as [lane][4]
@@ -229,9 +230,10 @@ struct PairSolve {
         const float4 z4 = *reinterpret_cast<const float4 *>(zb + 16 * J + 4 * g);
         const float z[4] = {z4.x, z4.y, z4.z, z4.w};
         float sx = 0.0f;
+        if (J + 1 < NB) Sm::row_sum4(part[0], part[1], part[2], part[3]);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          const float y = (J + 1 < NB) ? z[t] - Sm::row_sum(part[t]) : z[t];
+          const float y = (J + 1 < NB) ? z[t] - part[t] : z[t];
           sx = fmaf(Wd[t], y, sx);
         }
         sx = Sm::group_sum(sx);

@@ -390,10 +390,9 @@ struct WgSolve {
   }
   // y[4g+t] = sum_c M[4g+t][c] v[c], v given per column (vc = v[c]); result in every lane of group g
   static __device__ __forceinline__ acc_t matvec_n(const acc_t &m, float vc) {
-    acc_t y;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) y[t] = Sm::row_sum(m[t] * vc);
-    return y;
+    float y0 = m[0] * vc, y1 = m[1] * vc, y2 = m[2] * vc, y3 = m[3] * vc;
+    Sm::row_sum4(y0, y1, y2, y3);
+    return acc_t{y0, y1, y2, y3};
   }
 
   // value of lane N of the caller's 16-lane row, in every lane of the row (DPP row_newbcast)
