@@ -184,6 +184,27 @@ def test_js_train_on_per_gpu_processes(tmp_path, double, transport, sharding):
 
 
 @pytest.mark.gpu
+def test_js_train_falls_back_to_the_other_transport(tmp_path):
+    """EmfLord.trainOnGpus with two processes on ONE device asking for 'rccl' (which refuses duplicate devices): the Lord starts
+    the processes afresh over 'ipc' and says so in its result; with strictTransport the same train is an error."""
+    bu, user, typ, U, V = problem(seed=9, users=120, items=70)
+    inp = {"dir": str(tmp_path / "w2"), "k": 12, "iters": 2, "rip": 40, "threads": 2, "useDoublePrecision": False, "world": 2, "transport": "rccl",
+           "users": bu.rows, "items": bu.cols, "user": user.tolist(), "item": bu.indx.tolist(),
+           "rating": bu.vals.astype(np.float32).tolist(), "type": typ.tolist()}
+    (tmp_path / "in.json").write_text(json.dumps(inp))
+    r = subprocess.run(["node", os.path.join(HERE, "js", "train_gpu_ranks.js"), str(tmp_path / "in.json")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["commTransport"] == "ipc" and out["commFallback"] and out["commFallback"][0].startswith("rccl:")
+    assert len(out["history"]) == 2 and out["stepInfo"]["exchangeBytes"] > 0
+    inp["strict"] = True
+    inp["dir"] = str(tmp_path / "w2s")
+    (tmp_path / "in_strict.json").write_text(json.dumps(inp))
+    r = subprocess.run(["node", os.path.join(HERE, "js", "train_gpu_ranks.js"), str(tmp_path / "in_strict.json")], capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+
+
+@pytest.mark.gpu
 def test_node_split_and_stats_on_gpu(tmp_path):
     """N1 through the addon: the same split as the oracle, statistics as numpy."""
     from oracle import oracle as orc

@@ -72,6 +72,7 @@ class EmfBase extends EventEmitter {
       world: 1,
       commId: null,
       commTransport: 'rccl', // 'rccl' | 'ipc' (mapped peer replicas + copy engines; also several ranks on one GPU) | 'shm' (host-staged stand-in)
+      strictTransport: false, // true: trainOnGpus fails when commTransport cannot be set up in every GPU process (default: rccl <-> ipc are tried in turn)
       exchangeChunks: 4,
       rebalanceAfterIters: 2,   // multi-GPU: cut the row shards again from the measured compute times after each of the first N iterations (0 = never)
       // multi-GPU: 'rows' = items over the ranks, the user matrix all-gathered after every user half-step; 'bands' = the users in 8

@@ -178,9 +178,40 @@ class EmfLord extends EmfMaster {
    * @return Promise of rank 0's {history, calcInfo, stepInfo}
    */
   trainOnGpus(datasetSpec, config) {
-    const world = this.options.gpus, transport = this.options.commTransport;
+    // A device-to-device transport that cannot be set up in every GPU process is followed by the other one (rccl -> ipc, ipc -> rccl)
+    // unless options.strictTransport is set: a train on a node nobody has seen before should produce its factors, and the result says
+    // over which transport it ran (commTransport) and why not over the one asked for (commFallback).  Only failures of the
+    // set-up phase are retried (the processes are started afresh); a failure while training is an error as before.
+    const wanted = this.options.commTransport;
+    const d2d = ['rccl', 'ipc'];
+    const others = (!this.options.strictTransport && d2d.includes(wanted)) ? d2d.filter((t) => t != wanted) : [];
+    const why = [];
+    const attempt = (transport, rest) => this._trainOnGpusOver(transport, datasetSpec, config).then((res) => {
+      if (res && typeof res == 'object') {
+        res.commTransport = transport;
+        if (why.length) res.commFallback = why;
+      }
+      return res;
+    }, (e) => {
+      if (!(e && e.duringSetup) || !rest.length) return Promise.reject(e);
+      why.push(transport + ': ' + e.message);
+      return attempt(rest[0], rest.slice(1));
+    });
+    return attempt(wanted, others);
+  }
+
+  /** trainOnGpus over one transport; a rejection before every process reported 'ready' carries duringSetup = true */
+  _trainOnGpusOver(transport, datasetSpec, config) {
+    const world = this.options.gpus;
     if (!(world > 1)) return Promise.reject(new Error('trainOnGpus needs options.gpus > 1'));
-    const commId = Buffer.from(als.native.commUniqueId(als.commTransport[transport])).toString('base64');
+    let commId;
+    try {
+      commId = Buffer.from(als.native.commUniqueId(als.commTransport[transport])).toString('base64');
+    } catch (e) {
+      e.duringSetup = true;
+      return Promise.reject(e);
+    }
+    let settingUp = true;
     let devices = this.options.gpuDevices || 0;  // 0: ask the library (fails loudly without a HIP device)
     if (!devices) {
       try { devices = als.native.deviceCount(); } catch (e) { return Promise.reject(e); }
@@ -214,7 +245,7 @@ class EmfLord extends EmfMaster {
       k.once('error', (e) => onDeath(k, 'failed: ' + (e && e.message)));
       kids.push(k);
     }
-    const opts = Object.assign({}, this.options, { gpus: 1 });
+    const opts = Object.assign({}, this.options, { gpus: 1, commTransport: transport });
     // no train runs longer than this without a message (options.gpuProcessTimeoutMs, 0 = no limit)
     const limitMs = this.options.gpuProcessTimeoutMs || 0;
     let timer = null;
@@ -224,11 +255,15 @@ class EmfLord extends EmfMaster {
     const run = all('ready', (k) => {
       const rank = kids.indexOf(k);
       k.send({ cmd: 'init', config: config || {}, options: opts, rank, world, commId, device: rank % devices, dataset: datasetSpec });
-    }).then(() => all('trained', (k) => k.send({ cmd: 'train' })));
+    }).then(() => { settingUp = false; return all('trained', (k) => k.send({ cmd: 'train' })); });
     const done = (x) => { if (timer) clearTimeout(timer); kids.forEach((k) => { k.finished = true; }); return x; };
     return (guarded ? Promise.race([run, guarded]) : run)
       .then((res) => { done(); stop(); return res[0]; },
-            (e) => { done(); stop(); kids.forEach((k) => { try { k.kill('SIGKILL'); } catch (e2) { /* gone */ } }); return Promise.reject(e); });
+            (e) => {
+              done(); stop(); kids.forEach((k) => { try { k.kill('SIGKILL'); } catch (e2) { /* gone */ } });
+              if (settingUp && e && typeof e == 'object') e.duringSetup = true;
+              return Promise.reject(e);
+            });
   }
 
   /** 2 steps - first fix item vectors and calc user vectors, then vice versa (EmfLord.js:954-958) */

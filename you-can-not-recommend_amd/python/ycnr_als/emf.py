@@ -53,6 +53,9 @@ def default_options():
         # the copy engines; also runs with several ranks on one GPU) or "shm" (functional stand-in: ranks of
         # one node stage rows through POSIX shared memory)
         "commTransport": "rccl",
+        # True: fail when commTransport cannot be set up on every rank (default: rccl <-> ipc are tried in turn, then
+        # torch.distributed's all-gather; exchangePath / commFallback say what ran and why)
+        "strictTransport": False,
         # multi-GPU only: after this many iterations (counted from the first one this Lord runs) the row shards
         # are cut again from the compute time every rank measured (0 = never); the static cut comes from a cost
         # model (row_cost), this is the feedback that corrects it -- the role of the reference's work-stealing
