@@ -304,9 +304,9 @@ def test_full_size_iteration(als, oracle, name):
     check_sample(oracle, torch, bi, ri, U1, V, k, "byItem_sample", rec)
     # the north star's flat 1e-5 against float64 at iteration 1, as fixed floors (round 5; before: only relative to the float32
     # oracle's own fraction, which would have let the HIP path regress silently): every sampled user row of every config and every
-    # item row of c3 / mal / c5shard; the longest item rows of c5 / big2g / big4g are where the measured maxima sit just above it
-    # (1.09e-5 / 1.06e-5 / 1.31e-5: conditioning times the chunks' float32 chains, DESIGN.md 4 -- the float32 ORACLE is at 6e-5 ... 1.4e-4 there)
-    item_floor = {"c5": 0.96, "big2g": 0.995, "big4g": 0.985}.get(name, 1.0)
+    # item row of c3 / mal / c5shard / c5 (c5 since whole rows are at most 8192 ratings long: 1.09e-5 -> 7.2e-6); the longest item rows of
+    # big2g / big4g are where the measured maxima sit just above it (1.06e-5 / 1.31e-5: DESIGN.md 4 -- the float32 ORACLE is at 1.1e-4 / 1.4e-4 there)
+    item_floor = {"big2g": 0.995, "big4g": 0.985}.get(name, 1.0)
     assert rec["byUser_sample"]["frac_le_1e-5_vs_oracle_f64"] == 1.0, rec["byUser_sample"]
     assert rec["byItem_sample"]["frac_le_1e-5_vs_oracle_f64"] >= item_floor, rec["byItem_sample"]
     assert rec["byItem_sample"]["max_vs_oracle_f64"] <= (1e-5 if item_floor == 1.0 else 1.5e-5), rec["byItem_sample"]

@@ -65,7 +65,12 @@ constexpr int64_t kPairBatchRows = 4096;   // rows per batch of that path (a sla
                                            // 136.3 / 136.2 / 136.5 / 137.3 / 139.7 / 138.6 / 137.6 -- short batches leave more of a batch's slabs in the
                                            // last-level cache for its solve, shorter ones pay two kernel tails per batch (YCNR_PAIR_BATCH_ROWS overrides)
 constexpr int kWgChunk = 8192;       // ratings per chunk of a row that is split over workgroups (k > 128)
-constexpr int kWgFusedMax = 16384;   // longest row one workgroup takes whole (k > 128)
+#ifndef YCNR_WG_FUSED_MAX
+#define YCNR_WG_FUSED_MAX 8192
+#endif
+constexpr int kWgFusedMax = YCNR_WG_FUSED_MAX;  // longest row one workgroup takes whole (k > 128).  16384 until round 5: a row's Gramian is ONE float32 chain over
+                                     // its ratings / 32 steps, and the item rows of the full C5 that missed the flat 1e-5 against float64 (2 of 54 sampled,
+                                     // 1.09e-5) were whole rows of 8 - 16 K ratings; at 8192: every sampled row within 7.2e-6, item half-step + 1 %
 constexpr int kDefaultChunk = 1024;  // ratings per split unit (and the largest fused row)
 constexpr int kMaxSlabsPerRow = 64;  // heavier rows get proportionally longer chunks
 constexpr int kMaxSlabsPerRowBig = 4096;  // k > 128 (chunks of kWgChunk ratings): an item of the full C5 has 10 M ratings; with 64 slabs its
